@@ -1,0 +1,71 @@
+"""In-tree build of the HIP/C-ABI library (gfx950 only).
+
+``python -m pitchextractor_amd.build`` or ``__graft_entry__.build()``.  hipcc
+cross-compiles without a GPU.  Objects are cached under ``csrc/_obj`` by source
+mtime; the shared object lands next to the package so it travels with the tree.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+CSRC = PKG_DIR / "csrc"
+OBJ_DIR = CSRC / "_obj"
+LIB_PATH = PKG_DIR / "libpitchextractor_hip.so"
+ARCH = "gfx950"
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+            "-fno-gpu-rdc"]
+
+
+def _sources():
+    return sorted(CSRC.glob("*.hip"))
+
+
+def _headers():
+    return sorted(CSRC.glob("*.h")) + sorted((PKG_DIR.parent / "include").glob("*.h"))
+
+
+def _needs(target: Path, deps) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(d.stat().st_mtime > t for d in deps)
+
+
+def _compile(src: Path, verbose: bool) -> Path:
+    obj = OBJ_DIR / (src.stem + ".o")
+    if _needs(obj, [src] + _headers()):
+        cmd = [HIPCC, *CXXFLAGS, "-c", str(src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return obj
+
+
+def build_library(force: bool = False, verbose: bool = True, jobs: int = 4) -> Path:
+    OBJ_DIR.mkdir(parents=True, exist_ok=True)
+    if force:
+        for o in OBJ_DIR.glob("*.o"):
+            o.unlink()
+    srcs = _sources()
+    if not srcs:
+        raise RuntimeError(f"no .hip sources under {CSRC}")
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        objs = list(ex.map(lambda s: _compile(s, verbose), srcs))
+    if force or _needs(LIB_PATH, objs):
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc",
+               "-o", str(LIB_PATH), *map(str, objs)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    build_library(force="--force" in sys.argv)
+    print(LIB_PATH)

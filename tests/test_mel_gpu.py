@@ -1,0 +1,100 @@
+"""HIP mel front end vs the float64 oracle (oracle/mel_ref.py), through the C ABI.
+
+Tolerances (north_star: 1e-4 rel for fp32 floating point, bit-exact framing):
+* frame count / padding / layout: exact;
+* mel power: 1e-4 relative on every bin above the fp32 FFT rounding floor (>= 1e-2; the
+  frame peak is ~4e4, so smaller bins carry |dX| ~ 1e-8 |X|max of rounding noise and two
+  fp32 implementations already disagree there -- see tests/test_oracle_mel.py);
+* normalised log-mel: 1e-3 absolute everywhere (the 1e-5 log floor amplifies that noise).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mel_ref
+from pitchextractor_amd import synthetic
+from pitchextractor_amd.mel import MelSpectrogram
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_power(got, ref):
+    assert got.shape == ref.shape
+    strong = ref >= 1e-2
+    rel = np.abs(got - ref)[strong] / ref[strong]
+    assert rel.max() <= 1e-4, rel.max()
+    lg, lr = mel_ref.log_normalise(got.astype(np.float64)), mel_ref.log_normalise(ref)
+    assert np.abs(lg - lr).max() <= 1e-3
+
+
+def test_sweeps_match_oracle(hip_device):
+    waves, _, _ = synthetic.batch(0, 4)
+    tf = MelSpectrogram(**{k: v for k, v in mel_ref.DEFAULT_MEL_PARAMS.items()})
+    got = tf(torch.from_numpy(waves).to(hip_device)).cpu().numpy()
+    assert got.shape == (4, 80, 161)
+    for i in range(4):
+        _check_power(got[i], mel_ref.mel_spectrogram(waves[i]))
+
+
+@pytest.mark.parametrize("n", [513, 899, 900, 1000, 4799, 4800, 4801, 58624])
+def test_ragged_lengths_and_noise(hip_device, n):
+    rng = np.random.default_rng(n)
+    wave = (0.3 * rng.standard_normal(n)).astype(np.float32)
+    tf = MelSpectrogram()
+    got = tf(torch.from_numpy(wave).to(hip_device)).cpu().numpy()
+    assert got.shape == (80, 1 + n // 300)
+    _check_power(got, mel_ref.mel_spectrogram(wave))
+
+
+def test_log_mel_batch_layout_and_padding(hip_device):
+    waves, _, _ = synthetic.batch(10, 3)
+    tf = MelSpectrogram()
+    out = tf.log_mel_batch(torch.from_numpy(waves).to(hip_device))
+    assert out.shape == (3, 1, 80, 192) and out.is_contiguous()
+    got = out.cpu().numpy()
+    assert (got[:, :, :, 161:] == 0).all()            # Collater zero padding, bit exact
+    for i in range(3):
+        ref = mel_ref.log_mel(waves[i])
+        assert np.abs(got[i, 0, :, :161] - ref).max() <= 1e-3
+
+
+def test_transposed_output_layout(hip_device):
+    """Frame-major output (what the model consumes after x.transpose(-1, -2)) is the same numbers."""
+    waves, _, _ = synthetic.batch(20, 2)
+    tf = MelSpectrogram()
+    dev = torch.from_numpy(waves).to(hip_device)
+    a = tf.log_mel_batch(dev)
+    bt = torch.empty((2, 1, 192, 80), device=hip_device)
+    tf._run(dev, bt, (bt.stride(0), bt.stride(3), bt.stride(2)), 192, 1, 0.0)
+    assert torch.equal(a, bt.transpose(-1, -2))
+
+
+def test_truncation_to_max_frames(hip_device):
+    n = 58624   # reference pre-crop length at 24 kHz -> 196 frames > 192
+    wave = (0.1 * np.random.default_rng(1).standard_normal(n)).astype(np.float32)
+    tf = MelSpectrogram()
+    out = tf.log_mel_batch(torch.from_numpy(wave)[None].to(hip_device)).cpu().numpy()
+    ref = mel_ref.log_mel(wave)[:, :192]
+    assert np.abs(out[0, 0] - ref).max() <= 1e-3
+
+
+def test_full_size_scaling_property(hip_device):
+    """BASELINE size (B=256, 2 s): mel(2x) == 4 mel(x) bit for bit (power-of-two scaling is exact)."""
+    waves, _, _ = synthetic.batch(0, 8)
+    big = torch.from_numpy(np.tile(waves, (32, 1))).to(hip_device)
+    tf = MelSpectrogram()
+    a = tf(big)
+    b = tf(big * 2.0)
+    assert a.shape == (256, 80, 161)
+    assert torch.equal(a * 4.0, b)
+    assert torch.equal(a[:8], a[248:])                  # replicas agree: no cross-block leakage
+
+
+def test_rejects_bad_arguments(hip_device):
+    tf = MelSpectrogram()
+    with pytest.raises(RuntimeError):
+        tf(torch.zeros(4800))                            # CPU tensor: no fallback
+    with pytest.raises(RuntimeError):
+        tf(torch.zeros(512, device=hip_device))          # reflect pad needs N > n_fft/2
+    with pytest.raises(RuntimeError):
+        MelSpectrogram(n_fft=2048, win_length=2048)(torch.zeros(4800, device=hip_device))

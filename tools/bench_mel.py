@@ -1,0 +1,32 @@
+"""Micro-benchmark of the mel kernel alone (B=256, 2 s @ 24 kHz): HBM roofline fraction."""
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from pitchextractor_amd import synthetic
+from pitchextractor_amd.mel import MelSpectrogram
+
+B, reps = 256, 200
+waves, _, _ = synthetic.batch(0, 8)
+dev = torch.device("cuda:0")
+x = torch.from_numpy(np.tile(waves, (B // 8, 1))).to(dev)
+tf = MelSpectrogram()
+out = torch.empty((B, 1, 80, 192), device=dev)
+for _ in range(10):
+    tf.log_mel_batch(x, out=out)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(reps):
+    tf.log_mel_batch(x, out=out)
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / reps
+frames = B * 161
+alg_bytes = 1520 * frames
+print(json.dumps({"kernel": "mel_fwd", "ms": ms, "frames_per_s": frames / ms * 1e3,
+                  "alg_GBps": alg_bytes / ms / 1e6, "frac_of_8TBps": alg_bytes / ms / 1e6 / 8000}))
