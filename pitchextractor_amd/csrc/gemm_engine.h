@@ -1,0 +1,270 @@
+// fp32 MFMA tile engines for gfx950 (v_mfma_f32_32x32x2_f32: exact-f32 fmaf chains).
+//
+// Two main loops, both 256 threads = 4 waves, BK = 32, register-prefetched single LDS stage:
+//
+//   NT:  C[m][n] = sum_k A[m][k] * B[n][k]   both operands k-contiguous in memory.
+//        LDS images are [row][36] floats (32 + one 16-byte pad: conflict-free ds_read_b128).
+//        Lane (r = lane & 31, h = lane >> 5) reads 4 consecutive k with one ds_read_b128 and
+//        feeds 4 MFMAs; MFMA j of an 8-k block covers k = {j, 4 + j} (the k order inside a
+//        block is a free permutation as long as A and B agree).
+//
+//   TN:  C[m][n] = sum_k A[k][m] * B[k][n]   both operands k-major (weight-gradient GEMMs,
+//        k = pixels or batch*time).  LDS images are [k][cols]; operands come from
+//        conflict-free ds_read_b32 (32 consecutive lanes -> 32 consecutive columns).
+//
+// MFMA 32x32x2 maps (cdna_hip_programming.md section 3): A operand lane l holds A[i = l & 31][k = l >> 5],
+// B operand lane l holds B[k = l >> 5][j = l & 31]; accumulator register g of lane l is
+// C[row = (g & 3) + 8 * (g >> 2) + 4 * (l >> 5)][col = l & 31].
+#pragma once
+#include "common.h"
+
+namespace pe {
+
+constexpr int kBK = 32;
+constexpr int kLdsStride = kBK + 4;
+
+template <int BM_, int BN_, int WAVES_M_, int WAVES_N_>
+struct Tile {
+  static constexpr int BM = BM_, BN = BN_;
+  static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_;
+  static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  static constexpr int TM = WM / 32, TN = WN / 32;
+  static constexpr int A_LOADS = BM / 32, B_LOADS = BN / 32;   // float4 per thread per k-tile
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+  static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile is a multiple of the 32x32 MFMA");
+};
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// XCD-aware tile order: workgroups b and b+8 share an XCD (and its L2); give every XCD a
+// contiguous run of tiles so neighbouring tiles (shared halo rows / operand panels) hit the
+// same L2.  Bijective for any tile count.
+__device__ __forceinline__ int xcd_remap(int bid, int ntiles) {
+  const int q = ntiles >> 3, r = ntiles & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// ------------------------------------------------------------------ operand loaders (NT)
+// A loader hands out float4 = 4 consecutive k of one row.  `slot` i in [0, LOADS) addresses
+// row (tid >> 3) + 32 * i of the tile; k4 = (tid & 7) * 4 within the 32-wide k-tile.
+
+struct RowLoader {            // plain row-major matrix, rows x K, leading dimension ld
+  const float* p;
+  long ld;
+  int rows, K;
+  int row0;
+  __device__ __forceinline__ void init(int first_row) { row0 = first_row + (threadIdx.x >> 3); }
+  __device__ __forceinline__ float4 load(int slot, int kt) const {
+    const int row = row0 + 32 * slot;
+    const int k = kt * kBK + (threadIdx.x & 7) * 4;
+    if (row < rows && k < K) return *reinterpret_cast<const float4*>(p + (long)row * ld + k);
+    return make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+};
+
+template <int SLOTS>
+struct ConvLoader {           // implicit im2col of a channels-last [B][T][F][C] tensor, 3x3, pad 1
+  const float* p;
+  int T, F, C, rows;          // rows = B*T*F output pixels; K = 9*C ordered (kh, kw, c)
+  int t_[SLOTS], f_[SLOTS];
+  long base_[SLOTS];
+  bool ok_[SLOTS];
+  __device__ __forceinline__ void init(int first_row) {
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+      const int row = first_row + (threadIdx.x >> 3) + 32 * i;
+      ok_[i] = row < rows;
+      const int r = ok_[i] ? row : 0;
+      f_[i] = r % F;
+      t_[i] = (r / F) % T;
+      base_[i] = (long)r * C;
+    }
+  }
+  __device__ __forceinline__ float4 load(int slot, int kt) const {
+    const int kbase = kt * kBK;             // wave-uniform
+    const int tap = kbase / C;              // C % 32 == 0: a k-tile never straddles taps
+    const int c = kbase - tap * C + (threadIdx.x & 7) * 4;
+    const int dt = tap / 3 - 1, df = tap % 3 - 1;
+    const int tt = t_[slot] + dt, ff = f_[slot] + df;
+    if (ok_[slot] && tt >= 0 && tt < T && ff >= 0 && ff < F)
+      return *reinterpret_cast<const float4*>(p + base_[slot] + (long)(dt * F + df) * C + c);
+    return make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+};
+
+// ------------------------------------------------------------------ NT main loop
+template <class TL, class AL, class BL>
+__device__ __forceinline__ void nt_mainloop(AL& al, BL& bl, int K, float* As, float* Bs,
+                                            f32x16 (&acc)[TL::TM][TL::TN]) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm = wv / TL::WAVES_N, wn = wv % TL::WAVES_N;
+  const int r = lane & 31, h = lane >> 5;
+  const int nk = (K + kBK - 1) / kBK;
+  float4 ra[TL::A_LOADS], rb[TL::B_LOADS];
+#pragma unroll
+  for (int i = 0; i < TL::A_LOADS; ++i) ra[i] = al.load(i, 0);
+#pragma unroll
+  for (int i = 0; i < TL::B_LOADS; ++i) rb[i] = bl.load(i, 0);
+
+  const int st_off = (tid >> 3) * kLdsStride + (tid & 7) * 4;
+  const float* a_rd = As + (wm * TL::WM + r) * kLdsStride + h * 4;
+  const float* b_rd = Bs + (wn * TL::WN + r) * kLdsStride + h * 4;
+
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TL::A_LOADS; ++i)
+      *reinterpret_cast<float4*>(As + st_off + i * 32 * kLdsStride) = ra[i];
+#pragma unroll
+    for (int i = 0; i < TL::B_LOADS; ++i)
+      *reinterpret_cast<float4*>(Bs + st_off + i * 32 * kLdsStride) = rb[i];
+    __syncthreads();
+    if (kt + 1 < nk) {
+#pragma unroll
+      for (int i = 0; i < TL::A_LOADS; ++i) ra[i] = al.load(i, kt + 1);
+#pragma unroll
+      for (int i = 0; i < TL::B_LOADS; ++i) rb[i] = bl.load(i, kt + 1);
+    }
+#pragma unroll
+    for (int k8 = 0; k8 < kBK / 8; ++k8) {
+      float4 fa[TL::TM], fb[TL::TN];
+#pragma unroll
+      for (int i = 0; i < TL::TM; ++i)
+        fa[i] = *reinterpret_cast<const float4*>(a_rd + i * 32 * kLdsStride + k8 * 8);
+#pragma unroll
+      for (int j = 0; j < TL::TN; ++j)
+        fb[j] = *reinterpret_cast<const float4*>(b_rd + j * 32 * kLdsStride + k8 * 8);
+#pragma unroll
+      for (int i = 0; i < TL::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TL::TN; ++j) {
+          acc[i][j] = mfma32(fa[i].x, fb[j].x, acc[i][j]);
+          acc[i][j] = mfma32(fa[i].y, fb[j].y, acc[i][j]);
+          acc[i][j] = mfma32(fa[i].z, fb[j].z, acc[i][j]);
+          acc[i][j] = mfma32(fa[i].w, fb[j].w, acc[i][j]);
+        }
+    }
+  }
+}
+
+// Visit every accumulator element of this lane: fn(row_in_tile, col_in_tile, value).
+template <class TL, class FN>
+__device__ __forceinline__ void for_each_acc(const f32x16 (&acc)[TL::TM][TL::TN], FN&& fn) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wm = wv / TL::WAVES_N, wn = wv % TL::WAVES_N;
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < TL::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TL::TN; ++j)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int row = wm * TL::WM + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+        const int col = wn * TL::WN + j * 32 + r;
+        fn(row, col, acc[i][j][g]);
+      }
+}
+
+template <class TL>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[TL::TM][TL::TN]) {
+#pragma unroll
+  for (int i = 0; i < TL::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TL::TN; ++j)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.0f;
+}
+
+// ------------------------------------------------------------------ operand loaders (TN)
+// A TN loader hands out float4 = 4 consecutive columns of one k-row.  `slot` i addresses
+// k-row (tid >> 5) + 8 * i of the 32-row k-tile; col4 = (tid & 31) * 4 (tiles are 128 columns).
+
+struct KRowLoader {           // plain [K][cols] matrix
+  const float* p;
+  long ld;
+  int cols;
+  int col0;
+  __device__ __forceinline__ void init(int first_col) { col0 = first_col + (threadIdx.x & 31) * 4; }
+  __device__ __forceinline__ float4 load(int slot, int k0, int k_end) const {
+    const int k = k0 + (threadIdx.x >> 5) + 8 * slot;
+    if (k < k_end && col0 < cols) return *reinterpret_cast<const float4*>(p + (long)k * ld + col0);
+    return make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+};
+
+struct ShiftedPixelLoader {   // [B*T*F][C] channels-last tensor read at pixel + (dt, df), zero outside
+  const float* p;
+  int T, F, C, dt, df;
+  int cols;                   // = C
+  int col0;
+  __device__ __forceinline__ void init(int first_col) { col0 = first_col + (threadIdx.x & 31) * 4; }
+  __device__ __forceinline__ float4 load(int slot, int k0, int k_end) const {
+    const int k = k0 + (threadIdx.x >> 5) + 8 * slot;
+    if (k < k_end && col0 < cols) {
+      const int f = k % F, t = (k / F) % T;
+      const int tt = t + dt, ff = f + df;
+      if (tt >= 0 && tt < T && ff >= 0 && ff < F)
+        return *reinterpret_cast<const float4*>(p + ((long)k + dt * F + df) * C + col0);
+    }
+    return make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+};
+
+struct ShiftedTimeLoader {    // [B][T][ld] sequence read at time t + dt (zero outside): h_{t-1} for dW_hh
+  const float* p;
+  long ld;
+  int T, dt, cols;
+  int col0;
+  __device__ __forceinline__ void init(int first_col) { col0 = first_col + (threadIdx.x & 31) * 4; }
+  __device__ __forceinline__ float4 load(int slot, int k0, int k_end) const {
+    const int k = k0 + (threadIdx.x >> 5) + 8 * slot;
+    if (k < k_end && col0 < cols) {
+      const int t = k % T + dt;
+      if (t >= 0 && t < T) return *reinterpret_cast<const float4*>(p + ((long)k + dt) * ld + col0);
+    }
+    return make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+};
+
+// ------------------------------------------------------------------ TN main loop (128x128 tile)
+// As/Bs: [32][128] floats each.  k range [k_begin, k_end).
+template <class AL, class BL>
+__device__ __forceinline__ void tn_mainloop(AL& al, BL& bl, int k_begin, int k_end, float* As, float* Bs,
+                                            f32x16 (&acc)[2][2]) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm = wv >> 1, wn = wv & 1;
+  const int r = lane & 31, h = lane >> 5;
+  float4 ra[4], rb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { ra[i] = al.load(i, k_begin, k_end); rb[i] = bl.load(i, k_begin, k_end); }
+  const int st_off = (tid >> 5) * 128 + (tid & 31) * 4;
+  const float* a_rd = As + h * 128 + wm * 64 + r;
+  const float* b_rd = Bs + h * 128 + wn * 64 + r;
+  for (int k0 = k_begin; k0 < k_end; k0 += kBK) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<float4*>(As + st_off + i * 8 * 128) = ra[i];
+      *reinterpret_cast<float4*>(Bs + st_off + i * 8 * 128) = rb[i];
+    }
+    __syncthreads();
+    if (k0 + kBK < k_end) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { ra[i] = al.load(i, k0 + kBK, k_end); rb[i] = bl.load(i, k0 + kBK, k_end); }
+    }
+#pragma unroll
+    for (int s = 0; s < kBK / 2; ++s) {
+      const float a0 = a_rd[s * 256], a1 = a_rd[s * 256 + 32];
+      const float b0 = b_rd[s * 256], b1 = b_rd[s * 256 + 32];
+      acc[0][0] = mfma32(a0, b0, acc[0][0]);
+      acc[0][1] = mfma32(a0, b1, acc[0][1]);
+      acc[1][0] = mfma32(a1, b0, acc[1][0]);
+      acc[1][1] = mfma32(a1, b1, acc[1][1]);
+    }
+  }
+}
+
+}  // namespace pe

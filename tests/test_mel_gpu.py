@@ -40,7 +40,7 @@ def test_sweeps_match_oracle(hip_device):
 def test_ragged_lengths_and_noise(hip_device, n):
     rng = np.random.default_rng(n)
     wave = (0.3 * rng.standard_normal(n)).astype(np.float32)
-    tf = MelSpectrogram()
+    tf = MelSpectrogram(**mel_ref.DEFAULT_MEL_PARAMS)
     got = tf(torch.from_numpy(wave).to(hip_device)).cpu().numpy()
     assert got.shape == (80, 1 + n // 300)
     _check_power(got, mel_ref.mel_spectrogram(wave))
@@ -48,7 +48,7 @@ def test_ragged_lengths_and_noise(hip_device, n):
 
 def test_log_mel_batch_layout_and_padding(hip_device):
     waves, _, _ = synthetic.batch(10, 3)
-    tf = MelSpectrogram()
+    tf = MelSpectrogram(**mel_ref.DEFAULT_MEL_PARAMS)
     out = tf.log_mel_batch(torch.from_numpy(waves).to(hip_device))
     assert out.shape == (3, 1, 80, 192) and out.is_contiguous()
     got = out.cpu().numpy()
@@ -61,7 +61,7 @@ def test_log_mel_batch_layout_and_padding(hip_device):
 def test_transposed_output_layout(hip_device):
     """Frame-major output (what the model consumes after x.transpose(-1, -2)) is the same numbers."""
     waves, _, _ = synthetic.batch(20, 2)
-    tf = MelSpectrogram()
+    tf = MelSpectrogram(**mel_ref.DEFAULT_MEL_PARAMS)
     dev = torch.from_numpy(waves).to(hip_device)
     a = tf.log_mel_batch(dev)
     bt = torch.empty((2, 1, 192, 80), device=hip_device)
@@ -72,7 +72,7 @@ def test_transposed_output_layout(hip_device):
 def test_truncation_to_max_frames(hip_device):
     n = 58624   # reference pre-crop length at 24 kHz -> 196 frames > 192
     wave = (0.1 * np.random.default_rng(1).standard_normal(n)).astype(np.float32)
-    tf = MelSpectrogram()
+    tf = MelSpectrogram(**mel_ref.DEFAULT_MEL_PARAMS)
     out = tf.log_mel_batch(torch.from_numpy(wave)[None].to(hip_device)).cpu().numpy()
     ref = mel_ref.log_mel(wave)[:, :192]
     assert np.abs(out[0, 0] - ref).max() <= 1e-3
@@ -82,7 +82,7 @@ def test_full_size_scaling_property(hip_device):
     """BASELINE size (B=256, 2 s): mel(2x) == 4 mel(x) bit for bit (power-of-two scaling is exact)."""
     waves, _, _ = synthetic.batch(0, 8)
     big = torch.from_numpy(np.tile(waves, (32, 1))).to(hip_device)
-    tf = MelSpectrogram()
+    tf = MelSpectrogram(**mel_ref.DEFAULT_MEL_PARAMS)
     a = tf(big)
     b = tf(big * 2.0)
     assert a.shape == (256, 80, 161)
@@ -91,7 +91,7 @@ def test_full_size_scaling_property(hip_device):
 
 
 def test_rejects_bad_arguments(hip_device):
-    tf = MelSpectrogram()
+    tf = MelSpectrogram(**mel_ref.DEFAULT_MEL_PARAMS)
     with pytest.raises(RuntimeError):
         tf(torch.zeros(4800))                            # CPU tensor: no fallback
     with pytest.raises(RuntimeError):

@@ -14,7 +14,7 @@ B, reps = 256, 200
 waves, _, _ = synthetic.batch(0, 8)
 dev = torch.device("cuda:0")
 x = torch.from_numpy(np.tile(waves, (B // 8, 1))).to(dev)
-tf = MelSpectrogram()
+tf = MelSpectrogram(sample_rate=24000, n_fft=1024, win_length=1024, hop_length=300, n_mels=80)
 out = torch.empty((B, 1, 80, 192), device=dev)
 for _ in range(10):
     tf.log_mel_batch(x, out=out)
