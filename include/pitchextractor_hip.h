@@ -62,6 +62,112 @@ int pe_mel_forward(const pe_mel_plan* plan, const float* wave, int batch, int n_
                    int out_frames, int log_mode, float log_eps, float mean, float std,
                    float pad_value, void* stream);
 
+
+/* ---- dense fp32 GEMMs on the MFMA engine -----------------------------------
+ * pe_gemm_nt: C[M][N] = A[M][K] . B[N][K]^T + bias0[n] + bias1[n] (+ C when accumulate).
+ *   nn.Linear / LSTM input projection (model.py:220-227) / 1x1 convs (model.py:53,167).
+ * pe_gemm_tn: C[M][N] = sum_k A[k][m] * B[k][n] (+ C): weight gradients, k split across
+ *   workgroups into workspace slabs that are reduced in a fixed order (deterministic). */
+int pe_gemm_nt(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
+               int K, const float* bias0, const float* bias1, int accumulate, void* stream);
+size_t pe_gemm_tn_workspace_bytes(int M, int N, int K);
+int pe_gemm_tn(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
+               int K, int accumulate, float* workspace, size_t workspace_bytes, void* stream);
+int pe_transpose2d(const float* in, float* out, int rows, int cols, void* stream);
+
+/* ---- 3x3 / pad 1 convolutions (model.py:23-28,157-161), channels-last -------
+ * pe_conv3x3_repack: OIHW weights -> w_fwd [Cout][kh][kw][Cin] and/or the flipped, transposed
+ *   w_dgrad [Cin][2-kh][2-kw][Cout] (either may be NULL).
+ * pe_conv3x3_fwd:  y[B][T][F][N] (+)= conv(x[B][T][F][C], w_packed[N][9*C]); the data gradient
+ *   is the same call with (dy, w_dgrad, C = Cout, N = Cin).
+ * pe_conv3x3_wgrad: dw (OIHW) = sum_pixels dy (x) shifted x.
+ * pe_conv3x3_c1_*: the Cin = 1 first layer; x element (b,t,f) at x[b*sb + t*st + f*sf]. */
+int pe_conv3x3_repack(const float* w_oihw, float* w_fwd, float* w_dgrad, int Cout, int Cin, void* stream);
+int pe_conv3x3_fwd(const float* x, const float* w_packed, float* y, int B, int T, int F, int C, int N,
+                   int accumulate, void* stream);
+size_t pe_conv3x3_wgrad_workspace_bytes(int B, int T, int F, int Cin, int Cout);
+int pe_conv3x3_wgrad(const float* x, const float* dy, float* dw_oihw, int B, int T, int F, int Cin,
+                     int Cout, float* workspace, size_t workspace_bytes, void* stream);
+int pe_conv3x3_c1_fwd(const float* x, long sb, long st, long sf, const float* w_oihw, float* y, int B,
+                      int T, int F, void* stream);
+int pe_conv3x3_c1_wgrad(const float* x, long sb, long st, long sf, const float* dy, float* dw_oihw,
+                        int B, int T, int F, float* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- BatchNorm2d (train statistics) / LeakyReLU / MaxPool2d((1,k)) / dropout -
+ * Activations are [rows = B*T][F][C].  pe_bn_train_stats: batch mean / biased variance over all
+ * n_pix = rows*F pixels (model.py:25,37,54,150,159), running-stat update with `momentum` and the
+ * unbiased variance, plus the fused affine scale = gamma*invstd, shift = beta - mean*scale.
+ * pe_bn_act_pool_fwd: y = maxpool_k(lrelu(x*scale + shift)) written at
+ *   y[(row*Fout + fo)*ldy + coff + c] (model.py:36-41,148-153).
+ * pe_bn_act_pool_bwd: gradient of that block w.r.t. x, gamma, beta (train-mode BN). */
+size_t pe_bn_workspace_bytes(int C);
+int pe_bn_train_stats(const float* x, long n_pix, int C, const float* gamma, const float* beta, float eps,
+                      float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
+                      float* scale, float* shift, void* workspace, size_t workspace_bytes, void* stream);
+int pe_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                      const float* running_var, float eps, int C, float* scale, float* shift, void* stream);
+int pe_bn_act_pool_fwd(const float* x, const float* scale, const float* shift, float slope, float* y,
+                       long rows, int Fin, int C, int pool, long ldy, int coff, void* stream);
+int pe_bn_act_pool_bwd(const float* x, const float* dy, const float* scale, const float* shift,
+                       const float* mean, const float* invstd, float slope, float* dx, float* dgamma,
+                       float* dbeta, long rows, int Fin, int C, int pool, long lddy, int coff,
+                       void* workspace, size_t workspace_bytes, void* stream);
+/* detector-branch MaxPool2d((1,40|20|10)) (model.py:45-49,103-105) into a channel slice */
+int pe_maxpool_fwd(const float* x, float* y, long rows, int Fin, int C, int pool, long ldy, int coff,
+                   void* stream);
+int pe_maxpool_bwd_add(const float* x, const float* dy, float* dx, long rows, int Fin, int C, int pool,
+                       long lddy, int coff, void* stream);
+/* nn.Dropout (model.py:40,56; LSTM inter-layer): Philox4x32-10 keyed by (seed, offset + quad index);
+ * mask bytes (1 = kept) can be exported (mask_out) or replayed (mask_in). */
+int pe_dropout_fwd(const float* x, long ldx, float* y, long ldy, const unsigned char* mask_in,
+                   unsigned char* mask_out, long rows, int cols, float p, unsigned long long seed,
+                   unsigned long long offset, void* stream);
+/* (B,256,T,2) -> permute(0,2,1,3) -> (B,T,512) of model.py:93,112 and its transpose */
+int pe_nhwc_to_seq(const float* x, long ldx, int coff, float* seq, long rows, int C, void* stream);
+int pe_seq_to_nhwc(const float* seq, float* x, long ldx, int coff, long rows, int C, int accumulate,
+                   void* stream);
+int pe_copy2d(const float* src, long lds, float* dst, long ldd, long rows, int cols, int accumulate,
+              void* stream);
+
+/* ---- LSTM recurrence (nn.LSTM of model.py:218-227; gates i,f,g,o; zero initial state) ----
+ * Up to 4 cells (directions x models) advance together, one launch per time step.
+ * pe_lstm_fwd:  gates[c] holds X.W_ih^T + b_ih + b_hh on entry ([B][T][4H]) and the activated gates
+ *   on exit; y[c] (already offset to this direction's H-wide slice, row stride ldy) receives h_t,
+ *   cbuf[c] ([B][T][H]) the cell states.
+ * pe_lstm_bwd:  gates[c] holds activated gates on entry and d(pre-activation gates) on exit;
+ *   whh_t[c] = W_hh^T [H][4H]; dy[c] = dL/dh (same addressing as y); dcarry[c] = [B][H] scratch. */
+int pe_lstm_fwd(int ncells, const float* const* whh, float* const* gates, float* const* y,
+                float* const* cbuf, const int* reverse, long ldy, int B, int T, int H, void* stream);
+int pe_lstm_bwd(int ncells, const float* const* whh_t, float* const* gates, const float* const* cbuf,
+                const float* const* dy, float* const* dcarry, const int* reverse, long lddy, int B, int T,
+                int H, void* stream);
+size_t pe_lstm_whh_grad_workspace_bytes(int B, int T, int H);
+int pe_lstm_whh_grad(const float* dgates, const float* y, long ldy, float* dwhh, int B, int T, int H,
+                     int reverse, float* workspace, size_t workspace_bytes, void* stream);
+size_t pe_colsum_workspace_bytes(int cols);
+int pe_colsum(const float* x, long rows, int cols, long ld, float* out0, float* out1, void* workspace,
+              size_t workspace_bytes, void* stream);
+
+/* ---- heads, losses, optimiser ------------------------------------------------
+ * pe_head_fwd: y[r] = sum_{o<n_out} (x[r].w[o] + bias[o]) -- Linear(D,1) (n_out 1) and
+ *   Linear(D,2).sum(-1) (n_out 2) of model.py:67-70,96-98,115-117.
+ * pe_f0_sil_loss: out3 = {lambda*SmoothL1 + BCE, lambda*SmoothL1, BCE} (train.py:104-106,
+ *   trainer.py:237-239) and the gradients w.r.t. both prediction vectors (times grad_scale).
+ * pe_adamw_step: torch.optim.AdamW (optimizers.py:55-62) on a flat buffer; the caller passes the
+ *   current lr / beta1 (OneCycleLR rewrites both every step) and the bias corrections
+ *   1 - beta^step computed in double. Gradients are multiplied by grad_scale first. */
+int pe_head_fwd(const float* x, long ldx, const float* w, const float* bias, int n_out, float* y, long R,
+                int D, void* stream);
+size_t pe_head_bwd_workspace_bytes(int D);
+int pe_head_bwd(const float* x, long ldx, const float* w, const float* dy, int n_out, float* dx, long lddx,
+                float* dw, float* db, long R, int D, void* workspace, size_t workspace_bytes, void* stream);
+int pe_f0_sil_loss(const float* f0_pred, const float* f0, const float* sil_pred, const float* sil,
+                   float lambda_f0, long R, float grad_scale, float* out3, float* d_f0_pred,
+                   float* d_sil_pred, void* stream);
+int pe_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, double bias_correction1,
+                  double bias_correction2, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

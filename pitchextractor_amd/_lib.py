@@ -24,6 +24,10 @@ _i = C.c_int
 _l = C.c_long
 _f = C.c_float
 _d = C.c_double
+_z = C.c_size_t
+_u64 = C.c_ulonglong
+_pp = C.POINTER(C.c_void_p)
+_ip = C.POINTER(C.c_int)
 
 # name -> (restype, argtypes).  Mirrors include/pitchextractor_hip.h one to one;
 # tests/test_abi.py checks the two against each other and against the .so.
@@ -34,6 +38,38 @@ PROTOTYPES = {
     "pe_mel_plan_destroy": (_i, [_p]),
     "pe_mel_num_frames": (_i, [_p, _i]),
     "pe_mel_forward": (_i, [_p, _p, _i, _i, _l, _p, _l, _l, _l, _i, _i, _f, _f, _f, _f, _p]),
+    "pe_gemm_nt": (_i, [_p, _l, _p, _l, _p, _l, _i, _i, _i, _p, _p, _i, _p]),
+    "pe_gemm_tn_workspace_bytes": (_z, [_i, _i, _i]),
+    "pe_gemm_tn": (_i, [_p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _p, _z, _p]),
+    "pe_transpose2d": (_i, [_p, _p, _i, _i, _p]),
+    "pe_conv3x3_repack": (_i, [_p, _p, _p, _i, _i, _p]),
+    "pe_conv3x3_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "pe_conv3x3_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
+    "pe_conv3x3_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "pe_conv3x3_c1_fwd": (_i, [_p, _l, _l, _l, _p, _p, _i, _i, _i, _p]),
+    "pe_conv3x3_c1_wgrad": (_i, [_p, _l, _l, _l, _p, _p, _i, _i, _i, _p, _z, _p]),
+    "pe_bn_workspace_bytes": (_z, [_i]),
+    "pe_bn_train_stats": (_i, [_p, _l, _i, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "pe_bn_eval_affine": (_i, [_p, _p, _p, _p, _f, _i, _p, _p, _p]),
+    "pe_bn_act_pool_fwd": (_i, [_p, _p, _p, _f, _p, _l, _i, _i, _i, _l, _i, _p]),
+    "pe_bn_act_pool_bwd": (_i, [_p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _l, _i, _i, _i, _l, _i, _p, _z, _p]),
+    "pe_maxpool_fwd": (_i, [_p, _p, _l, _i, _i, _i, _l, _i, _p]),
+    "pe_maxpool_bwd_add": (_i, [_p, _p, _p, _l, _i, _i, _i, _l, _i, _p]),
+    "pe_dropout_fwd": (_i, [_p, _l, _p, _l, _p, _p, _l, _i, _f, _u64, _u64, _p]),
+    "pe_nhwc_to_seq": (_i, [_p, _l, _i, _p, _l, _i, _p]),
+    "pe_seq_to_nhwc": (_i, [_p, _p, _l, _i, _l, _i, _i, _p]),
+    "pe_copy2d": (_i, [_p, _l, _p, _l, _l, _i, _i, _p]),
+    "pe_lstm_fwd": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _p]),
+    "pe_lstm_bwd": (_i, [_i, _pp, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _p]),
+    "pe_lstm_whh_grad_workspace_bytes": (_z, [_i, _i, _i]),
+    "pe_lstm_whh_grad": (_i, [_p, _p, _l, _p, _i, _i, _i, _i, _p, _z, _p]),
+    "pe_colsum_workspace_bytes": (_z, [_i]),
+    "pe_colsum": (_i, [_p, _l, _i, _l, _p, _p, _p, _z, _p]),
+    "pe_head_fwd": (_i, [_p, _l, _p, _p, _i, _p, _l, _i, _p]),
+    "pe_head_bwd_workspace_bytes": (_z, [_i]),
+    "pe_head_bwd": (_i, [_p, _l, _p, _p, _i, _p, _l, _p, _p, _l, _i, _p, _z, _p]),
+    "pe_f0_sil_loss": (_i, [_p, _p, _p, _p, _f, _l, _f, _p, _p, _p, _p]),
+    "pe_adamw_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _d, _d, _f, _p]),
 }
 
 

@@ -1,0 +1,301 @@
+// 3x3 / pad-1 convolutions of the JDCNet stack (model.py:23-28,157-161) as implicit GEMMs on the
+// fp32 MFMA engine, activations channels-last [B][T][F][C].
+//
+//   forward / data-gradient:  Y[p][n] = sum_{tap,c} X[p + tap][c] * Wp[n][tap][c]   (NT engine,
+//       im2col gathered on the fly by ConvLoader; dgrad is the same kernel on flipped, transposed
+//       weights);
+//   weight gradient:          dW[n][tap][c] = sum_p dY[p][n] * X[p + tap][c]         (TN engine,
+//       pixels split across workgroups, per-split slabs reduced in a fixed order -> deterministic);
+//   first layer (Cin = 1, model.py:24): 9 FMAs per output, HBM-bound on the 64-channel write.
+#include "gemm_engine.h"
+
+namespace {
+using namespace pe;
+
+// ---------------------------------------------------------------- weight repack (OIHW -> packed)
+__global__ void repack3x3_kernel(const float* __restrict__ w, float* __restrict__ w_fwd,
+                                 float* __restrict__ w_dgrad, int Cout, int Cin) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Cout * Cin * 9) return;
+  const int tap = idx % 9, ci = (idx / 9) % Cin, co = idx / (9 * Cin);
+  const float v = w[idx];
+  if (w_fwd) w_fwd[((long)co * 9 + tap) * Cin + ci] = v;
+  if (w_dgrad) w_dgrad[((long)ci * 9 + (8 - tap)) * Cout + co] = v;   // (2-kh)*3 + (2-kw) = 8 - tap
+}
+
+__global__ void transpose2d_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + threadIdx.x;
+    tile[i][threadIdx.x] = (r < rows && c < cols) ? in[(long)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + threadIdx.x;
+    if (r < rows && c < cols) out[(long)c * rows + r] = tile[threadIdx.x][i];
+  }
+}
+
+// ---------------------------------------------------------------- forward / dgrad
+struct ConvEpi {
+  float* Y;
+  int rows, N, accumulate;
+  __device__ __forceinline__ void operator()(int row, int col, float v) const {
+    if (row < rows && col < N) {
+      float* d = Y + (long)row * N + col;
+      if (accumulate) v += *d;
+      *d = v;
+    }
+  }
+};
+
+template <class TL>
+__global__ __launch_bounds__(256) void conv3x3_kernel(ConvLoader<TL::A_LOADS> al, RowLoader bl, ConvEpi ep,
+                                                      int K, int tiles_m, int tiles_n) {
+  __shared__ __attribute__((aligned(16))) float As[TL::BM * kLdsStride];
+  __shared__ __attribute__((aligned(16))) float Bs[TL::BN * kLdsStride];
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (tile / tiles_n) * TL::BM, n0 = (tile % tiles_n) * TL::BN;
+  al.init(m0);
+  bl.init(n0);
+  f32x16 acc[TL::TM][TL::TN];
+  zero_acc<TL>(acc);
+  nt_mainloop<TL>(al, bl, K, As, Bs, acc);
+  for_each_acc<TL>(acc, [&](int r, int c, float v) { ep(m0 + r, n0 + c, v); });
+}
+
+template <class TL>
+int launch_conv(const float* x, const float* wp, float* y, int B, int T, int F, int C, int N, int accumulate,
+                hipStream_t st) {
+  const int rows = B * T * F, K = 9 * C;
+  ConvLoader<TL::A_LOADS> al;
+  al.p = x; al.T = T; al.F = F; al.C = C; al.rows = rows;
+  RowLoader bl{wp, (long)K, N, K, 0};
+  ConvEpi ep{y, rows, N, accumulate};
+  const int tm = pe_cdiv(rows, TL::BM), tn = pe_cdiv(N, TL::BN);
+  hipLaunchKernelGGL(conv3x3_kernel<TL>, dim3(tm * tn), dim3(256), 0, st, al, bl, ep, K, tm, tn);
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+
+// ---------------------------------------------------------------- weight gradient
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            float* __restrict__ ws, int T, int F, int Cin,
+                                                            int Cout, int P, int k_per_split, int tiles_n) {
+  __shared__ __attribute__((aligned(16))) float As[kBK * BM];
+  __shared__ __attribute__((aligned(16))) float Bs[kBK * BN];
+  const int tap = blockIdx.z;
+  const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+  const int kb = blockIdx.y * k_per_split;
+  const int ke = min(P, kb + k_per_split);
+  KRowLoader<BM> al{dy, (long)Cout, Cout, 0};
+  ShiftedPixelLoader<BN> bl{x, T, F, Cin, tap / 3 - 1, tap % 3 - 1, 0};
+  al.init(m0);
+  bl.init(n0);
+  f32x16 acc[BM / 64][BN / 64];
+#pragma unroll
+  for (int i = 0; i < BM / 64; ++i)
+#pragma unroll
+    for (int j = 0; j < BN / 64; ++j)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
+  tn_mainloop<BM, BN>(al, bl, kb, ke, As, Bs, acc);
+  // slab layout: [split][tap][Cout][Cin]
+  float* dst = ws + ((long)blockIdx.y * 9 + tap) * Cout * Cin;
+  tn_for_each_acc<BM, BN>(acc, [&](int r, int c, float v) {
+    const int co = m0 + r, ci = n0 + c;
+    if (co < Cout && ci < Cin) dst[(long)co * Cin + ci] = v;
+  });
+}
+
+// sum slabs in split order and scatter to OIHW: dw[(co*Cin + ci)*9 + tap]
+__global__ void conv3x3_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits,
+                                            int Cout, int Cin) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // over [tap][co][ci]
+  const int n = 9 * Cout * Cin;
+  if (idx >= n) return;
+  float s = 0.f;
+  for (int z = 0; z < splits; ++z) s += ws[(long)z * n + idx];
+  const int ci = idx % Cin, co = (idx / Cin) % Cout, tap = idx / (Cin * Cout);
+  dw[((long)co * Cin + ci) * 9 + tap] = s;
+}
+
+void wgrad_plan(int P, int Cout, int Cin, int* bm, int* bn, int* splits, int* kps) {
+  *bm = Cout <= 64 ? 64 : 128;
+  *bn = Cin <= 64 ? 64 : 128;
+  const int tiles = pe_cdiv(Cout, *bm) * pe_cdiv(Cin, *bn) * 9;
+  int s = pe_cdiv(1024, tiles);
+  const int max_s = P / 1024 > 0 ? P / 1024 : 1;
+  if (s > max_s) s = max_s;
+  int k = pe_cdiv(P, s);
+  k = (k + kBK - 1) / kBK * kBK;
+  *kps = k;
+  *splits = pe_cdiv(P, k);
+}
+
+template <int BM, int BN>
+int launch_wgrad(const float* x, const float* dy, float* dw, float* ws, int B, int T, int F, int Cin, int Cout,
+                 int splits, int kps, hipStream_t st) {
+  const int P = B * T * F;
+  const int tm = pe_cdiv(Cout, BM), tn = pe_cdiv(Cin, BN);
+  hipLaunchKernelGGL((conv3x3_wgrad_kernel<BM, BN>), dim3(tm * tn, splits, 9), dim3(256), 0, st, dy, x, ws, T, F,
+                     Cin, Cout, P, kps, tn);
+  PE_LAUNCH_CHECK();
+  const int n = 9 * Cout * Cin;
+  hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(pe_cdiv(n, 256)), dim3(256), 0, st, ws, dw, splits, Cout,
+                     Cin);
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+
+// ---------------------------------------------------------------- first layer, Cin = 1 -> Cout = 64
+// x element (b, t, f) at x[b*sb + t*st + f*sf]; y channels-last [B][T][F][64].  16 threads per pixel,
+// 4 output channels each (one float4 store; 16 threads write one 256-B pixel row).
+__global__ __launch_bounds__(256) void conv3x3_c1_fwd_kernel(const float* __restrict__ x, long sb, long st_, long sf,
+                                                             const float* __restrict__ w, float* __restrict__ y,
+                                                             int B, int T, int F) {
+  const int q = threadIdx.x & 15;                 // channel quad
+  float wr[4][9];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wr[c][k] = w[(q * 4 + c) * 9 + k];
+  const long P = (long)B * T * F;
+  for (long p = (long)blockIdx.x * 16 + (threadIdx.x >> 4); p < P; p += (long)gridDim.x * 16) {
+    const int f = (int)(p % F), t = (int)((p / F) % T);
+    const long b = p / ((long)F * T);
+    float in[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int tt = t + k / 3 - 1, ff = f + k % 3 - 1;
+      in[k] = (tt >= 0 && tt < T && ff >= 0 && ff < F) ? x[b * sb + tt * st_ + ff * sf] : 0.f;
+    }
+    float4 o;
+    float* op = reinterpret_cast<float*>(&o);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) s = fmaf(in[k], wr[c][k], s);
+      op[c] = s;
+    }
+    *reinterpret_cast<float4*>(y + p * 64 + q * 4) = o;
+  }
+}
+
+// dW[co][tap] = sum_p dY[p][co] * x[p + tap]; partials per workgroup, then an ordered reduce.
+__global__ __launch_bounds__(256) void conv3x3_c1_wgrad_kernel(const float* __restrict__ x, long sb, long st_,
+                                                               long sf, const float* __restrict__ dy,
+                                                               float* __restrict__ partial, int B, int T, int F) {
+  __shared__ float red[4][64][9];
+  const int co = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  float acc[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) acc[k] = 0.f;
+  const long P = (long)B * T * F;
+  for (long p = (long)blockIdx.x * 4 + grp; p < P; p += (long)gridDim.x * 4) {
+    const int f = (int)(p % F), t = (int)((p / F) % T);
+    const long b = p / ((long)F * T);
+    const float g = dy[p * 64 + co];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int tt = t + k / 3 - 1, ff = f + k % 3 - 1;
+      const float xv = (tt >= 0 && tt < T && ff >= 0 && ff < F) ? x[b * sb + tt * st_ + ff * sf] : 0.f;
+      acc[k] = fmaf(g, xv, acc[k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) red[grp][co][k] = acc[k];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 9; i += 256) {
+    const int c = i / 9, k = i % 9;
+    partial[(long)blockIdx.x * 576 + i] = (red[0][c][k] + red[1][c][k]) + (red[2][c][k] + red[3][c][k]);
+  }
+}
+
+__global__ void c1_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int nblocks) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 576) return;
+  double s = 0.0;
+  for (int z = 0; z < nblocks; ++z) s += (double)partial[(long)z * 576 + i];
+  dw[i] = (float)s;
+}
+
+constexpr int kC1WgradBlocks = 2048;
+
+}  // namespace
+
+extern "C" int pe_conv3x3_repack(const float* w_oihw, float* w_fwd, float* w_dgrad, int Cout, int Cin,
+                                 void* stream) {
+  if (!w_oihw || Cout <= 0 || Cin <= 0) return PE_E_ARG;
+  const int n = Cout * Cin * 9;
+  hipLaunchKernelGGL(repack3x3_kernel, dim3(pe_cdiv(n, 256)), dim3(256), 0, pe_stream(stream), w_oihw, w_fwd,
+                     w_dgrad, Cout, Cin);
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+
+extern "C" int pe_transpose2d(const float* in, float* out, int rows, int cols, void* stream) {
+  if (!in || !out || rows <= 0 || cols <= 0) return PE_E_ARG;
+  hipLaunchKernelGGL(transpose2d_kernel, dim3(pe_cdiv(cols, 32), pe_cdiv(rows, 32)), dim3(32, 8), 0,
+                     pe_stream(stream), in, out, rows, cols);
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+
+extern "C" int pe_conv3x3_fwd(const float* x, const float* w_packed, float* y, int B, int T, int F, int C, int N,
+                              int accumulate, void* stream) {
+  if (!x || !w_packed || !y || B <= 0 || T <= 0 || F <= 0 || C <= 0 || N <= 0) return PE_E_ARG;
+  if ((C % 32) != 0 || (long)B * T * F * (C > N ? C : N) >= (1L << 31)) return PE_E_UNSUPPORTED;
+  hipStream_t st = pe_stream(stream);
+  if (N <= 64) return launch_conv<Tile<256, 64, 4, 1>>(x, w_packed, y, B, T, F, C, N, accumulate, st);
+  if (N % 192 == 0 && N % 128 != 0) return launch_conv<Tile<128, 192, 2, 2>>(x, w_packed, y, B, T, F, C, N, accumulate, st);
+  return launch_conv<Tile<128, 128, 2, 2>>(x, w_packed, y, B, T, F, C, N, accumulate, st);
+}
+
+extern "C" size_t pe_conv3x3_wgrad_workspace_bytes(int B, int T, int F, int Cin, int Cout) {
+  if (Cin == 1) return (size_t)kC1WgradBlocks * 576 * sizeof(float);
+  int bm, bn, splits, kps;
+  wgrad_plan(B * T * F, Cout, Cin, &bm, &bn, &splits, &kps);
+  return (size_t)splits * 9 * Cout * Cin * sizeof(float);
+}
+
+extern "C" int pe_conv3x3_wgrad(const float* x, const float* dy, float* dw_oihw, int B, int T, int F, int Cin,
+                                int Cout, float* workspace, size_t workspace_bytes, void* stream) {
+  if (!x || !dy || !dw_oihw || B <= 0 || T <= 0 || F <= 0 || Cin <= 0 || Cout <= 0) return PE_E_ARG;
+  if ((Cin & 3) || (Cout & 3)) return PE_E_UNSUPPORTED;
+  if (!workspace || workspace_bytes < pe_conv3x3_wgrad_workspace_bytes(B, T, F, Cin, Cout)) return PE_E_WORKSPACE;
+  int bm, bn, splits, kps;
+  wgrad_plan(B * T * F, Cout, Cin, &bm, &bn, &splits, &kps);
+  hipStream_t st = pe_stream(stream);
+  if (bm == 64 && bn == 64) return launch_wgrad<64, 64>(x, dy, dw_oihw, workspace, B, T, F, Cin, Cout, splits, kps, st);
+  if (bm == 64) return launch_wgrad<64, 128>(x, dy, dw_oihw, workspace, B, T, F, Cin, Cout, splits, kps, st);
+  if (bn == 64) return launch_wgrad<128, 64>(x, dy, dw_oihw, workspace, B, T, F, Cin, Cout, splits, kps, st);
+  return launch_wgrad<128, 128>(x, dy, dw_oihw, workspace, B, T, F, Cin, Cout, splits, kps, st);
+}
+
+extern "C" int pe_conv3x3_c1_fwd(const float* x, long sb, long st, long sf, const float* w_oihw, float* y, int B,
+                                 int T, int F, void* stream) {
+  if (!x || !w_oihw || !y || B <= 0 || T <= 0 || F <= 0) return PE_E_ARG;
+  const long P = (long)B * T * F;
+  const int grid = (int)((P + 15) / 16 < 8192 ? (P + 15) / 16 : 8192);
+  hipLaunchKernelGGL(conv3x3_c1_fwd_kernel, dim3(grid), dim3(256), 0, pe_stream(stream), x, sb, st, sf, w_oihw, y,
+                     B, T, F);
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+
+extern "C" int pe_conv3x3_c1_wgrad(const float* x, long sb, long st, long sf, const float* dy, float* dw_oihw,
+                                   int B, int T, int F, float* workspace, size_t workspace_bytes, void* stream) {
+  if (!x || !dy || !dw_oihw || B <= 0 || T <= 0 || F <= 0) return PE_E_ARG;
+  if (!workspace || workspace_bytes < (size_t)kC1WgradBlocks * 576 * sizeof(float)) return PE_E_WORKSPACE;
+  hipLaunchKernelGGL(conv3x3_c1_wgrad_kernel, dim3(kC1WgradBlocks), dim3(256), 0, pe_stream(stream), x, sb, st, sf,
+                     dy, workspace, B, T, F);
+  PE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(c1_wgrad_reduce_kernel, dim3(3), dim3(256), 0, pe_stream(stream), workspace, dw_oihw,
+                     kC1WgradBlocks);
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}

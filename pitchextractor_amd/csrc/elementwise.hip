@@ -1,0 +1,521 @@
+// HBM-bound stages of the JDCNet stack on channels-last activations [rows = B*T][F][C]:
+// train-mode BatchNorm2d statistics (model.py:25,37,54,150,159), the fused
+// BN -> LeakyReLU(0.01) -> MaxPool2d((1, k)) blocks (model.py:36-41,148-153) forward and backward,
+// the detector-branch max-pools (model.py:45-49), dropout (model.py:40,56) and the
+// (B,256,T,2) -> (B,T,512) re-layout of model.py:93,112.  Everything moves float4 (4 channels).
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxPartials = 1024;
+
+// ---------------------------------------------------------------- per-channel two-value reduction
+// Each thread owns one channel quad and every G-th pixel; sums are kept in double so the biased
+// variance E[x^2] - E[x]^2 loses nothing at 4M samples per channel.
+template <class F>
+__device__ __forceinline__ void column_reduce2(F&& f, long n_pix, int C, double* partial /*[grid][2][C]*/) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* red = reinterpret_cast<double*>(smem_raw);            // [G][2][C]
+  const int quads = C >> 2;
+  const int G = 256 / quads;
+  const int q = threadIdx.x % quads, g = threadIdx.x / quads;
+  double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  if (g < G) {
+    for (long p = (long)blockIdx.x * G + g; p < n_pix; p += (long)gridDim.x * G) {
+      float4 a, b;
+      f(p, q * 4, a, b);
+      s1[0] += a.x; s1[1] += a.y; s1[2] += a.z; s1[3] += a.w;
+      s2[0] += b.x; s2[1] += b.y; s2[2] += b.z; s2[3] += b.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      red[(g * 2 + 0) * C + q * 4 + i] = s1[i];
+      red[(g * 2 + 1) * C + q * 4 + i] = s2[i];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    double s = 0;
+    for (int gg = 0; gg < G; ++gg) s += red[gg * 2 * C + i];
+    partial[(long)blockIdx.x * 2 * C + i] = s;
+  }
+}
+
+__device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+// ---------------------------------------------------------------- BN statistics
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, long n_pix, int C,
+                                                               double* __restrict__ partial) {
+  column_reduce2(
+      [&](long p, int c, float4& a, float4& b) {
+        a = *reinterpret_cast<const float4*>(x + p * C + c);
+        b = make_float4(a.x * a.x, a.y * a.y, a.z * a.z, a.w * a.w);
+      },
+      n_pix, C, partial);
+}
+
+__global__ void bn_stats_finalize_kernel(const double* __restrict__ partial, int nparts, long n_pix, int C,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                         float momentum, float* __restrict__ running_mean,
+                                         float* __restrict__ running_var, float* __restrict__ mean_out,
+                                         float* __restrict__ invstd_out, float* __restrict__ scale,
+                                         float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0, s2 = 0;
+  for (int z = 0; z < nparts; ++z) {
+    s1 += partial[(long)z * 2 * C + c];
+    s2 += partial[(long)z * 2 * C + C + c];
+  }
+  const double n = (double)n_pix;
+  const double mean = s1 / n;
+  double var = s2 / n - mean * mean;
+  if (var < 0) var = 0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  mean_out[c] = (float)mean;
+  invstd_out[c] = invstd;
+  const float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mean * sc;
+  if (running_mean) {
+    const double unbiased = n > 1 ? var * n / (n - 1.0) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+__global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ rm, const float* __restrict__ rv, float eps, int C,
+                                      float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = 1.0f / sqrtf(rv[c] + eps);
+  const float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - rm[c] * sc;
+}
+
+// ---------------------------------------------------------------- BN -> LReLU -> MaxPool(1,k) forward
+// x: [rows][Fin][C]; y: pixel (row, fo) at y[(row*Fout + fo)*ldy + coff + c]
+__global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, float slope,
+                                                              float* __restrict__ y, long n_out_pix, int Fin, int C,
+                                                              int pool, long ldy, int coff) {
+  const int quads = C >> 2;
+  const int Fout = Fin / pool;
+  const long total = n_out_pix * quads;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int q = (int)(i % quads);
+    const long op = i / quads;
+    const long row = op / Fout;
+    const int fo = (int)(op % Fout);
+    const float4 sc = *reinterpret_cast<const float4*>(scale + q * 4);
+    const float4 sh = *reinterpret_cast<const float4*>(shift + q * 4);
+    const float* xp = x + ((row * Fin + (long)fo * pool) * C + q * 4);
+    float4 m;
+    for (int j = 0; j < pool; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(xp + (long)j * C);
+      float4 a;
+      a.x = lrelu(fmaf(v.x, sc.x, sh.x), slope);
+      a.y = lrelu(fmaf(v.y, sc.y, sh.y), slope);
+      a.z = lrelu(fmaf(v.z, sc.z, sh.z), slope);
+      a.w = lrelu(fmaf(v.w, sc.w, sh.w), slope);
+      if (j == 0) m = a;
+      else { m.x = fmaxf(m.x, a.x); m.y = fmaxf(m.y, a.y); m.z = fmaxf(m.z, a.z); m.w = fmaxf(m.w, a.w); }
+    }
+    *reinterpret_cast<float4*>(y + op * ldy + coff + q * 4) = m;
+  }
+}
+
+// dz for the input pixel (row, f) of a BN->LReLU->MaxPool block, recomputed from x and dy.
+// The max-pool routes dy to the FIRST maximum of each window (torch max_pool2d backward).
+__device__ __forceinline__ float dz_one(const float* __restrict__ xwin, long cstride, int j, int pool, float sc,
+                                        float sh, float slope, float dyv) {
+  // xwin points at window element 0 of this channel
+  float best = lrelu(fmaf(xwin[0], sc, sh), slope);
+  int arg = 0;
+  for (int k = 1; k < pool; ++k) {
+    const float a = lrelu(fmaf(xwin[(long)k * cstride], sc, sh), slope);
+    if (a > best) { best = a; arg = k; }
+  }
+  if (arg != j) return 0.f;
+  const float z = fmaf(xwin[(long)j * cstride], sc, sh);
+  return z > 0.f ? dyv : dyv * slope;
+}
+
+struct BnBwdArgs {
+  const float* x;       // [rows][Fin][C]
+  const float* dy;      // pixel (row, fo) at dy[(row*Fout + fo)*lddy + coff + c]
+  const float* scale;
+  const float* shift;
+  const float* mean;
+  const float* invstd;
+  float slope;
+  long n_in_pix;        // rows * Fin
+  int Fin, C, pool;
+  long lddy;
+  int coff;
+};
+
+__device__ __forceinline__ float4 dz_quad(const BnBwdArgs& a, long p, int c) {
+  const int Fout = a.Fin / a.pool;
+  const long row = p / a.Fin;
+  const int f = (int)(p % a.Fin);
+  const int fo = f / a.pool, j = f - fo * a.pool;
+  float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (fo >= Fout) return out;                                   // floor-mode remainder gets no gradient
+  const float4 dyv = *reinterpret_cast<const float4*>(a.dy + (row * Fout + fo) * a.lddy + a.coff + c);
+  const float* xw = a.x + (row * a.Fin + (long)fo * a.pool) * a.C + c;
+  const float4 sc = *reinterpret_cast<const float4*>(a.scale + c);
+  const float4 sh = *reinterpret_cast<const float4*>(a.shift + c);
+  if (a.pool == 1) {
+    const float4 v = *reinterpret_cast<const float4*>(xw);
+    out.x = fmaf(v.x, sc.x, sh.x) > 0.f ? dyv.x : dyv.x * a.slope;
+    out.y = fmaf(v.y, sc.y, sh.y) > 0.f ? dyv.y : dyv.y * a.slope;
+    out.z = fmaf(v.z, sc.z, sh.z) > 0.f ? dyv.z : dyv.z * a.slope;
+    out.w = fmaf(v.w, sc.w, sh.w) > 0.f ? dyv.w : dyv.w * a.slope;
+    return out;
+  }
+  out.x = dz_one(xw + 0, a.C, j, a.pool, sc.x, sh.x, a.slope, dyv.x);
+  out.y = dz_one(xw + 1, a.C, j, a.pool, sc.y, sh.y, a.slope, dyv.y);
+  out.z = dz_one(xw + 2, a.C, j, a.pool, sc.z, sh.z, a.slope, dyv.z);
+  out.w = dz_one(xw + 3, a.C, j, a.pool, sc.w, sh.w, a.slope, dyv.w);
+  return out;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const BnBwdArgs a, double* __restrict__ partial) {
+  column_reduce2(
+      [&](long p, int c, float4& s, float4& t) {
+        s = dz_quad(a, p, c);
+        const float4 v = *reinterpret_cast<const float4*>(a.x + p * a.C + c);
+        const float4 mu = *reinterpret_cast<const float4*>(a.mean + c);
+        const float4 is = *reinterpret_cast<const float4*>(a.invstd + c);
+        t = make_float4(s.x * ((v.x - mu.x) * is.x), s.y * ((v.y - mu.y) * is.y), s.z * ((v.z - mu.z) * is.z),
+                        s.w * ((v.w - mu.w) * is.w));
+      },
+      a.n_in_pix, a.C, partial);
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nparts, long n_pix, int C,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       float* __restrict__ c1, float* __restrict__ c2) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0, s2 = 0;
+  for (int z = 0; z < nparts; ++z) {
+    s1 += partial[(long)z * 2 * C + c];
+    s2 += partial[(long)z * 2 * C + C + c];
+  }
+  dbeta[c] = (float)s1;
+  dgamma[c] = (float)s2;
+  c1[c] = (float)(s1 / (double)n_pix);
+  c2[c] = (float)(s2 / (double)n_pix);
+}
+
+// dx = gamma*invstd * (dz - mean(dz) - xhat * mean(dz*xhat));  scale == gamma*invstd
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a, const float* __restrict__ c1,
+                                                           const float* __restrict__ c2, float* __restrict__ dx) {
+  const int quads = a.C >> 2;
+  const long total = a.n_in_pix * quads;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % quads) * 4;
+    const long p = i / quads;
+    const float4 dz = dz_quad(a, p, c);
+    const float4 v = *reinterpret_cast<const float4*>(a.x + p * a.C + c);
+    const float4 mu = *reinterpret_cast<const float4*>(a.mean + c);
+    const float4 is = *reinterpret_cast<const float4*>(a.invstd + c);
+    const float4 sc = *reinterpret_cast<const float4*>(a.scale + c);
+    const float4 k1 = *reinterpret_cast<const float4*>(c1 + c);
+    const float4 k2 = *reinterpret_cast<const float4*>(c2 + c);
+    float4 o;
+    o.x = sc.x * (dz.x - k1.x - (v.x - mu.x) * is.x * k2.x);
+    o.y = sc.y * (dz.y - k1.y - (v.y - mu.y) * is.y * k2.y);
+    o.z = sc.z * (dz.z - k1.z - (v.z - mu.z) * is.z * k2.z);
+    o.w = sc.w * (dz.w - k1.w - (v.w - mu.w) * is.w * k2.w);
+    *reinterpret_cast<float4*>(dx + p * a.C + c) = o;
+  }
+}
+
+// ---------------------------------------------------------------- plain MaxPool(1,k) (detector taps)
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          long n_out_pix, int Fin, int C, int pool, long ldy,
+                                                          int coff) {
+  const int quads = C >> 2, Fout = Fin / pool;
+  const long total = n_out_pix * quads;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int q = (int)(i % quads);
+    const long op = i / quads, row = op / Fout;
+    const int fo = (int)(op % Fout);
+    const float* xp = x + ((row * Fin + (long)fo * pool) * C + q * 4);
+    float4 m = *reinterpret_cast<const float4*>(xp);
+    for (int j = 1; j < pool; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(xp + (long)j * C);
+      m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+    }
+    *reinterpret_cast<float4*>(y + op * ldy + coff + q * 4) = m;
+  }
+}
+
+// dx[first argmax of each window] += dy   (one thread owns a whole window: no atomics)
+__global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ dy, float* __restrict__ dx,
+                                                              long n_out_pix, int Fin, int C, int pool, long lddy,
+                                                              int coff) {
+  const int Fout = Fin / pool;
+  const long total = n_out_pix * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long op = i / C, row = op / Fout;
+    const int fo = (int)(op % Fout);
+    const long base = (row * Fin + (long)fo * pool) * C + c;
+    float best = x[base];
+    int arg = 0;
+    for (int j = 1; j < pool; ++j) {
+      const float v = x[base + (long)j * C];
+      if (v > best) { best = v; arg = j; }
+    }
+    dx[base + (long)arg * C] += dy[op * lddy + coff + c];
+  }
+}
+
+// ---------------------------------------------------------------- dropout (Philox4x32-10)
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+  const uint64_t p0 = (uint64_t)M0 * c[0], p1 = (uint64_t)M1 * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0];
+  const uint32_t n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1];
+  const uint32_t n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+  k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+}
+
+__device__ __forceinline__ void philox4(uint64_t seed, uint64_t ctr, uint32_t (&out)[4]) {
+  uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+  uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+  for (int i = 0; i < 10; ++i) philox_round(c, k);
+  out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+
+// rows x cols, x row stride ldx, y row stride ldy; mask is dense [rows*cols] bytes (1 = kept).
+// mask_in != NULL replays a given mask (parity tests); otherwise keep = (u >= p).
+__global__ __launch_bounds__(256) void dropout_fwd_kernel(const float* __restrict__ x, long ldx,
+                                                          float* __restrict__ y, long ldy,
+                                                          const uint8_t* __restrict__ mask_in,
+                                                          uint8_t* __restrict__ mask_out, long rows, int cols,
+                                                          float p, float scale, uint64_t seed, uint64_t offset) {
+  const int quads = cols >> 2;
+  const long total = rows * quads;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % quads) * 4;
+    const long r = i / quads;
+    uint8_t keep[4];
+    if (mask_in) {
+      const uchar4 m = *reinterpret_cast<const uchar4*>(mask_in + r * cols + c);
+      keep[0] = m.x; keep[1] = m.y; keep[2] = m.z; keep[3] = m.w;
+    } else {
+      uint32_t rnd[4];
+      philox4(seed, offset + (uint64_t)i, rnd);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) keep[k] = ((float)(rnd[k] >> 8) * (1.0f / 16777216.0f)) >= p ? 1 : 0;
+    }
+    const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
+    float4 o;
+    o.x = keep[0] ? v.x * scale : 0.f;
+    o.y = keep[1] ? v.y * scale : 0.f;
+    o.z = keep[2] ? v.z * scale : 0.f;
+    o.w = keep[3] ? v.w * scale : 0.f;
+    *reinterpret_cast<float4*>(y + r * ldy + c) = o;
+    if (mask_out) *reinterpret_cast<uchar4*>(mask_out + r * cols + c) = make_uchar4(keep[0], keep[1], keep[2], keep[3]);
+  }
+}
+
+// ---------------------------------------------------------------- (B,256,T,2) <-> (B,T,512) re-layout
+// channels-last pixel pair (row, w in {0,1}) at x[(row*2 + w)*ldx + coff + c]  <->  seq[row][c*2 + w]
+__global__ __launch_bounds__(256) void nhwc_to_seq_kernel(const float* __restrict__ x, long ldx, int coff,
+                                                          float* __restrict__ seq, long rows, int C) {
+  const long total = rows * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long r = i / C;
+    const float a = x[(r * 2 + 0) * ldx + coff + c];
+    const float b = x[(r * 2 + 1) * ldx + coff + c];
+    *reinterpret_cast<float2*>(seq + r * 2 * C + 2 * c) = make_float2(a, b);
+  }
+}
+
+__global__ __launch_bounds__(256) void seq_to_nhwc_kernel(const float* __restrict__ seq, float* __restrict__ x,
+                                                          long ldx, int coff, long rows, int C, int accumulate) {
+  const long total = rows * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long r = i / C;
+    const float2 v = *reinterpret_cast<const float2*>(seq + r * 2 * C + 2 * c);
+    float* d0 = x + (r * 2 + 0) * ldx + coff + c;
+    float* d1 = x + (r * 2 + 1) * ldx + coff + c;
+    if (accumulate) { *d0 += v.x; *d1 += v.y; }
+    else { *d0 = v.x; *d1 = v.y; }
+  }
+}
+
+// strided 2-D copy / add: dst[r*ldd + c] (+)= src[r*lds + c]
+__global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ src, long lds, float* __restrict__ dst,
+                                                     long ldd, long rows, int cols, int accumulate) {
+  const int quads = cols >> 2;
+  const long total = rows * quads;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % quads) * 4;
+    const long r = i / quads;
+    float4 v = *reinterpret_cast<const float4*>(src + r * lds + c);
+    float4* d = reinterpret_cast<float4*>(dst + r * ldd + c);
+    if (accumulate) { const float4 o = *d; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+    *d = v;
+  }
+}
+
+int ew_grid(long total_threads) {
+  long g = (total_threads + 255) / 256;
+  if (g > 16384) g = 16384;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+int reduce_grid(long n_pix, int C) {
+  const int G = 256 / (C / 4);
+  long g = (n_pix + G - 1) / G;
+  if (g > kMaxPartials) g = kMaxPartials;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+size_t reduce_lds(int C) { return (size_t)(256 / (C / 4)) * 2 * C * sizeof(double); }
+
+bool bn_channels_ok(int C) { return C >= 4 && (C % 4) == 0 && C <= 1024; }
+
+}  // namespace
+
+extern "C" size_t pe_bn_workspace_bytes(int C) { return (size_t)kMaxPartials * 2 * C * sizeof(double); }
+
+extern "C" int pe_bn_train_stats(const float* x, long n_pix, int C, const float* gamma, const float* beta, float eps,
+                                 float momentum, float* running_mean, float* running_var, float* mean,
+                                 float* invstd, float* scale, float* shift, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+  if (!x || !gamma || !beta || !mean || !invstd || !scale || !shift || n_pix <= 0) return PE_E_ARG;
+  if (!bn_channels_ok(C)) return PE_E_UNSUPPORTED;
+  if (!workspace || workspace_bytes < pe_bn_workspace_bytes(C)) return PE_E_WORKSPACE;
+  hipStream_t st = pe_stream(stream);
+  const int grid = reduce_grid(n_pix, C);
+  double* partial = reinterpret_cast<double*>(workspace);
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(grid), dim3(256), reduce_lds(C), st, x, n_pix, C, partial);
+  PE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(pe_cdiv(C, 64)), dim3(64), 0, st, partial, grid, n_pix, C, gamma,
+                     beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+
+extern "C" int pe_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                                 const float* running_var, float eps, int C, float* scale, float* shift,
+                                 void* stream) {
+  if (!gamma || !beta || !running_mean || !running_var || !scale || !shift || C <= 0) return PE_E_ARG;
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(pe_cdiv(C, 64)), dim3(64), 0, pe_stream(stream), gamma, beta,
+                     running_mean, running_var, eps, C, scale, shift);
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+
+extern "C" int pe_bn_act_pool_fwd(const float* x, const float* scale, const float* shift, float slope, float* y,
+                                  long rows, int Fin, int C, int pool, long ldy, int coff, void* stream) {
+  if (!x || !scale || !shift || !y || rows <= 0 || Fin <= 0 || pool <= 0) return PE_E_ARG;
+  if (!bn_channels_ok(C) || (ldy & 3) || (coff & 3)) return PE_E_UNSUPPORTED;
+  const long n_out = rows * (Fin / pool);
+  hipLaunchKernelGGL(bn_act_pool_fwd_kernel, dim3(ew_grid(n_out * (C / 4))), dim3(256), 0, pe_stream(stream), x, scale,
+                     shift, slope, y, n_out, Fin, C, pool, ldy, coff);
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+
+extern "C" int pe_bn_act_pool_bwd(const float* x, const float* dy, const float* scale, const float* shift,
+                                  const float* mean, const float* invstd, float slope, float* dx, float* dgamma,
+                                  float* dbeta, long rows, int Fin, int C, int pool, long lddy, int coff,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+  if (!x || !dy || !scale || !shift || !mean || !invstd || !dx || !dgamma || !dbeta || rows <= 0) return PE_E_ARG;
+  if (!bn_channels_ok(C) || (lddy & 3) || (coff & 3) || pool <= 0) return PE_E_UNSUPPORTED;
+  const size_t need = pe_bn_workspace_bytes(C) + 2 * (size_t)C * sizeof(float);
+  if (!workspace || workspace_bytes < need) return PE_E_WORKSPACE;
+  hipStream_t st = pe_stream(stream);
+  BnBwdArgs a{x, dy, scale, shift, mean, invstd, slope, rows * Fin, Fin, C, pool, lddy, coff};
+  double* partial = reinterpret_cast<double*>(workspace);
+  float* c1 = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + pe_bn_workspace_bytes(C));
+  float* c2 = c1 + C;
+  const int grid = reduce_grid(a.n_in_pix, C);
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(grid), dim3(256), reduce_lds(C), st, a, partial);
+  PE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pe_cdiv(C, 64)), dim3(64), 0, st, partial, grid, a.n_in_pix, C,
+                     dgamma, dbeta, c1, c2);
+  PE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(a.n_in_pix * (C / 4))), dim3(256), 0, st, a, c1, c2, dx);
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+
+extern "C" int pe_maxpool_fwd(const float* x, float* y, long rows, int Fin, int C, int pool, long ldy, int coff,
+                              void* stream) {
+  if (!x || !y || rows <= 0 || Fin <= 0 || pool <= 0) return PE_E_ARG;
+  if ((C & 3) || (ldy & 3) || (coff & 3)) return PE_E_UNSUPPORTED;
+  const long n_out = rows * (Fin / pool);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(n_out * (C / 4))), dim3(256), 0, pe_stream(stream), x, y, n_out,
+                     Fin, C, pool, ldy, coff);
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+
+extern "C" int pe_maxpool_bwd_add(const float* x, const float* dy, float* dx, long rows, int Fin, int C, int pool,
+                                  long lddy, int coff, void* stream) {
+  if (!x || !dy || !dx || rows <= 0 || Fin <= 0 || pool <= 0 || C <= 0) return PE_E_ARG;
+  const long n_out = rows * (Fin / pool);
+  hipLaunchKernelGGL(maxpool_bwd_add_kernel, dim3(ew_grid(n_out * C)), dim3(256), 0, pe_stream(stream), x, dy, dx,
+                     n_out, Fin, C, pool, lddy, coff);
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+
+extern "C" int pe_dropout_fwd(const float* x, long ldx, float* y, long ldy, const unsigned char* mask_in,
+                              unsigned char* mask_out, long rows, int cols, float p, unsigned long long seed,
+                              unsigned long long offset, void* stream) {
+  if (!x || !y || rows <= 0 || cols <= 0 || p < 0.f || p >= 1.f) return PE_E_ARG;
+  if ((cols & 3) || (ldx & 3) || (ldy & 3)) return PE_E_UNSUPPORTED;
+  hipLaunchKernelGGL(dropout_fwd_kernel, dim3(ew_grid(rows * (cols / 4))), dim3(256), 0, pe_stream(stream), x, ldx, y,
+                     ldy, mask_in, mask_out, rows, cols, p, 1.0f / (1.0f - p), (uint64_t)seed, (uint64_t)offset);
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+
+extern "C" int pe_nhwc_to_seq(const float* x, long ldx, int coff, float* seq, long rows, int C, void* stream) {
+  if (!x || !seq || rows <= 0 || C <= 0) return PE_E_ARG;
+  hipLaunchKernelGGL(nhwc_to_seq_kernel, dim3(ew_grid(rows * C)), dim3(256), 0, pe_stream(stream), x, ldx, coff, seq,
+                     rows, C);
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+
+extern "C" int pe_seq_to_nhwc(const float* seq, float* x, long ldx, int coff, long rows, int C, int accumulate,
+                              void* stream) {
+  if (!x || !seq || rows <= 0 || C <= 0) return PE_E_ARG;
+  hipLaunchKernelGGL(seq_to_nhwc_kernel, dim3(ew_grid(rows * C)), dim3(256), 0, pe_stream(stream), seq, x, ldx, coff,
+                     rows, C, accumulate);
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+
+extern "C" int pe_copy2d(const float* src, long lds, float* dst, long ldd, long rows, int cols, int accumulate,
+                         void* stream) {
+  if (!src || !dst || rows <= 0 || cols <= 0) return PE_E_ARG;
+  if ((cols & 3) || (lds & 3) || (ldd & 3)) return PE_E_UNSUPPORTED;
+  hipLaunchKernelGGL(copy2d_kernel, dim3(ew_grid(rows * (cols / 4))), dim3(256), 0, pe_stream(stream), src, lds, dst,
+                     ldd, rows, cols, accumulate);
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}

@@ -1,0 +1,173 @@
+// Dense fp32 GEMMs on the MFMA tile engines (gemm_engine.h).
+//
+//   pe_gemm_nt:  C[M][N] = A[M][K] . B[N][K]^T (+ bias0[n] + bias1[n]) (+ C)
+//                -> nn.Linear forward, LSTM input projections (model.py:220-227), 1x1 convs in
+//                   channels-last (model.py:53,167), transposed-weight dgrad products.
+//   pe_gemm_tn:  C[M][N] = sum_k A[k][m] . B[k][n]  (k = rows), split over k across workgroups
+//                -> weight gradients (dW = dY^T X), deterministic slab + ordered reduce.
+#include "gemm_engine.h"
+
+namespace {
+using namespace pe;
+
+struct StoreEpi {
+  float* C;
+  long ldc;
+  const float* bias0;
+  const float* bias1;
+  int M, N, accumulate;
+  __device__ __forceinline__ void operator()(int row, int col, float v) const {
+    if (row < M && col < N) {
+      if (bias0) v += bias0[col];
+      if (bias1) v += bias1[col];
+      float* dst = C + (long)row * ldc + col;
+      if (accumulate) v += *dst;
+      *dst = v;
+    }
+  }
+};
+
+template <class TL>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(RowLoader al, RowLoader bl, StoreEpi ep, int K,
+                                                      int tiles_m, int tiles_n) {
+  __shared__ __attribute__((aligned(16))) float As[TL::BM * kLdsStride];
+  __shared__ __attribute__((aligned(16))) float Bs[TL::BN * kLdsStride];
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (tile / tiles_n) * TL::BM, n0 = (tile % tiles_n) * TL::BN;
+  al.init(m0);
+  bl.init(n0);
+  f32x16 acc[TL::TM][TL::TN];
+  zero_acc<TL>(acc);
+  nt_mainloop<TL>(al, bl, K, As, Bs, acc);
+  for_each_acc<TL>(acc, [&](int r, int c, float v) { ep(m0 + r, n0 + c, v); });
+}
+
+template <class TL>
+int launch_nt(const RowLoader& al, const RowLoader& bl, const StoreEpi& ep, int M, int N, int K,
+              hipStream_t st) {
+  const int tm = pe_cdiv(M, TL::BM), tn = pe_cdiv(N, TL::BN);
+  hipLaunchKernelGGL(gemm_nt_kernel<TL>, dim3(tm * tn), dim3(256), 0, st, al, bl, ep, K, tm, tn);
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+
+// ---- TN with split-K
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(KRowLoader<BM> al, KRowLoader<BN> bl, float* out,
+                                                      long ldo, long split_stride, int M, int N, int K,
+                                                      int k_per_split, int tiles_n, int accumulate) {
+  __shared__ __attribute__((aligned(16))) float As[kBK * BM];
+  __shared__ __attribute__((aligned(16))) float Bs[kBK * BN];
+  const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+  const int kb = blockIdx.y * k_per_split;
+  const int ke = min(K, kb + k_per_split);
+  al.init(m0);
+  bl.init(n0);
+  f32x16 acc[BM / 64][BN / 64];
+#pragma unroll
+  for (int i = 0; i < BM / 64; ++i)
+#pragma unroll
+    for (int j = 0; j < BN / 64; ++j)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
+  tn_mainloop<BM, BN>(al, bl, kb, ke, As, Bs, acc);
+  float* dst = out + (long)blockIdx.y * split_stride;
+  tn_for_each_acc<BM, BN>(acc, [&](int r, int c, float v) {
+    const int row = m0 + r, col = n0 + c;
+    if (row < M && col < N) {
+      float* d = dst + (long)row * ldo + col;
+      if (accumulate) v += *d;
+      *d = v;
+    }
+  });
+}
+
+__global__ void splitk_reduce_kernel(const float* ws, long split_stride, int splits, float* C, long ldc,
+                                     int M, int N, int accumulate) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)M * N) return;
+  const int row = (int)(idx / N), col = (int)(idx % N);
+  float s = 0.f;
+  for (int z = 0; z < splits; ++z) s += ws[(long)z * split_stride + idx];
+  float* d = C + (long)row * ldc + col;
+  *d = accumulate ? *d + s : s;
+}
+
+void tn_plan(int M, int N, int K, int bm, int bn, int* splits, int* k_per_split) {
+  const int tiles = pe_cdiv(M, bm) * pe_cdiv(N, bn);
+  int s = pe_cdiv(768, tiles);
+  const int max_s = K / 256 > 0 ? K / 256 : 1;
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  int kps = pe_cdiv(K, s);
+  kps = (kps + kBK - 1) / kBK * kBK;
+  *splits = pe_cdiv(K, kps);
+  *k_per_split = kps;
+}
+
+template <int BM, int BN>
+int launch_tn(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, int K,
+              int accumulate, float* ws, size_t ws_bytes, hipStream_t st) {
+  int splits, kps;
+  tn_plan(M, N, K, BM, BN, &splits, &kps);
+  KRowLoader<BM> al{A, lda, M, 0};
+  KRowLoader<BN> bl{B, ldb, N, 0};
+  const int tm = pe_cdiv(M, BM), tn = pe_cdiv(N, BN);
+  if (splits == 1) {
+    hipLaunchKernelGGL((gemm_tn_kernel<BM, BN>), dim3(tm * tn, 1), dim3(256), 0, st, al, bl, C, ldc, 0L, M, N,
+                       K, kps, tn, accumulate);
+    PE_LAUNCH_CHECK();
+    return PE_OK;
+  }
+  const size_t need = (size_t)splits * M * N * sizeof(float);
+  if (!ws || ws_bytes < need) return PE_E_WORKSPACE;
+  hipLaunchKernelGGL((gemm_tn_kernel<BM, BN>), dim3(tm * tn, splits), dim3(256), 0, st, al, bl, ws, (long)N,
+                     (long)M * N, M, N, K, kps, tn, 0);
+  PE_LAUNCH_CHECK();
+  const long total = (long)M * N;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(pe_cdiv(total, 256)), dim3(256), 0, st, ws, (long)M * N, splits,
+                     C, ldc, M, N, accumulate);
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int pe_gemm_nt(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
+                          int K, const float* bias0, const float* bias1, int accumulate, void* stream) {
+  if (!A || !B || !C || M < 0 || N < 0 || K <= 0) return PE_E_ARG;
+  if (M == 0 || N == 0) return PE_OK;
+  if ((K & 3) || (lda & 3) || (ldb & 3) || !aligned16(A) || !aligned16(B)) return PE_E_UNSUPPORTED;
+  RowLoader al{A, lda, M, K, 0};
+  RowLoader bl{B, ldb, N, K, 0};
+  StoreEpi ep{C, ldc, bias0, bias1, M, N, accumulate};
+  hipStream_t st = pe_stream(stream);
+  if (N <= 32) return launch_nt<Tile<128, 32, 4, 1>>(al, bl, ep, M, N, K, st);
+  if (N <= 64) return launch_nt<Tile<256, 64, 4, 1>>(al, bl, ep, M, N, K, st);
+  if (N % 192 == 0 && N % 128 != 0) return launch_nt<Tile<128, 192, 2, 2>>(al, bl, ep, M, N, K, st);
+  return launch_nt<Tile<128, 128, 2, 2>>(al, bl, ep, M, N, K, st);
+}
+
+extern "C" size_t pe_gemm_tn_workspace_bytes(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  int splits, kps;
+  tn_plan(M, N, K, M <= 64 ? 64 : 128, N <= 64 ? 64 : 128, &splits, &kps);
+  return splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
+}
+
+extern "C" int pe_gemm_tn(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
+                          int K, int accumulate, float* workspace, size_t workspace_bytes, void* stream) {
+  if (!A || !B || !C || M < 0 || N < 0 || K <= 0) return PE_E_ARG;
+  if (M == 0 || N == 0) return PE_OK;
+  if ((M & 3) || (N & 3) || (lda & 3) || (ldb & 3) || !aligned16(A) || !aligned16(B)) return PE_E_UNSUPPORTED;
+  hipStream_t st = pe_stream(stream);
+  if (M <= 64 && N <= 64)
+    return launch_tn<64, 64>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, st);
+  if (M <= 64)
+    return launch_tn<64, 128>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, st);
+  if (N <= 64)
+    return launch_tn<128, 64>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, st);
+  return launch_tn<128, 128>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, st);
+}

@@ -179,31 +179,41 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[TL::TM][TL::TN]) {
 }
 
 // ------------------------------------------------------------------ operand loaders (TN)
-// A TN loader hands out float4 = 4 consecutive columns of one k-row.  `slot` i addresses
-// k-row (tid >> 5) + 8 * i of the 32-row k-tile; col4 = (tid & 31) * 4 (tiles are 128 columns).
+// A TN loader hands out float4 = 4 consecutive columns of one k-row of a [32][COLS] k-tile.
+// COLS/4 threads cover a row, 1024/COLS rows per pass, COLS/32 passes ("slots") per k-tile.
+template <int COLS>
+struct TnGeom {
+  static constexpr int TPR = COLS / 4;           // threads per k-row
+  static constexpr int ROWS = 256 / TPR;         // k-rows per pass
+  static constexpr int SLOTS = kBK / ROWS;
+  static_assert(COLS == 64 || COLS == 128 || COLS == 256, "TN tile widths");
+  __device__ static __forceinline__ int col4() { return (threadIdx.x % TPR) * 4; }
+  __device__ static __forceinline__ int krow(int slot) { return threadIdx.x / TPR + ROWS * slot; }
+};
 
+template <int COLS>
 struct KRowLoader {           // plain [K][cols] matrix
   const float* p;
   long ld;
   int cols;
   int col0;
-  __device__ __forceinline__ void init(int first_col) { col0 = first_col + (threadIdx.x & 31) * 4; }
+  __device__ __forceinline__ void init(int first_col) { col0 = first_col + TnGeom<COLS>::col4(); }
   __device__ __forceinline__ float4 load(int slot, int k0, int k_end) const {
-    const int k = k0 + (threadIdx.x >> 5) + 8 * slot;
+    const int k = k0 + TnGeom<COLS>::krow(slot);
     if (k < k_end && col0 < cols) return *reinterpret_cast<const float4*>(p + (long)k * ld + col0);
     return make_float4(0.f, 0.f, 0.f, 0.f);
   }
 };
 
+template <int COLS>
 struct ShiftedPixelLoader {   // [B*T*F][C] channels-last tensor read at pixel + (dt, df), zero outside
   const float* p;
   int T, F, C, dt, df;
-  int cols;                   // = C
   int col0;
-  __device__ __forceinline__ void init(int first_col) { col0 = first_col + (threadIdx.x & 31) * 4; }
+  __device__ __forceinline__ void init(int first_col) { col0 = first_col + TnGeom<COLS>::col4(); }
   __device__ __forceinline__ float4 load(int slot, int k0, int k_end) const {
-    const int k = k0 + (threadIdx.x >> 5) + 8 * slot;
-    if (k < k_end && col0 < cols) {
+    const int k = k0 + TnGeom<COLS>::krow(slot);
+    if (k < k_end && col0 < C) {
       const int f = k % F, t = (k / F) % T;
       const int tt = t + dt, ff = f + df;
       if (tt >= 0 && tt < T && ff >= 0 && ff < F)
@@ -213,14 +223,15 @@ struct ShiftedPixelLoader {   // [B*T*F][C] channels-last tensor read at pixel +
   }
 };
 
+template <int COLS>
 struct ShiftedTimeLoader {    // [B][T][ld] sequence read at time t + dt (zero outside): h_{t-1} for dW_hh
   const float* p;
   long ld;
   int T, dt, cols;
   int col0;
-  __device__ __forceinline__ void init(int first_col) { col0 = first_col + (threadIdx.x & 31) * 4; }
+  __device__ __forceinline__ void init(int first_col) { col0 = first_col + TnGeom<COLS>::col4(); }
   __device__ __forceinline__ float4 load(int slot, int k0, int k_end) const {
-    const int k = k0 + (threadIdx.x >> 5) + 8 * slot;
+    const int k = k0 + TnGeom<COLS>::krow(slot);
     if (k < k_end && col0 < cols) {
       const int t = k % T + dt;
       if (t >= 0 && t < T) return *reinterpret_cast<const float4*>(p + ((long)k + dt) * ld + col0);
@@ -229,42 +240,67 @@ struct ShiftedTimeLoader {    // [B][T][ld] sequence read at time t + dt (zero o
   }
 };
 
-// ------------------------------------------------------------------ TN main loop (128x128 tile)
-// As/Bs: [32][128] floats each.  k range [k_begin, k_end).
-template <class AL, class BL>
+// ------------------------------------------------------------------ TN main loop
+// Workgroup tile BM x BN (each 64 or 128), waves 2 x 2.  As: [32][BM], Bs: [32][BN] floats.
+// k range [k_begin, k_end), k_begin a multiple of 32.
+template <int BM, int BN, class AL, class BL>
 __device__ __forceinline__ void tn_mainloop(AL& al, BL& bl, int k_begin, int k_end, float* As, float* Bs,
-                                            f32x16 (&acc)[2][2]) {
+                                            f32x16 (&acc)[BM / 64][BN / 64]) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int SA = TnGeom<BM>::SLOTS, SB = TnGeom<BN>::SLOTS;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm = wv >> 1, wn = wv & 1;
   const int r = lane & 31, h = lane >> 5;
-  float4 ra[4], rb[4];
+  float4 ra[SA], rb[SB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { ra[i] = al.load(i, k_begin, k_end); rb[i] = bl.load(i, k_begin, k_end); }
-  const int st_off = (tid >> 5) * 128 + (tid & 31) * 4;
-  const float* a_rd = As + h * 128 + wm * 64 + r;
-  const float* b_rd = Bs + h * 128 + wn * 64 + r;
+  for (int i = 0; i < SA; ++i) ra[i] = al.load(i, k_begin, k_end);
+#pragma unroll
+  for (int i = 0; i < SB; ++i) rb[i] = bl.load(i, k_begin, k_end);
+  const int sta = (tid / TnGeom<BM>::TPR) * BM + TnGeom<BM>::col4();
+  const int stb = (tid / TnGeom<BN>::TPR) * BN + TnGeom<BN>::col4();
+  const float* a_rd = As + h * BM + wm * (BM / 2) + r;
+  const float* b_rd = Bs + h * BN + wn * (BN / 2) + r;
   for (int k0 = k_begin; k0 < k_end; k0 += kBK) {
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<float4*>(As + st_off + i * 8 * 128) = ra[i];
-      *reinterpret_cast<float4*>(Bs + st_off + i * 8 * 128) = rb[i];
-    }
+    for (int i = 0; i < SA; ++i) *reinterpret_cast<float4*>(As + sta + i * TnGeom<BM>::ROWS * BM) = ra[i];
+#pragma unroll
+    for (int i = 0; i < SB; ++i) *reinterpret_cast<float4*>(Bs + stb + i * TnGeom<BN>::ROWS * BN) = rb[i];
     __syncthreads();
     if (k0 + kBK < k_end) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { ra[i] = al.load(i, k0 + kBK, k_end); rb[i] = bl.load(i, k0 + kBK, k_end); }
+      for (int i = 0; i < SA; ++i) ra[i] = al.load(i, k0 + kBK, k_end);
+#pragma unroll
+      for (int i = 0; i < SB; ++i) rb[i] = bl.load(i, k0 + kBK, k_end);
     }
 #pragma unroll
     for (int s = 0; s < kBK / 2; ++s) {
-      const float a0 = a_rd[s * 256], a1 = a_rd[s * 256 + 32];
-      const float b0 = b_rd[s * 256], b1 = b_rd[s * 256 + 32];
-      acc[0][0] = mfma32(a0, b0, acc[0][0]);
-      acc[0][1] = mfma32(a0, b1, acc[0][1]);
-      acc[1][0] = mfma32(a1, b0, acc[1][0]);
-      acc[1][1] = mfma32(a1, b1, acc[1][1]);
+      float fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = a_rd[s * 2 * BM + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = b_rd[s * 2 * BN + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(fa[i], fb[j], acc[i][j]);
     }
   }
+}
+
+// Visit the accumulators of a TN tile: fn(row_in_tile, col_in_tile, value).
+template <int BM, int BN, class FN>
+__device__ __forceinline__ void tn_for_each_acc(const f32x16 (&acc)[BM / 64][BN / 64], FN&& fn) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wm = wv >> 1, wn = wv & 1;
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < BM / 64; ++i)
+#pragma unroll
+    for (int j = 0; j < BN / 64; ++j)
+#pragma unroll
+      for (int g = 0; g < 16; ++g)
+        fn(wm * (BM / 2) + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * h, wn * (BN / 2) + j * 32 + r, acc[i][j][g]);
 }
 
 }  // namespace pe

@@ -1,0 +1,506 @@
+"""JDCNet on hand-written HIP kernels: drop-in for the reference ``model.JDCNet``.
+
+Same constructor, same ``forward(x: (B,1,T,80)) -> ((B,T,num_class), (B,T))`` and the same
+``state_dict`` keys/shapes as the reference (model.py:13-122, 143-175, 196-256), so
+checkpoints move both ways.  What differs is everything underneath:
+
+* all parameters live in ONE flat fp32 buffer (fused AdamW, one gradient buffer for the
+  data-parallel all-reduce); the ``nn.Parameter`` objects are views into it;
+* activations are channels-last ``[B, T, F, C]``; the 3x3 convolutions are implicit GEMMs on
+  fp32 MFMA, BatchNorm statistics / LeakyReLU / max-pool / dropout are fused HBM passes, the
+  BiLSTM recurrence runs one launch per time step for all 4 (direction x branch) cells;
+* the whole network is a single ``autograd.Function`` with a hand-written backward that
+  writes parameter gradients straight into the flat gradient buffer.
+
+There is no eager/CPU path: running the module needs the HIP library and device tensors.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch import nn
+
+from . import ops
+
+_ALIGN = 4  # parameters start on 16-byte boundaries inside the flat buffer
+
+
+# --------------------------------------------------------------------------- parameter holders
+class _Conv(nn.Module):
+    """Bias-free Conv2d weight in the reference's OIHW layout."""
+
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+
+
+class _BatchNorm(nn.Module):
+    def __init__(self, c, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.eps, self.momentum = eps, momentum
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+
+class _Slots(nn.Module):
+    """Children addressed by position, so keys read ``block.0.weight`` like the reference's Sequential."""
+
+    def __init__(self, **children):
+        super().__init__()
+        for name, mod in children.items():
+            self.add_module(name.lstrip("_"), mod)
+
+    def __getitem__(self, idx):
+        return self._modules[str(idx)]
+
+
+class _ResBlock(nn.Module):
+    """Parameters of model.py:143-175 (pre_conv BN; conv, BN, conv; 1x1 projection)."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.cin, self.cout = cin, cout
+        self.pre_conv = _Slots(_0=_BatchNorm(cin))
+        self.conv = _Slots(_0=_Conv(cin, cout, 3), _1=_BatchNorm(cout), _3=_Conv(cout, cout, 3))
+        self.conv1by1 = _Conv(cin, cout, 1)
+
+
+class _LSTMWeights(nn.Module):
+    """Parameter set of ``nn.LSTM(input, hidden, num_layers, bidirectional)`` with torch's names and order."""
+
+    def __init__(self, input_size, hidden_size, num_layers, bidirectional):
+        super().__init__()
+        self.input_size, self.hidden_size = input_size, hidden_size
+        self.num_layers, self.num_dirs = num_layers, 2 if bidirectional else 1
+        for layer in range(num_layers):
+            in_sz = input_size if layer == 0 else hidden_size * self.num_dirs
+            for d in range(self.num_dirs):
+                sfx = f"_l{layer}" + ("_reverse" if d else "")
+                self.register_parameter("weight_ih" + sfx, nn.Parameter(torch.empty(4 * hidden_size, in_sz)))
+                self.register_parameter("weight_hh" + sfx, nn.Parameter(torch.empty(4 * hidden_size, hidden_size)))
+                self.register_parameter("bias_ih" + sfx, nn.Parameter(torch.empty(4 * hidden_size)))
+                self.register_parameter("bias_hh" + sfx, nn.Parameter(torch.empty(4 * hidden_size)))
+
+    def cell(self, layer, d):
+        sfx = f"_l{layer}" + ("_reverse" if d else "")
+        return (getattr(self, "weight_ih" + sfx), getattr(self, "weight_hh" + sfx),
+                getattr(self, "bias_ih" + sfx), getattr(self, "bias_hh" + sfx))
+
+
+class SequenceModel(nn.Module):
+    """Temporal block of model.py:196-256.  ``bilstm`` runs on the HIP recurrence kernels."""
+
+    def __init__(self, input_size, model_type="bilstm", hidden_size=384, num_layers=2, dropout=0.3,
+                 bidirectional=True, nhead=8, dim_feedforward=1024, max_len=2000):
+        super().__init__()
+        self.model_type = model_type.lower()
+        self.input_size, self.hidden_size = input_size, hidden_size
+        self.bidirectional, self.num_layers = bidirectional, num_layers
+        if self.model_type == "bilstm":
+            self.dropout = dropout if num_layers > 1 else 0.0
+            self.model = _LSTMWeights(input_size, hidden_size, num_layers, bidirectional)
+            self._output_dim = hidden_size * (2 if bidirectional else 1)
+        elif self.model_type == "transformer":
+            raise NotImplementedError("sequence_model.model_type='transformer' is not on the HIP path yet")
+        else:
+            raise ValueError(f"Unsupported sequence model type: {model_type}")
+
+    @property
+    def output_dim(self):
+        return self._output_dim
+
+
+class _Linear(nn.Module):
+    def __init__(self, d_in, d_out):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(d_out, d_in))
+        self.bias = nn.Parameter(torch.zeros(d_out))
+
+
+# --------------------------------------------------------------------------- the network function
+class _Ctx:
+    """Tensors one forward pass leaves behind for its backward."""
+
+
+def _bn(mod: _BatchNorm, x, train: bool):
+    if train:
+        st = ops.bn_train_stats(x, mod.weight, mod.bias, mod.running_mean, mod.running_var, mod.eps, mod.momentum)
+        mod.num_batches_tracked += 1
+        return st
+    return ops.bn_eval_affine(mod.weight, mod.bias, mod.running_mean, mod.running_var, mod.eps)
+
+
+def _flat2(t):
+    return t.view(-1, t.shape[-1])
+
+
+def _res_forward(blk: _ResBlock, x, pool, train, need_grad, slope):
+    """x [B,T,F,Cin] -> [B,T,F/pool,Cout]; returns (out, saved)."""
+    s = _Ctx()
+    s.x = x
+    s.bn_pre = _bn(blk.pre_conv[0], x, train)
+    s.p = ops.bn_act_pool_fwd(x, s.bn_pre, pool=pool, slope=slope)
+    out = ops.gemm_nt(_flat2(s.p), blk.conv1by1.weight.view(blk.cout, blk.cin)).view(*s.p.shape[:3], blk.cout)
+    wf0, s.wd0 = ops.conv3x3_repack(blk.conv[0].weight, True, need_grad)
+    s.c = ops.conv3x3_fwd(s.p, wf0)
+    s.bn_mid = _bn(blk.conv[1], s.c, train)
+    s.a = ops.bn_act_pool_fwd(s.c, s.bn_mid, pool=1, slope=slope)
+    wf3, s.wd3 = ops.conv3x3_repack(blk.conv[3].weight, True, need_grad)
+    ops.conv3x3_fwd(s.a, wf3, out=out, accumulate=True)      # conv(x) + conv1by1(x), model.py:171-172
+    return out, s
+
+
+def _res_backward(blk: _ResBlock, s, d_out, pool, slope, grads):
+    """d_out: grad of the block output.  Returns grad wrt the block input (dense, overwritten)."""
+    ops.conv3x3_wgrad(s.a, d_out, grads[blk.conv[3].weight])
+    d_a = ops.conv3x3_fwd(d_out, s.wd3)
+    d_c = ops.bn_act_pool_bwd(s.c, d_a, s.bn_mid, grads[blk.conv[1].weight], grads[blk.conv[1].bias], pool=1,
+                              slope=slope, dx=d_a)
+    ops.conv3x3_wgrad(s.p, d_c, grads[blk.conv[0].weight])
+    d_p = ops.conv3x3_fwd(d_c, s.wd0)
+    ops.gemm_tn(_flat2(d_out), _flat2(s.p), out=grads[blk.conv1by1.weight].view(blk.cout, blk.cin))
+    w1t = ops.transpose2d(blk.conv1by1.weight.view(blk.cout, blk.cin))
+    ops.gemm_nt(_flat2(d_out), w1t, out=_flat2(d_p), accumulate=True)
+    return ops.bn_act_pool_bwd(s.x, d_p, s.bn_pre, grads[blk.pre_conv[0].weight], grads[blk.pre_conv[0].bias],
+                               pool=pool, slope=slope)
+
+
+class _DropoutCfg:
+    def __init__(self, seed=0):
+        self.seed = int(seed)
+        self.offset = 0
+        self.inject = None          # optional iterator of uint8 masks replayed instead of Philox (parity tests)
+
+    def next_offset(self, n_quads):
+        off = self.offset
+        self.offset += int(n_quads)
+        return off
+
+
+def _dropout(cfg: _DropoutCfg, x2d, p, out2d=None):
+    """Returns (y, mask).  p == 0 -> identity (mask None)."""
+    if p <= 0.0:
+        if out2d is not None:
+            ops.copy2d(x2d, out2d)
+            return out2d, None
+        return x2d, None
+    mask_in = next(cfg.inject) if cfg.inject is not None else None
+    quads = x2d.shape[0] * (x2d.shape[1] // 4)
+    return ops.dropout(x2d, p, out2d=out2d, mask_in=mask_in, seed=cfg.seed, offset=cfg.next_offset(quads))
+
+
+def _dropout_bwd(dy2d, p, mask, out2d=None):
+    if mask is None:
+        if out2d is not None:
+            ops.copy2d(dy2d, out2d)
+            return out2d
+        return dy2d
+    out, _ = ops.dropout(dy2d, p, out2d=out2d, mask_in=mask)
+    return out
+
+
+def _lstm_forward(models, xs, train, need_grad, drop: _DropoutCfg):
+    """models: list of SequenceModel (identical shapes); xs: list of [B,T,in].  One launch per time step
+    advances every (model, direction) cell of a layer together."""
+    m0 = models[0].model
+    H, L, ND = m0.hidden_size, m0.num_layers, m0.num_dirs
+    B, T = xs[0].shape[:2]
+    saved = []
+    cur = list(xs)
+    for layer in range(L):
+        lay = _Ctx()
+        lay.x = cur
+        lay.gates, lay.cbuf, lay.y, lay.mask = [], [], [], []
+        ys = [torch.empty((B, T, ND * H), dtype=torch.float32, device=cur[0].device) for _ in models]
+        whh, gts, ysl, cbs, rev = [], [], [], [], []
+        for mi, sm in enumerate(models):
+            for d in range(ND):
+                w_ih, w_hh, b_ih, b_hh = sm.model.cell(layer, d)
+                g = ops.gemm_nt(_flat2(cur[mi]), w_ih, bias0=b_ih, bias1=b_hh).view(B, T, 4 * H)
+                cb = torch.empty((B, T, H), dtype=torch.float32, device=g.device)
+                whh.append(w_hh); gts.append(g); cbs.append(cb); rev.append(d)
+                ysl.append(ys[mi][:, :, d * H:(d + 1) * H])
+        ops.lstm_fwd(whh, gts, ysl, cbs, rev, B, T, H)
+        lay.gates, lay.cbuf, lay.y = gts, cbs, ys
+        nxt = []
+        for mi, sm in enumerate(models):
+            p = sm.dropout if (train and layer < L - 1) else 0.0
+            yd, mask = _dropout(drop, _flat2(ys[mi]), p)
+            lay.mask.append((p, mask))
+            nxt.append(yd.view(B, T, ND * H))
+        cur = nxt
+        saved.append(lay if need_grad else None)
+    return cur, saved
+
+
+def _lstm_backward(models, saved, dys, grads):
+    """dys: list of [B,T,ND*H] grads of the top layer outputs.  Returns grads of the inputs."""
+    m0 = models[0].model
+    H, L, ND = m0.hidden_size, m0.num_layers, m0.num_dirs
+    B, T = dys[0].shape[:2]
+    dev = dys[0].device
+    for layer in reversed(range(L)):
+        lay = saved[layer]
+        dys = [_dropout_bwd(_flat2(dys[mi]), lay.mask[mi][0], lay.mask[mi][1]).view(B, T, ND * H)
+               for mi in range(len(models))]
+        whh_t, dsl, dcs, rev = [], [], [], []
+        for mi, sm in enumerate(models):
+            for d in range(ND):
+                _, w_hh, _, _ = sm.model.cell(layer, d)
+                whh_t.append(ops.transpose2d(w_hh))
+                dsl.append(dys[mi][:, :, d * H:(d + 1) * H])
+                dcs.append(torch.empty((B, H), dtype=torch.float32, device=dev))
+                rev.append(d)
+        ops.lstm_bwd(whh_t, lay.gates, lay.cbuf, dsl, dcs, rev, B, T, H)      # gates now hold d(pre-activations)
+        dxs = []
+        for mi, sm in enumerate(models):
+            x2 = _flat2(lay.x[mi])
+            dx = torch.empty_like(lay.x[mi])
+            for d in range(ND):
+                w_ih, w_hh, b_ih, b_hh = sm.model.cell(layer, d)
+                dg = lay.gates[mi * ND + d]
+                dg2 = _flat2(dg)
+                ops.gemm_tn(dg2, x2, out=grads[w_ih])
+                ops.lstm_whh_grad(dg, lay.y[mi][:, :, d * H:(d + 1) * H], grads[w_hh], d, B, T, H)
+                ops.colsum(dg2, grads[b_ih], grads[b_hh])
+                ops.gemm_nt(dg2, ops.transpose2d(w_ih), out=_flat2(dx), accumulate=(d > 0))
+            dxs.append(dx)
+        dys = dxs
+    return dys
+
+
+class _JDCFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, x, _anchor, need_grad):
+        out_cls, out_det, saved = net._forward_impl(x, need_grad)
+        ctx.net, ctx.saved = net, saved
+        return out_cls, out_det
+
+    @staticmethod
+    def backward(ctx, d_cls, d_det):
+        if ctx.saved is None:
+            raise RuntimeError("JDCNet backward called on a forward that ran without gradient bookkeeping")
+        ctx.net._backward_impl(ctx.saved, d_cls, d_det)
+        ctx.saved = None
+        return None, None, None, None
+
+
+class JDCNet(nn.Module):
+    """Joint Detection and Classification network (reference model.py:13-122) on HIP kernels."""
+
+    def __init__(self, num_class=722, leaky_relu_slope=0.01, sequence_model_config=None):
+        super().__init__()
+        self.num_class = num_class
+        self.leaky_relu_slope = leaky_relu_slope
+        sequence_model_config = sequence_model_config if sequence_model_config is not None else {}
+
+        self.conv_block = _Slots(_0=_Conv(1, 64, 3), _1=_BatchNorm(64), _3=_Conv(64, 64, 3))
+        self.res_block1 = _ResBlock(64, 128)
+        self.res_block2 = _ResBlock(128, 192)
+        self.res_block3 = _ResBlock(192, 256)
+        self.pool_block = _Slots(_0=_BatchNorm(256))
+        self.detector_conv = _Slots(_0=_Conv(640, 256, 1), _1=_BatchNorm(256))
+
+        sequence_model_config.setdefault("input_size", 512)          # model.py:59 (mutates the caller's dict)
+        self.sequence_classifier = SequenceModel(**sequence_model_config)
+        self.sequence_detector = SequenceModel(**sequence_model_config)
+        self.classifier = _Linear(self.sequence_classifier.output_dim, num_class)
+        self.detector = _Linear(self.sequence_detector.output_dim, 2)
+
+        self.block_dropout = 0.5                                       # model.py:40,56
+        self.dropout_cfg = _DropoutCfg()
+        self.training_graph_wanted = True
+        self._init_weights()
+        self._flat = None
+        self._grad_flat = None
+        self._flatten()
+
+    # ---- initialisation (model.py:124-140) -------------------------------------------------
+    def _init_weights(self):
+        for m in self.modules():
+            if isinstance(m, _Linear):
+                nn.init.kaiming_uniform_(m.weight)
+                nn.init.constant_(m.bias, 0)
+            elif isinstance(m, _Conv):
+                nn.init.xavier_normal_(m.weight)
+            elif isinstance(m, _LSTMWeights):
+                for p in m.parameters():
+                    if p.dim() >= 2:
+                        nn.init.orthogonal_(p.data)
+                    else:
+                        nn.init.normal_(p.data)
+
+    # ---- flat parameter / gradient storage --------------------------------------------------
+    def _flatten(self):
+        params = list(self.parameters())
+        if not params:
+            return
+        device = params[0].device
+        offsets, total = [], 0
+        for p in params:
+            offsets.append(total)
+            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        flat = torch.zeros(total, dtype=torch.float32, device=device)
+        for p, off in zip(params, offsets):
+            view = flat[off:off + p.numel()].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+        self._flat = flat
+        self._flat.requires_grad_(True)
+        self._grad_flat = None
+        self._param_offsets = {id(p): off for p, off in zip(params, offsets)}
+        self._param_list = params
+
+    def _apply(self, fn, recurse=True):
+        out = super()._apply(fn, recurse)
+        self._flatten()                    # .to(device) / .float() re-materialise parameters: re-pack them
+        return out
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        res = super().load_state_dict(state_dict, strict=strict, assign=False)
+        return res
+
+    @property
+    def flat_parameters(self) -> torch.Tensor:
+        return self._flat
+
+    def flat_gradients(self) -> torch.Tensor:
+        """The flat gradient buffer; ``p.grad`` of every parameter is a view into it."""
+        if self._grad_flat is None or self._grad_flat.device != self._flat.device:
+            self._grad_flat = torch.zeros_like(self._flat, requires_grad=False)
+        return self._grad_flat
+
+    def _grad_views(self):
+        gflat = self.flat_gradients()
+        views = {}
+        for p in self._param_list:
+            off = self._param_offsets[id(p)]
+            g = gflat[off:off + p.numel()].view_as(p)
+            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+                p.grad = g
+            views[p] = g
+        return views
+
+    # ---- forward / backward -----------------------------------------------------------------
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("JDCNet (HIP) needs device tensors; there is no CPU fallback")
+        if x.dim() != 4 or x.shape[1] != 1:
+            raise ValueError("expected input of shape (B, 1, T, n_mels)")
+        need_grad = torch.is_grad_enabled() and self.training_graph_wanted
+        return _JDCFunction.apply(self, x, self._flat, need_grad)
+
+    def _forward_impl(self, x, need_grad):
+        train = self.training
+        slope = self.leaky_relu_slope
+        s = _Ctx()
+        x_btf = x[:, 0].float()
+        B, T, F = x_btf.shape
+        s.x_btf = x_btf
+        cbk = self.conv_block
+        s.y0 = ops.conv3x3_c1_fwd(x_btf, cbk[0].weight)
+        s.bn0 = _bn(cbk[1], s.y0, train)
+        s.a0 = ops.bn_act_pool_fwd(s.y0, s.bn0, pool=1, slope=slope)
+        wf, s.wd_cb = ops.conv3x3_repack(cbk[3].weight, True, need_grad)
+        s.cb = ops.conv3x3_fwd(s.a0, wf)                                            # convblock_out
+        s.rb1, s.r1 = _res_forward(self.res_block1, s.cb, 2, train, need_grad, slope)
+        s.rb2, s.r2 = _res_forward(self.res_block2, s.rb1, 2, train, need_grad, slope)
+        s.rb3, s.r3 = _res_forward(self.res_block3, s.rb2, 2, train, need_grad, slope)
+
+        # pool_block -> channels [384, 640) of the detector concat (model.py:36-41,90,108)
+        Fp = s.rb3.shape[2] // 4
+        if Fp != 2:
+            raise ValueError("JDCNet geometry expects 80 mel bins (F/40 == 2)")
+        s.bnp = _bn(self.pool_block[0], s.rb3, train)
+        pooled = ops.bn_act_pool_fwd(s.rb3, s.bnp, pool=4, slope=slope)            # [B,T,2,256]
+        s.concat = torch.empty((B, T, 2, 640), dtype=torch.float32, device=x.device)
+        p_blk = self.block_dropout if train else 0.0
+        cslice = s.concat.view(-1, 640)[:, 384:640]
+        _, s.mask_pool = _dropout(self.dropout_cfg, _flat2(pooled), p_blk, out2d=cslice)
+        seq_c = ops.nhwc_to_seq(s.concat, 256, coff=384)
+
+        ops.maxpool_fwd(s.cb, 40, out=s.concat, coff=0)
+        ops.maxpool_fwd(s.rb1, 20, out=s.concat, coff=64)
+        ops.maxpool_fwd(s.rb2, 10, out=s.concat, coff=192)
+        wdet = self.detector_conv[0].weight.view(256, 640)
+        s.dconv = ops.gemm_nt(s.concat.view(-1, 640), wdet).view(B, T, 2, 256)
+        s.bnd = _bn(self.detector_conv[1], s.dconv, train)
+        dact = ops.bn_act_pool_fwd(s.dconv, s.bnd, pool=1, slope=slope)
+        ddrop, s.mask_det = _dropout(self.dropout_cfg, _flat2(dact), p_blk)
+        seq_d = ops.nhwc_to_seq(ddrop.view(B, T, 2, 256), 256)
+
+        models = [self.sequence_classifier, self.sequence_detector]
+        (yc, yd), s.lstm = _lstm_forward(models, [seq_c, seq_d], train, need_grad, self.dropout_cfg)
+        s.yc, s.yd = yc, yd
+        D = yc.shape[-1]
+        if self.num_class == 1:
+            out_cls = ops.head_fwd(yc.view(-1, D), self.classifier.weight, self.classifier.bias).view(B, T, 1)
+        else:
+            out_cls = ops.gemm_nt(yc.view(-1, D), self.classifier.weight, bias0=self.classifier.bias)
+            out_cls = out_cls.view(B, T, self.num_class)
+        out_det = ops.head_fwd(yd.view(-1, D), self.detector.weight, self.detector.bias).view(B, T)
+        s.shape = (B, T, F)
+        return out_cls, out_det, (s if need_grad else None)
+
+    def _backward_impl(self, s, d_cls, d_det):
+        g = self._grad_views()
+        slope = self.leaky_relu_slope
+        B, T, F = s.shape
+        D = s.yc.shape[-1]
+        dev = s.yc.device
+        if d_cls is None:
+            d_cls = torch.zeros((B, T, self.num_class), dtype=torch.float32, device=dev)
+        if d_det is None:
+            d_det = torch.zeros((B, T), dtype=torch.float32, device=dev)
+        d_cls = d_cls.contiguous().float()
+        d_det = d_det.contiguous().float()
+        cls, det = self.classifier, self.detector
+        if self.num_class == 1:
+            dyc = ops.head_bwd(s.yc.view(-1, D), cls.weight, d_cls.view(-1), g[cls.weight], g[cls.bias])
+        else:
+            d2 = d_cls.view(-1, self.num_class)
+            ops.gemm_tn(d2, s.yc.view(-1, D), out=g[cls.weight])
+            ops.colsum(d2, g[cls.bias])
+            dyc = ops.gemm_nt(d2, ops.transpose2d(cls.weight))
+        dyd = ops.head_bwd(s.yd.view(-1, D), det.weight, d_det.view(-1), g[det.weight], g[det.bias])
+
+        models = [self.sequence_classifier, self.sequence_detector]
+        dseq_c, dseq_d = _lstm_backward(models, s.lstm, [dyc.view(B, T, D), dyd.view(B, T, D)], g)
+
+        # detector branch (model.py:103-112)
+        p_blk = self.block_dropout
+        d_ddrop = torch.empty((B, T, 2, 256), dtype=torch.float32, device=dev)
+        ops.seq_to_nhwc(dseq_d, d_ddrop, 256)
+        d_dact = _dropout_bwd(_flat2(d_ddrop), p_blk, s.mask_det).view(B, T, 2, 256)
+        bn1 = self.detector_conv[1]
+        d_dconv = ops.bn_act_pool_bwd(s.dconv, d_dact, s.bnd, g[bn1.weight], g[bn1.bias], pool=1, slope=slope)
+        wdet = self.detector_conv[0].weight
+        ops.gemm_tn(_flat2(d_dconv), s.concat.view(-1, 640), out=g[wdet].view(256, 640))
+        d_concat = ops.gemm_nt(_flat2(d_dconv), ops.transpose2d(wdet.view(256, 640))).view(B, T, 2, 640)
+        # classifier branch joins at the pool_block output (channels 384..639 of the concat)
+        ops.seq_to_nhwc(dseq_c, d_concat, 256, coff=384, accumulate=True)
+        d_pool = torch.empty((B, T, 2, 256), dtype=torch.float32, device=dev)
+        _dropout_bwd(d_concat.view(-1, 640)[:, 384:640], p_blk if s.mask_pool is not None else 0.0, s.mask_pool,
+                     out2d=_flat2(d_pool))
+        bnp = self.pool_block[0]
+        d_rb3 = ops.bn_act_pool_bwd(s.rb3, d_pool, s.bnp, g[bnp.weight], g[bnp.bias], pool=4, slope=slope)
+
+        d_rb2 = _res_backward(self.res_block3, s.r3, d_rb3, 2, slope, g)
+        ops.maxpool_bwd_add(s.rb2, d_concat, d_rb2, 10, coff=192)
+        d_rb1 = _res_backward(self.res_block2, s.r2, d_rb2, 2, slope, g)
+        ops.maxpool_bwd_add(s.rb1, d_concat, d_rb1, 20, coff=64)
+        d_cb = _res_backward(self.res_block1, s.r1, d_rb1, 2, slope, g)
+        ops.maxpool_bwd_add(s.cb, d_concat, d_cb, 40, coff=0)
+
+        cbk = self.conv_block
+        ops.conv3x3_wgrad(s.a0, d_cb, g[cbk[3].weight])
+        d_a0 = ops.conv3x3_fwd(d_cb, s.wd_cb)
+        d_y0 = ops.bn_act_pool_bwd(s.y0, d_a0, s.bn0, g[cbk[1].weight], g[cbk[1].bias], pool=1, slope=slope, dx=d_a0)
+        ops.conv3x3_c1_wgrad(s.x_btf, d_y0, g[cbk[0].weight])
+        hook = getattr(self, "_grads_ready_hook", None)
+        if hook is not None:
+            hook()

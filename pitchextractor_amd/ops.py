@@ -1,0 +1,449 @@
+"""Tensor-level wrappers over the C ABI (include/pitchextractor_hip.h).
+
+Every function checks operand shapes/devices on the host before a kernel is launched (an
+out-of-bounds launch can reset the GPU), passes raw device pointers plus the current HIP
+stream, and never falls back to a torch op.  Activations are channels-last:
+``[B, T, F, C]`` float32 contiguous.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+_WS: dict = {}
+
+
+def _chk(cond, msg):
+    if not cond:
+        raise ValueError(msg)
+
+
+def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    _chk(t.is_cuda, f"{name}: expected a HIP device tensor (no CPU fallback)")
+    _chk(t.dtype == torch.float32, f"{name}: expected float32")
+    return t
+
+
+def _dense(t: torch.Tensor, name: str) -> torch.Tensor:
+    _f32c(t, name)
+    _chk(t.is_contiguous(), f"{name}: expected a contiguous tensor")
+    return t
+
+
+def _rows2d(t: torch.Tensor, name: str):
+    """(rows, cols, ld) of a 2-D row-major view whose rows may be strided."""
+    _f32c(t, name)
+    _chk(t.dim() == 2 and t.stride(1) == 1, f"{name}: expected 2-D with unit column stride")
+    ld = t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+    return t.shape[0], t.shape[1], ld
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Grow-only per-device scratch buffer (bytes).  Consumers on one stream run in order, so
+    a single buffer is shared by all ops."""
+    key = torch.device(device)
+    buf = _WS.get(key)
+    nbytes = max(int(nbytes), 1 << 20)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=key)
+        _WS[key] = buf
+    return buf
+
+
+def _call(name, *args):
+    lib = _lib.load()
+    _lib.check(getattr(lib, name)(*args), name)
+
+
+def _s():
+    return _lib.stream_ptr()
+
+
+# ------------------------------------------------------------------ GEMM
+def gemm_nt(A, B, bias0=None, bias1=None, out=None, accumulate=False):
+    """out[M,N] = A[M,K] @ B[N,K]^T + bias0 + bias1 (+ out)."""
+    M, K, lda = _rows2d(A, "A")
+    N, K2, ldb = _rows2d(B, "B")
+    _chk(K == K2, "gemm_nt: K mismatch")
+    if out is None:
+        _chk(not accumulate, "accumulate needs out")
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    Mo, No, ldc = _rows2d(out, "out")
+    _chk((Mo, No) == (M, N), "gemm_nt: out shape")
+    for b in (bias0, bias1):
+        if b is not None:
+            _chk(_dense(b, "bias").numel() == N, "bias size")
+    _call("pe_gemm_nt", A.data_ptr(), lda, B.data_ptr(), ldb, out.data_ptr(), ldc, M, N, K,
+          _lib.ptr(bias0), _lib.ptr(bias1), int(bool(accumulate)), _s())
+    return out
+
+
+def gemm_tn(A, B, out=None, accumulate=False):
+    """out[M,N] = A[K,M]^T @ B[K,N] (+ out); deterministic split-K."""
+    K, M, lda = _rows2d(A, "A")
+    K2, N, ldb = _rows2d(B, "B")
+    _chk(K == K2, "gemm_tn: K mismatch")
+    if out is None:
+        _chk(not accumulate, "accumulate needs out")
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    Mo, No, ldc = _rows2d(out, "out")
+    _chk((Mo, No) == (M, N), "gemm_tn: out shape")
+    lib = _lib.load()
+    need = lib.pe_gemm_tn_workspace_bytes(M, N, K)
+    ws = workspace(need, A.device)
+    _call("pe_gemm_tn", A.data_ptr(), lda, B.data_ptr(), ldb, out.data_ptr(), ldc, M, N, K,
+          int(bool(accumulate)), ws.data_ptr(), ws.numel(), _s())
+    return out
+
+
+def transpose2d(x, out=None):
+    x = _dense(x, "x")
+    _chk(x.dim() == 2, "transpose2d: 2-D")
+    if out is None:
+        out = torch.empty((x.shape[1], x.shape[0]), dtype=torch.float32, device=x.device)
+    _chk(_dense(out, "out").numel() == x.numel(), "transpose2d: out size")
+    _call("pe_transpose2d", x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], _s())
+    return out
+
+
+# ------------------------------------------------------------------ conv
+def conv3x3_repack(w, want_fwd=True, want_dgrad=True):
+    """OIHW (Cout,Cin,3,3) -> (w_fwd [Cout, 9*Cin], w_dgrad [Cin, 9*Cout])."""
+    w = _dense(w, "w")
+    _chk(w.dim() == 4 and w.shape[2:] == (3, 3), "conv3x3_repack: OIHW 3x3")
+    co, ci = w.shape[0], w.shape[1]
+    wf = torch.empty((co, 9 * ci), dtype=torch.float32, device=w.device) if want_fwd else None
+    wd = torch.empty((ci, 9 * co), dtype=torch.float32, device=w.device) if want_dgrad else None
+    _call("pe_conv3x3_repack", w.data_ptr(), _lib.ptr(wf), _lib.ptr(wd), co, ci, _s())
+    return wf, wd
+
+
+def conv3x3_fwd(x, w_packed, out=None, accumulate=False):
+    """x [B,T,F,C], w_packed [N, 9*C] -> y [B,T,F,N] (+= when accumulate)."""
+    x = _dense(x, "x")
+    w_packed = _dense(w_packed, "w_packed")
+    _chk(x.dim() == 4 and w_packed.dim() == 2, "conv3x3_fwd: ranks")
+    B, T, F, Cc = x.shape
+    N = w_packed.shape[0]
+    _chk(w_packed.shape[1] == 9 * Cc, "conv3x3_fwd: weight K")
+    if out is None:
+        _chk(not accumulate, "accumulate needs out")
+        out = torch.empty((B, T, F, N), dtype=torch.float32, device=x.device)
+    _chk(_dense(out, "out").shape == (B, T, F, N), "conv3x3_fwd: out shape")
+    _call("pe_conv3x3_fwd", x.data_ptr(), w_packed.data_ptr(), out.data_ptr(), B, T, F, Cc, N,
+          int(bool(accumulate)), _s())
+    return out
+
+
+def conv3x3_wgrad(x, dy, dw):
+    """dw (OIHW view, contiguous) = grad of conv3x3 wrt weights."""
+    x = _dense(x, "x")
+    dy = _dense(dy, "dy")
+    dw = _dense(dw, "dw")
+    B, T, F, Ci = x.shape
+    Co = dy.shape[3]
+    _chk(dy.shape[:3] == (B, T, F), "conv3x3_wgrad: dy shape")
+    _chk(dw.shape == (Co, Ci, 3, 3), "conv3x3_wgrad: dw shape")
+    lib = _lib.load()
+    ws = workspace(lib.pe_conv3x3_wgrad_workspace_bytes(B, T, F, Ci, Co), x.device)
+    _call("pe_conv3x3_wgrad", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, T, F, Ci, Co,
+          ws.data_ptr(), ws.numel(), _s())
+    return dw
+
+
+def _btf_view(x):
+    """(B,T,F) float32 view with arbitrary strides (the mel batch after transpose(-1,-2))."""
+    _f32c(x, "x")
+    _chk(x.dim() == 3, "expected (B,T,F)")
+    return x.shape, x.stride()
+
+
+def conv3x3_c1_fwd(x_btf, w, out=None):
+    (B, T, F), (sb, st, sf) = _btf_view(x_btf)
+    w = _dense(w, "w")
+    _chk(w.shape == (64, 1, 3, 3), "first conv is 1 -> 64")
+    if out is None:
+        out = torch.empty((B, T, F, 64), dtype=torch.float32, device=x_btf.device)
+    _chk(_dense(out, "out").shape == (B, T, F, 64), "conv3x3_c1_fwd: out shape")
+    _call("pe_conv3x3_c1_fwd", x_btf.data_ptr(), sb, st, sf, w.data_ptr(), out.data_ptr(), B, T, F, _s())
+    return out
+
+
+def conv3x3_c1_wgrad(x_btf, dy, dw):
+    (B, T, F), (sb, st, sf) = _btf_view(x_btf)
+    dy = _dense(dy, "dy")
+    dw = _dense(dw, "dw")
+    _chk(dy.shape == (B, T, F, 64) and dw.shape == (64, 1, 3, 3), "conv3x3_c1_wgrad: shapes")
+    lib = _lib.load()
+    ws = workspace(lib.pe_conv3x3_wgrad_workspace_bytes(B, T, F, 1, 64), dy.device)
+    _call("pe_conv3x3_c1_wgrad", x_btf.data_ptr(), sb, st, sf, dy.data_ptr(), dw.data_ptr(), B, T, F,
+          ws.data_ptr(), ws.numel(), _s())
+    return dw
+
+
+# ------------------------------------------------------------------ BN / pooling / dropout
+class BnState:
+    """Per-call BN tensors: mean, invstd, scale, shift (all [C])."""
+
+    def __init__(self, C_, device):
+        buf = torch.empty((4, C_), dtype=torch.float32, device=device)
+        self.mean, self.invstd, self.scale, self.shift = buf[0], buf[1], buf[2], buf[3]
+
+
+def bn_train_stats(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1):
+    x = _dense(x, "x")
+    Cc = x.shape[-1]
+    for t, n in ((gamma, "gamma"), (beta, "beta"), (running_mean, "running_mean"), (running_var, "running_var")):
+        if t is not None:
+            _chk(_dense(t, n).numel() == Cc, f"{n}: size")
+    st = BnState(Cc, x.device)
+    lib = _lib.load()
+    ws = workspace(lib.pe_bn_workspace_bytes(Cc), x.device)
+    _call("pe_bn_train_stats", x.data_ptr(), x.numel() // Cc, Cc, gamma.data_ptr(), beta.data_ptr(), eps, momentum,
+          _lib.ptr(running_mean), _lib.ptr(running_var), st.mean.data_ptr(), st.invstd.data_ptr(),
+          st.scale.data_ptr(), st.shift.data_ptr(), ws.data_ptr(), ws.numel(), _s())
+    return st
+
+
+def bn_eval_affine(gamma, beta, running_mean, running_var, eps=1e-5):
+    Cc = gamma.numel()
+    st = BnState(Cc, gamma.device)
+    for t in (gamma, beta, running_mean, running_var):
+        _chk(_dense(t, "bn tensor").numel() == Cc, "bn tensor size")
+    _call("pe_bn_eval_affine", gamma.data_ptr(), beta.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(),
+          eps, Cc, st.scale.data_ptr(), st.shift.data_ptr(), _s())
+    return st
+
+
+def _slice_target(out, B, T, Fo, Cc, coff):
+    """out is a dense [B,T,Fo,Ctot] tensor; we write channels [coff, coff+C)."""
+    _dense(out, "out")
+    _chk(out.dim() == 4 and out.shape[:3] == (B, T, Fo), "output pixel grid mismatch")
+    ld = out.shape[3]
+    _chk(0 <= coff and coff + Cc <= ld, "channel slice out of range")
+    return ld
+
+
+def bn_act_pool_fwd(x, st: BnState, pool=1, slope=0.01, out=None, coff=0):
+    x = _dense(x, "x")
+    B, T, F, Cc = x.shape
+    Fo = F // pool
+    if out is None:
+        out = torch.empty((B, T, Fo, Cc), dtype=torch.float32, device=x.device)
+    ld = _slice_target(out, B, T, Fo, Cc, coff)
+    _call("pe_bn_act_pool_fwd", x.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), slope, out.data_ptr(),
+          B * T, F, Cc, pool, ld, coff, _s())
+    return out
+
+
+def bn_act_pool_bwd(x, dy, st: BnState, dgamma, dbeta, pool=1, slope=0.01, coff=0, dx=None):
+    x = _dense(x, "x")
+    B, T, F, Cc = x.shape
+    ld = _slice_target(dy, B, T, F // pool, Cc, coff)
+    if dx is None:
+        dx = torch.empty_like(x)
+    _chk(_dense(dx, "dx").shape == x.shape, "dx shape")
+    _chk(_dense(dgamma, "dgamma").numel() == Cc and _dense(dbeta, "dbeta").numel() == Cc, "dgamma/dbeta size")
+    lib = _lib.load()
+    ws = workspace(lib.pe_bn_workspace_bytes(Cc) + 8 * Cc, x.device)
+    _call("pe_bn_act_pool_bwd", x.data_ptr(), dy.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(),
+          st.mean.data_ptr(), st.invstd.data_ptr(), slope, dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+          B * T, F, Cc, pool, ld, coff, ws.data_ptr(), ws.numel(), _s())
+    return dx
+
+
+def maxpool_fwd(x, pool, out=None, coff=0):
+    x = _dense(x, "x")
+    B, T, F, Cc = x.shape
+    Fo = F // pool
+    if out is None:
+        out = torch.empty((B, T, Fo, Cc), dtype=torch.float32, device=x.device)
+    ld = _slice_target(out, B, T, Fo, Cc, coff)
+    _call("pe_maxpool_fwd", x.data_ptr(), out.data_ptr(), B * T, F, Cc, pool, ld, coff, _s())
+    return out
+
+
+def maxpool_bwd_add(x, dy, dx, pool, coff=0):
+    x = _dense(x, "x")
+    B, T, F, Cc = x.shape
+    ld = _slice_target(dy, B, T, F // pool, Cc, coff)
+    _chk(_dense(dx, "dx").shape == x.shape, "dx shape")
+    _call("pe_maxpool_bwd_add", x.data_ptr(), dy.data_ptr(), dx.data_ptr(), B * T, F, Cc, pool, ld, coff, _s())
+    return dx
+
+
+def dropout(x2d, p, out2d=None, mask_in=None, want_mask=True, seed=0, offset=0):
+    """Row-strided 2-D dropout.  Returns (out, mask uint8 [rows, cols] or None)."""
+    rows, cols, ldx = _rows2d(x2d, "x")
+    if out2d is None:
+        out2d = torch.empty((rows, cols), dtype=torch.float32, device=x2d.device)
+    r2, c2, ldy = _rows2d(out2d, "out")
+    _chk((r2, c2) == (rows, cols), "dropout: out shape")
+    mask_out = None
+    if mask_in is not None:
+        _chk(mask_in.is_cuda and mask_in.dtype == torch.uint8 and mask_in.is_contiguous()
+             and mask_in.numel() == rows * cols, "dropout: mask_in")
+    elif want_mask:
+        mask_out = torch.empty((rows, cols), dtype=torch.uint8, device=x2d.device)
+    _call("pe_dropout_fwd", x2d.data_ptr(), ldx, out2d.data_ptr(), ldy, _lib.ptr(mask_in), _lib.ptr(mask_out),
+          rows, cols, float(p), int(seed), int(offset), _s())
+    return out2d, (mask_in if mask_in is not None else mask_out)
+
+
+def nhwc_to_seq(x, Cc, coff=0, out=None):
+    """x dense [B,T,2,Ctot] (channels [coff,coff+C)) -> seq [B,T,2C] with feature c*2+w."""
+    x = _dense(x, "x")
+    B, T, two, ld = x.shape
+    _chk(two == 2 and coff + Cc <= ld, "nhwc_to_seq: shape")
+    if out is None:
+        out = torch.empty((B, T, 2 * Cc), dtype=torch.float32, device=x.device)
+    _chk(_dense(out, "out").shape == (B, T, 2 * Cc), "nhwc_to_seq: out shape")
+    _call("pe_nhwc_to_seq", x.data_ptr(), ld, coff, out.data_ptr(), B * T, Cc, _s())
+    return out
+
+
+def seq_to_nhwc(seq, out, Cc, coff=0, accumulate=False):
+    seq = _dense(seq, "seq")
+    out = _dense(out, "out")
+    B, T, two, ld = out.shape
+    _chk(two == 2 and coff + Cc <= ld and seq.shape == (B, T, 2 * Cc), "seq_to_nhwc: shape")
+    _call("pe_seq_to_nhwc", seq.data_ptr(), out.data_ptr(), ld, coff, B * T, Cc, int(bool(accumulate)), _s())
+    return out
+
+
+def copy2d(src2d, dst2d, accumulate=False):
+    r, c, lds = _rows2d(src2d, "src")
+    r2, c2, ldd = _rows2d(dst2d, "dst")
+    _chk((r, c) == (r2, c2), "copy2d: shape")
+    _call("pe_copy2d", src2d.data_ptr(), lds, dst2d.data_ptr(), ldd, r, c, int(bool(accumulate)), _s())
+    return dst2d
+
+
+# ------------------------------------------------------------------ LSTM
+def _ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def _int_array(vals):
+    arr = (C.c_int * len(vals))()
+    for i, v in enumerate(vals):
+        arr[i] = int(v)
+    return arr
+
+
+def lstm_fwd(whh, gates, y_slices, cbuf, reverse, B, T, H):
+    """Advance len(whh) cells through all T steps.  y_slices[i] is a view [B,T,H] into a dense
+    [B,T,ldy] output (ldy = 2H for bidirectional)."""
+    n = len(whh)
+    _chk(1 <= n <= 4 and len(gates) == len(y_slices) == len(cbuf) == len(reverse) == n, "lstm_fwd: cell lists")
+    ldy = None
+    for i in range(n):
+        _chk(_dense(whh[i], "whh").shape == (4 * H, H), "whh shape")
+        _chk(_dense(gates[i], "gates").shape == (B, T, 4 * H), "gates shape")
+        _chk(_dense(cbuf[i], "cbuf").shape == (B, T, H), "cbuf shape")
+        ys = _f32c(y_slices[i], "y")
+        _chk(ys.shape == (B, T, H) and ys.stride(2) == 1 and ys.stride(0) == T * ys.stride(1), "y slice layout")
+        _chk(ldy in (None, ys.stride(1)), "all y slices share ldy")
+        ldy = ys.stride(1)
+    _call("pe_lstm_fwd", n, _ptr_array(whh), _ptr_array(gates), _ptr_array(y_slices), _ptr_array(cbuf),
+          _int_array(reverse), ldy, B, T, H, _s())
+
+
+def lstm_bwd(whh_t, gates, cbuf, dy_slices, dcarry, reverse, B, T, H):
+    n = len(whh_t)
+    _chk(1 <= n <= 4 and len(gates) == len(dy_slices) == len(cbuf) == len(reverse) == len(dcarry) == n,
+         "lstm_bwd: cell lists")
+    ld = None
+    for i in range(n):
+        _chk(_dense(whh_t[i], "whh_t").shape == (H, 4 * H), "whh_t shape")
+        _chk(_dense(gates[i], "gates").shape == (B, T, 4 * H), "gates shape")
+        _chk(_dense(cbuf[i], "cbuf").shape == (B, T, H), "cbuf shape")
+        _chk(_dense(dcarry[i], "dcarry").shape == (B, H), "dcarry shape")
+        d = _f32c(dy_slices[i], "dy")
+        _chk(d.shape == (B, T, H) and d.stride(2) == 1 and d.stride(0) == T * d.stride(1), "dy slice layout")
+        _chk(ld in (None, d.stride(1)), "all dy slices share ld")
+        ld = d.stride(1)
+    _call("pe_lstm_bwd", n, _ptr_array(whh_t), _ptr_array(gates), _ptr_array(cbuf), _ptr_array(dy_slices),
+          _ptr_array(dcarry), _int_array(reverse), ld, B, T, H, _s())
+
+
+def lstm_whh_grad(dgates, y_slice, dwhh, reverse, B, T, H):
+    _chk(_dense(dgates, "dgates").shape == (B, T, 4 * H), "dgates shape")
+    ys = _f32c(y_slice, "y")
+    _chk(ys.shape == (B, T, H) and ys.stride(2) == 1 and ys.stride(0) == T * ys.stride(1), "y slice layout")
+    _chk(_dense(dwhh, "dwhh").shape == (4 * H, H), "dwhh shape")
+    lib = _lib.load()
+    ws = workspace(lib.pe_lstm_whh_grad_workspace_bytes(B, T, H), dgates.device)
+    _call("pe_lstm_whh_grad", dgates.data_ptr(), ys.data_ptr(), ys.stride(1), dwhh.data_ptr(), B, T, H,
+          int(bool(reverse)), ws.data_ptr(), ws.numel(), _s())
+    return dwhh
+
+
+def colsum(x2d, out0, out1=None):
+    rows, cols, ld = _rows2d(x2d, "x")
+    _chk(_dense(out0, "out0").numel() == cols, "colsum: out size")
+    if out1 is not None:
+        _chk(_dense(out1, "out1").numel() == cols, "colsum: out1 size")
+    lib = _lib.load()
+    ws = workspace(lib.pe_colsum_workspace_bytes(cols), x2d.device)
+    _call("pe_colsum", x2d.data_ptr(), rows, cols, ld, out0.data_ptr(), _lib.ptr(out1), ws.data_ptr(), ws.numel(),
+          _s())
+    return out0
+
+
+# ------------------------------------------------------------------ heads / loss / optimiser
+def head_fwd(x2d, w, bias, out=None):
+    R, D, ldx = _rows2d(x2d, "x")
+    w = _dense(w, "w")
+    bias = _dense(bias, "bias")
+    n_out = w.shape[0]
+    _chk(w.shape == (n_out, D) and bias.numel() == n_out, "head_fwd: weight shape")
+    if out is None:
+        out = torch.empty((R,), dtype=torch.float32, device=x2d.device)
+    _chk(_dense(out, "out").numel() == R, "head_fwd: out size")
+    _call("pe_head_fwd", x2d.data_ptr(), ldx, w.data_ptr(), bias.data_ptr(), n_out, out.data_ptr(), R, D, _s())
+    return out
+
+
+def head_bwd(x2d, w, dy, dw, db, dx=None):
+    R, D, ldx = _rows2d(x2d, "x")
+    n_out = w.shape[0]
+    _chk(_dense(dy, "dy").numel() == R, "head_bwd: dy size")
+    _chk(_dense(dw, "dw").shape == (n_out, D) and _dense(db, "db").numel() == n_out, "head_bwd: grads shape")
+    if dx is None:
+        dx = torch.empty((R, D), dtype=torch.float32, device=x2d.device)
+    R2, D2, lddx = _rows2d(dx, "dx")
+    _chk((R2, D2) == (R, D), "head_bwd: dx shape")
+    lib = _lib.load()
+    ws = workspace(lib.pe_head_bwd_workspace_bytes(D), x2d.device)
+    _call("pe_head_bwd", x2d.data_ptr(), ldx, w.data_ptr(), dy.data_ptr(), n_out, dx.data_ptr(), lddx,
+          dw.data_ptr(), db.data_ptr(), R, D, ws.data_ptr(), ws.numel(), _s())
+    return dx
+
+
+def f0_sil_loss(f0_pred, f0, sil_pred, sil, lambda_f0, grad_scale=1.0, want_grads=True):
+    R = f0.numel()
+    for t, n in ((f0_pred, "f0_pred"), (f0, "f0"), (sil_pred, "sil_pred"), (sil, "sil")):
+        _chk(_dense(t, n).numel() == R, f"{n}: size")
+    out3 = torch.empty((3,), dtype=torch.float32, device=f0.device)
+    d_f0 = torch.empty((R,), dtype=torch.float32, device=f0.device) if want_grads else None
+    d_sil = torch.empty((R,), dtype=torch.float32, device=f0.device) if want_grads else None
+    _call("pe_f0_sil_loss", f0_pred.data_ptr(), f0.data_ptr(), sil_pred.data_ptr(), sil.data_ptr(),
+          float(lambda_f0), R, float(grad_scale), out3.data_ptr(), _lib.ptr(d_f0), _lib.ptr(d_sil), _s())
+    return out3, d_f0, d_sil
+
+
+def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    n = param.numel()
+    for t, nme in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _chk(_dense(t, nme).numel() == n, f"{nme}: size")
+    bc1 = 1.0 - float(beta1) ** int(step)
+    bc2 = 1.0 - float(beta2) ** int(step)
+    _call("pe_adamw_step", param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), n,
+          float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), bc1, bc2, float(grad_scale), _s())

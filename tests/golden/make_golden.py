@@ -1,0 +1,240 @@
+"""Generate the golden vectors under tests/golden/ by importing the reference's own modules.
+
+Run ONLY in the build container (``/root/reference`` present):  python tests/golden/make_golden.py
+The reference never travels; what is committed are inputs-by-seed and its outputs (small .npz).
+
+Importable reference modules used as the direct oracle: model.py, trainer.py,
+optimizers.py, f0_backends.py (``F0Extractor.align_length`` called unbound),
+Utils/dynamic_pitch_tools.py.  ``meldataset.py`` / ``train.py`` are not importable here
+(soundfile / torchaudio / tensorboard missing), so Collater and the mel transform are pinned by
+restatement only (see oracle/__init__.py).
+"""
+import importlib.util
+import io
+import logging
+import sys
+from contextlib import redirect_stdout
+from pathlib import Path
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parent.parent
+REF = Path("/root/reference")
+sys.path.insert(0, str(ROOT))
+
+from oracle import mel_ref, model_ref  # noqa: E402
+from pitchextractor_amd import synthetic  # noqa: E402
+
+SEQ_CFG = {"model_type": "bilstm", "num_layers": 4, "dropout": 0.0, "nhead": 8,
+           "dim_feedforward": 1536, "max_len": 2048}
+
+
+def ref_module(name, rel):
+    spec = importlib.util.spec_from_file_location(name, REF / rel)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def golden_input(seed, B=2, T=192, F=80):
+    """Mel-shaped input (B,1,T,F): smooth positive-ish field like a log-mel in [-1, 1.5]."""
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, 1, T, F)).astype(np.float32) * 0.5 + 0.3
+    return torch.from_numpy(x)
+
+
+def golden_targets(seed, B=2, T=192):
+    rng = np.random.default_rng(seed + 1)
+    f0 = rng.uniform(80.0, 380.0, (B, T)).astype(np.float32)
+    voiced = rng.uniform(size=(B, T)) > 0.3
+    f0 = np.where(voiced, f0, 0.0).astype(np.float32)
+    sil = (f0 == 0).astype(np.float32)
+    return torch.from_numpy(f0), torch.from_numpy(sil)
+
+
+def disable_dropout(model):
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+
+
+def tap_summary(t):
+    t = t.detach().double()
+    flat = t.flatten()
+    idx = torch.linspace(0, flat.numel() - 1, 16).long()
+    return np.concatenate([[t.mean().item(), t.std().item(), t.abs().max().item()], flat[idx].numpy()])
+
+
+def make_model_goldens(ref_model_mod):
+    out = {}
+    for tag, num_class, hidden, dtype in (("nc1", 1, 384, torch.float32), ("nc360", 360, 64, torch.float32),
+                                          ("nc1_f64", 1, 384, torch.float64)):
+        state = model_ref.seeded_state(11, num_class=num_class, hidden_size=hidden)
+        cfg = dict(SEQ_CFG, hidden_size=hidden)
+        net = ref_model_mod.JDCNet(num_class=num_class, sequence_model_config=dict(cfg))
+        missing = net.load_state_dict(state, strict=True)
+        assert not missing.missing_keys and not missing.unexpected_keys
+        disable_dropout(net)
+        net = net.to(dtype)
+        x = golden_input(3).to(dtype)
+        f0, sil = golden_targets(3)
+        f0, sil = f0.to(dtype), sil.to(dtype)
+
+        # eval-mode forward (running statistics)
+        net.eval()
+        with torch.no_grad():
+            cls_e, det_e = net(x)
+        out[f"{tag}_eval_cls"] = cls_e.numpy()
+        out[f"{tag}_eval_det"] = det_e.numpy()
+
+        # train-mode forward/backward with all dropout rates 0
+        net.train()
+        taps = {}
+        hooks = []
+        for name in ("conv_block", "res_block1", "res_block2", "res_block3", "pool_block", "detector_conv",
+                     "sequence_classifier", "sequence_detector"):
+            hooks.append(getattr(net, name).register_forward_hook(
+                lambda m, i, o, n=name: taps.__setitem__(n, o)))
+        cls_t, det_t = net(x)
+        for h in hooks:
+            h.remove()
+        out[f"{tag}_train_cls"] = cls_t.detach().numpy()
+        out[f"{tag}_train_det"] = det_t.detach().numpy()
+        for k, v in taps.items():
+            out[f"{tag}_tap_{k}"] = tap_summary(v)
+        if num_class == 1:
+            l1 = torch.nn.SmoothL1Loss()(cls_t.squeeze(), f0)
+            bce = torch.nn.BCEWithLogitsLoss()(det_t, sil)
+            loss = 0.1 * l1 + bce
+            loss.backward()
+            out[f"{tag}_loss"] = np.array([loss.item(), 0.1 * l1.item(), bce.item()], dtype=np.float64)
+            names, norms = [], []
+            for n, p in net.named_parameters():
+                names.append(n)
+                norms.append(p.grad.double().norm().item())
+            out[f"{tag}_grad_names"] = np.array(names)
+            out[f"{tag}_grad_norms"] = np.array(norms)
+            for n in ("conv_block.0.weight", "conv_block.1.weight", "res_block2.conv.3.weight",
+                      "res_block3.conv1by1.weight", "detector_conv.0.weight",
+                      "sequence_classifier.model.weight_hh_l0", "sequence_detector.model.weight_ih_l3_reverse",
+                      "sequence_classifier.model.bias_ih_l2", "classifier.weight", "detector.bias"):
+                g = dict(net.named_parameters())[n].grad.flatten()
+                idx = torch.linspace(0, g.numel() - 1, min(32, g.numel())).long()
+                out[f"{tag}_grad_{n}"] = g[idx].numpy()
+            sd = net.state_dict()
+            for n in ("conv_block.1.running_mean", "conv_block.1.running_var", "res_block3.conv.1.running_var",
+                      "detector_conv.1.running_mean"):
+                out[f"{tag}_stat_{n}"] = sd[n].numpy()
+    np.savez_compressed(HERE / "model_golden.npz", **out)
+    print("model_golden.npz", len(out), "arrays")
+
+
+def make_optimizer_golden(ref_opt_mod):
+    torch.manual_seed(0)
+    p = torch.nn.Parameter(torch.from_numpy(np.linspace(-1.0, 1.0, 24, dtype=np.float32)))
+    with redirect_stdout(io.StringIO()):
+        opt, sched = ref_opt_mod.build_optimizer({
+            "params": [p], "optimizer_params": {},
+            "scheduler_params": {"max_lr": 3e-4, "pct_start": 0.0, "epochs": 100, "steps_per_epoch": 8}})
+    rng = np.random.default_rng(5)
+    rec = {"lr": [], "beta1": [], "param": [], "exp_avg": [], "exp_avg_sq": []}
+    rec["lr0"] = np.array([opt.param_groups[0]["lr"]])
+    rec["beta1_0"] = np.array([opt.param_groups[0]["betas"][0]])
+    grads = rng.standard_normal((12, 24)).astype(np.float32)
+    for step in range(12):
+        p.grad = torch.from_numpy(grads[step].copy())
+        rec["lr"].append(opt.param_groups[0]["lr"])
+        rec["beta1"].append(opt.param_groups[0]["betas"][0])
+        opt.step()
+        sched.step()
+        rec["param"].append(p.detach().numpy().copy())
+        rec["exp_avg"].append(opt.state[p]["exp_avg"].numpy().copy())
+        rec["exp_avg_sq"].append(opt.state[p]["exp_avg_sq"].numpy().copy())
+    # the schedule far into training as well
+    far = []
+    for _ in range(12, 800):
+        far.append((opt.param_groups[0]["lr"], opt.param_groups[0]["betas"][0]))
+        opt.step()
+        sched.step()
+    np.savez_compressed(HERE / "optimizer_golden.npz", grads=grads, far=np.array(far[::37], dtype=np.float64),
+                        **{k: np.array(v, dtype=np.float64) for k, v in rec.items()})
+    print("optimizer_golden.npz")
+
+
+def training_batches(n_steps, B=4):
+    """Deterministic (mel, f0, sil) batches: synthetic glides -> float64 oracle log-mel -> zero pad to 192."""
+    for s in range(n_steps):
+        waves, f0s, sils = synthetic.batch((s * B) % 32, B)
+        mels = np.zeros((B, 1, 80, 192), dtype=np.float32)
+        for i in range(B):
+            lm = mel_ref.log_mel(waves[i]).astype(np.float32)
+            mels[i, 0, :, :lm.shape[1]] = lm[:, :192]
+        yield torch.from_numpy(mels), torch.from_numpy(f0s), torch.from_numpy(sils)
+
+
+def make_step_golden(ref_model_mod, ref_opt_mod, ref_trainer_mod, n_steps=100):
+    state = model_ref.seeded_state(21, num_class=1, hidden_size=384)
+    net = ref_model_mod.JDCNet(num_class=1, sequence_model_config=dict(SEQ_CFG))
+    net.load_state_dict(state, strict=True)
+    disable_dropout(net)
+    with redirect_stdout(io.StringIO()):
+        opt, sched = ref_opt_mod.build_optimizer({
+            "params": net.parameters(), "optimizer_params": {},
+            "scheduler_params": {"max_lr": 3e-4, "pct_start": 0.0, "epochs": 100, "steps_per_epoch": 8}})
+    crit = {"l1": torch.nn.SmoothL1Loss(), "ce": torch.nn.BCEWithLogitsLoss()}
+    tr = ref_trainer_mod.Trainer(model=net, criterion=crit, optimizer=opt, scheduler=sched, device="cpu",
+                                 loss_config={"lambda_f0": 0.1}, logger=logging.getLogger("golden"))
+    net.train()
+    curve = []
+    for i, batch in enumerate(training_batches(n_steps)):
+        r = tr.run(batch)
+        curve.append([r["loss"], r["f0"], r["sil"]])
+        if i % 10 == 0:
+            print("step", i, r, flush=True)
+    np.savez_compressed(HERE / "step_golden.npz", curve=np.array(curve, dtype=np.float64))
+    print("step_golden.npz")
+
+
+def make_data_golden(ref_f0_mod, ref_tools_mod):
+    out = {}
+    align = ref_f0_mod.F0Extractor.align_length
+    rng = np.random.default_rng(9)
+    for n in (159, 161, 163, 200, 7, 1):
+        v = rng.uniform(80, 400, n)
+        v[rng.uniform(size=n) < 0.3] = 0.0
+        if n >= 20:
+            v[5:9] = 0.0
+        out[f"align_in_{n}"] = v
+        out[f"align_out_{n}"] = align(None, v, 161)
+    out["align_probe"] = align(None, np.array([0, 0, 100, 110, 120, 0, 0, 130, 140, 150], dtype=np.float64), 7)
+    out["align_empty"] = align(None, np.zeros((0,)), 5)
+    audio, t, f0 = ref_tools_mod.generate_glide_waveform(2.0, 60.0, 500.0, 24000)
+    out["glide_head"] = audio[:64]
+    out["glide_tail"] = audio[-64:]
+    out["glide_mid"] = audio[24000:24064]
+    out["glide_f0"] = f0[::4800]
+    out["glide_ref_f0"] = ref_tools_mod.sample_reference_f0(t, f0, 161)
+    np.savez_compressed(HERE / "data_golden.npz", **out)
+    print("data_golden.npz")
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    sys.path.insert(0, str(REF))
+    ref_model = ref_module("ref_model", "model.py")
+    ref_opt = ref_module("ref_optimizers", "optimizers.py")
+    ref_trainer = ref_module("ref_trainer", "trainer.py")
+    ref_f0 = ref_module("ref_f0_backends", "f0_backends.py")
+    ref_tools = ref_module("ref_dynamic_pitch_tools", "Utils/dynamic_pitch_tools.py")
+    what = sys.argv[1:] or ["model", "optimizer", "data", "step"]
+    if "model" in what:
+        make_model_goldens(ref_model)
+    if "optimizer" in what:
+        make_optimizer_golden(ref_opt)
+    if "data" in what:
+        make_data_golden(ref_f0, ref_tools)
+    if "step" in what:
+        make_step_golden(ref_model, ref_opt, ref_trainer)
