@@ -278,6 +278,8 @@ class _JDCFunction(torch.autograd.Function):
     def forward(ctx, net, x, _anchor, need_grad):
         out_cls, out_det, saved = net._forward_impl(x, need_grad)
         ctx.net, ctx.saved = net, saved
+        if net.keep_last_context:
+            net.last_context = saved
         return out_cls, out_det
 
     @staticmethod
@@ -314,6 +316,8 @@ class JDCNet(nn.Module):
         self.block_dropout = 0.5                                       # model.py:40,56
         self.dropout_cfg = _DropoutCfg()
         self.training_graph_wanted = True
+        self.keep_last_context = False      # tests: expose the saved tensors (dropout masks) of the last forward
+        self.last_context = None
         self._init_weights()
         self._flat = None
         self._grad_flat = None

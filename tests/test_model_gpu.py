@@ -1,0 +1,182 @@
+"""JDCNet on the HIP path vs the functional CPU oracle / the reference's golden vectors.
+
+Tolerances: the oracle side is float64 (exact to ~1e-9 against the reference, see
+tests/test_oracle_golden.py), the HIP side is fp32 MFMA (exact-f32 fmaf chains).  Outputs are held
+to 1e-4 of their scale (north_star), per-parameter gradient norms to 2e-3 and the 100-step loss
+curve to 1e-3 relative.
+"""
+import logging
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import model_ref
+from pitchextractor_amd.model import JDCNet
+from pitchextractor_amd.optimizers import build_optimizer
+from pitchextractor_amd.trainer import Trainer
+from tests.golden.make_golden import SEQ_CFG, golden_input, golden_targets, tap_summary, training_batches
+
+pytestmark = pytest.mark.gpu
+
+
+def build(state, num_class, hidden, device, dropout=0.0):
+    cfg = dict(SEQ_CFG, hidden_size=hidden, dropout=dropout)
+    net = JDCNet(num_class=num_class, sequence_model_config=cfg)
+    net.load_state_dict(state, strict=True)
+    return net.to(device)
+
+
+def close(got, ref, tol):
+    got = np.asarray(got.detach().cpu().double() if torch.is_tensor(got) else got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape
+    scale = np.abs(ref).max() + 1e-30
+    assert np.abs(got - ref).max() <= tol * scale, (np.abs(got - ref).max(), scale)
+
+
+@pytest.fixture(scope="module")
+def G(golden_dir):
+    return np.load(golden_dir / "model_golden.npz")
+
+
+def test_state_dict_layout_matches_reference(G, hip_device):
+    net = build(model_ref.seeded_state(11), 1, 384, hip_device)
+    sd = net.state_dict()
+    assert len(sd) == 125 and sum(p.numel() for p in net.parameters()) == 28882755
+    assert [str(n) for n in G["nc1_grad_names"]] == [n for n, _ in net.named_parameters()]
+    assert sd["conv_block.1.num_batches_tracked"].dtype == torch.long
+    assert sd["detector_conv.0.weight"].shape == (256, 640, 1, 1)
+    assert all(p.data_ptr() >= net.flat_parameters.data_ptr() for p in net.parameters())
+
+
+@pytest.mark.parametrize("tag,nc,hidden", [("nc1", 1, 384), ("nc360", 360, 64)])
+def test_eval_forward_matches_reference_golden(G, hip_device, tag, nc, hidden):
+    net = build(model_ref.seeded_state(11, num_class=nc, hidden_size=hidden), nc, hidden, hip_device).eval()
+    with torch.no_grad():
+        cls, det = net(golden_input(3).to(hip_device))
+    assert cls.shape == (2, 192, nc) and det.shape == (2, 192)
+    close(cls, G[f"{tag}_eval_cls"], 1e-4)
+    close(det, G[f"{tag}_eval_det"], 1e-4)
+
+
+@pytest.fixture(scope="module")
+def train_pass(hip_device):
+    net = build(model_ref.seeded_state(11), 1, 384, hip_device).train()
+    net.block_dropout = 0.0
+    net.keep_last_context = True
+    x = golden_input(3).to(hip_device)
+    f0, sil = (t.to(hip_device) for t in golden_targets(3))
+    cls, det = net(x)
+    from pitchextractor_amd import ops
+    out3, d_f0, d_sil = ops.f0_sil_loss(cls.detach().reshape(-1), f0.reshape(-1), det.detach().reshape(-1),
+                                        sil.reshape(-1), 0.1)
+    torch.autograd.backward([cls, det], [d_f0.view_as(cls), d_sil.view_as(det)])
+    return net, cls, det, out3
+
+
+def test_train_forward_loss_and_taps(G, train_pass):
+    net, cls, det, out3 = train_pass
+    close(cls, G["nc1_f64_train_cls"], 1e-4)
+    close(det, G["nc1_f64_train_det"], 1e-4)
+    np.testing.assert_allclose(out3.cpu().numpy(), G["nc1_f64_loss"], rtol=1e-5)
+    s = net.last_context
+    nchw = lambda t: t.permute(0, 3, 1, 2)
+    for name, ours in (("conv_block", nchw(s.cb)), ("res_block1", nchw(s.rb1)), ("res_block2", nchw(s.rb2)),
+                       ("res_block3", nchw(s.rb3)), ("sequence_classifier", s.yc), ("sequence_detector", s.yd)):
+        ref = G[f"nc1_f64_tap_{name}"]
+        got = tap_summary(ours.cpu())
+        assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), name
+
+
+def test_gradients_match_reference_float64(G, train_pass):
+    net = train_pass[0]
+    names = [str(n) for n in G["nc1_f64_grad_names"]]
+    norms = dict(zip(names, G["nc1_f64_grad_norms"]))
+    bad = []
+    for n, p in net.named_parameters():
+        assert p.grad is not None and p.grad.data_ptr() >= net.flat_gradients().data_ptr()
+        got = p.grad.double().norm().item()
+        if abs(got - norms[n]) > 2e-3 * norms[n] + 1e-9:
+            bad.append((n, got, norms[n]))
+    assert not bad, bad
+    for key in G.files:
+        if key.startswith("nc1_f64_grad_") and not key.endswith(("_grad_names", "_grad_norms")):
+            n = key[len("nc1_f64_grad_"):]
+            g = dict(net.named_parameters())[n].grad.flatten().cpu()
+            idx = torch.linspace(0, g.numel() - 1, min(32, g.numel())).long()
+            ref = G[key]
+            assert np.abs(g[idx].numpy() - ref).max() <= 5e-3 * np.abs(ref).max() + 1e-9, n
+
+
+def test_running_stats_updated_like_reference(G, train_pass):
+    sd = train_pass[0].state_dict()
+    for key in G.files:
+        if key.startswith("nc1_f64_stat_"):
+            n = key[len("nc1_f64_stat_"):]
+            close(sd[n], G[key], 1e-5)
+    assert int(sd["conv_block.1.num_batches_tracked"]) == 1
+
+
+def test_dropout_masks_replayed_in_oracle(hip_device):
+    """Train mode with every dropout live: export the HIP masks, replay them in the float64 oracle."""
+    state = model_ref.seeded_state(11, hidden_size=64)
+    net = build(state, 1, 64, hip_device, dropout=0.1).train()
+    net.keep_last_context = True
+    net.dropout_cfg.seed = 77
+    x = golden_input(5)
+    cls, det = net(x.to(hip_device))
+    s = net.last_context
+    masks = [s.mask_pool.cpu().view(2, 192, 2, 256), s.mask_det.cpu().view(2, 192, 2, 256)]
+    for lay in s.lstm[:-1]:
+        masks += [m.cpu().view(2, 192, -1) for (_, m) in lay.mask]
+    assert abs(masks[0].float().mean().item() - 0.5) < 0.02 and abs(masks[2].float().mean().item() - 0.9) < 0.02
+    st64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in state.items()}
+    cfg = dict(SEQ_CFG, hidden_size=64, dropout=0.1)
+    ref_cls, ref_det = model_ref.jdcnet_forward(st64, x.double(), cfg, train=True, masks=iter(masks))
+    close(cls, ref_cls.detach().numpy(), 1e-4)
+    close(det, ref_det.detach().numpy(), 1e-4)
+
+
+def test_hundred_step_loss_curve_matches_reference_trainer(golden_dir, hip_device):
+    """BASELINE config 1 (B=4, default JDCNet+BiLSTM, dropout off): reference Trainer.run x100 on CPU
+    (tests/golden/step_golden.npz) vs the HIP trainer on identical batches."""
+    curve = np.load(golden_dir / "step_golden.npz")["curve"]
+    net = build(model_ref.seeded_state(21), 1, 384, hip_device).train()
+    net.block_dropout = 0.0
+    opt, sched = build_optimizer({"params": net.parameters(), "optimizer_params": {},
+                                  "scheduler_params": {"max_lr": 3e-4, "pct_start": 0.0, "epochs": 100,
+                                                       "steps_per_epoch": 8}})
+    crit = {"l1": torch.nn.SmoothL1Loss(), "ce": torch.nn.BCEWithLogitsLoss()}
+    tr = Trainer(model=net, criterion=crit, optimizer=opt, scheduler=sched, device="cuda:0",
+                 loss_config={"lambda_f0": 0.1}, logger=logging.getLogger("t"))
+    got = []
+    for batch in training_batches(len(curve)):
+        r = tr.run(batch)
+        got.append([r["loss"], r["f0"], r["sil"]])
+    got = np.array(got)
+    rel = np.abs(got[:, 0] - curve[:, 0]) / curve[:, 0]
+    assert rel.max() <= 1e-3, (rel.max(), int(rel.argmax()))
+    assert abs(got[-1, 0] - curve[-1, 0]) <= 1e-3 * curve[-1, 0]
+    assert np.abs(got[:, 2] - curve[:, 2]).max() <= 1e-3 * max(curve[:, 2].max(), 1e-2) + 2e-4
+
+
+def test_full_batch_is_sample_independent_and_deterministic(hip_device):
+    """BASELINE size B=256 in eval mode: every sample's logits equal the same sample run in a batch of 8,
+    bit for bit (tile position must not change a row's summation order), and reruns are identical."""
+    net = build(model_ref.seeded_state(11), 1, 384, hip_device).eval()
+    x8 = golden_input(9, B=8).to(hip_device)
+    big = x8.repeat(32, 1, 1, 1)
+    with torch.no_grad():
+        c8, d8 = net(x8)
+        cb, db = net(big)
+        cb2, db2 = net(big)
+    assert cb.shape == (256, 192, 1)
+    assert torch.equal(cb, cb2) and torch.equal(db, db2)
+    assert torch.equal(cb[:8], c8) and torch.equal(cb[248:], c8) and torch.equal(db[96:104], d8)
+
+
+def test_cpu_input_fails_loudly():
+    net = JDCNet(num_class=1, sequence_model_config=dict(SEQ_CFG))
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 1, 192, 80))

@@ -1,0 +1,317 @@
+"""Each HIP op, called through the C ABI, against a plain PyTorch fp32/fp64 CPU reference of the same op.
+
+fp32 MFMA is an exact-f32 fmaf chain, so GEMM-shaped ops are held to 1e-5 of the result scale
+(north_star: 1e-4 relative for fp32); index/layout work is bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from pitchextractor_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def close(got, ref, tol=1e-5):
+    got = got.detach().cpu().double()
+    ref = ref.detach().double()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    scale = ref.abs().max().item() + 1e-30
+    err = (got - ref).abs().max().item()
+    assert err <= tol * scale, (err, scale)
+
+
+def nhwc(x):      # NCHW -> channels-last contiguous
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(300, 1536, 384), (1000, 64, 576), (257, 192, 96), (130, 20, 64),
+                                   (64, 128, 32), (5, 360, 768), (1024, 256, 640), (33, 1, 4)])
+def test_gemm_nt(hip_device, M, N, K):
+    A, B = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    b0, b1 = rnd(N, seed=3), rnd(N, seed=4)
+    ref = A.double() @ B.double().T
+    close(ops.gemm_nt(A.to(hip_device), B.to(hip_device)), ref)
+    close(ops.gemm_nt(A.to(hip_device), B.to(hip_device), bias0=b0.to(hip_device), bias1=b1.to(hip_device)),
+          ref + b0.double() + b1.double())
+    out = rnd(M, N, seed=5).to(hip_device)
+    ref2 = ref + out.cpu().double()
+    close(ops.gemm_nt(A.to(hip_device), B.to(hip_device), out=out, accumulate=True), ref2)
+
+
+def test_gemm_nt_strided_rows(hip_device):
+    big = rnd(40, 7, 96, seed=6).to(hip_device)              # rows taken at a fixed time step: ld = 7*96
+    A = big[:, 3, 32:96]
+    B = rnd(50, 64, seed=7).to(hip_device)
+    out = torch.zeros(40, 80, device=hip_device)
+    ops.gemm_nt(A, B, out=out[:, 10:60])
+    close(out[:, 10:60], A.cpu().double() @ B.cpu().double().T)
+    assert (out[:, :10] == 0).all() and (out[:, 60:] == 0).all()
+
+
+@pytest.mark.parametrize("K,M,N", [(5000, 64, 64), (3001, 192, 128), (777, 1536, 96), (20000, 128, 64), (64, 4, 8)])
+def test_gemm_tn(hip_device, K, M, N):
+    A, B = rnd(K, M, seed=1), rnd(K, N, seed=2)
+    ref = A.double().T @ B.double()
+    close(ops.gemm_tn(A.to(hip_device), B.to(hip_device)), ref)
+    out = rnd(M, N, seed=3).to(hip_device)
+    ref2 = ref + out.cpu().double()
+    close(ops.gemm_tn(A.to(hip_device), B.to(hip_device), out=out, accumulate=True), ref2)
+
+
+def test_gemm_tn_is_deterministic(hip_device):
+    A, B = rnd(30000, 128, seed=1).to(hip_device), rnd(30000, 128, seed=2).to(hip_device)
+    assert torch.equal(ops.gemm_tn(A, B), ops.gemm_tn(A, B))
+
+
+def test_transpose2d(hip_device):
+    x = rnd(70, 45, seed=1).to(hip_device)
+    assert torch.equal(ops.transpose2d(x).cpu(), x.cpu().T.contiguous())
+
+
+# ------------------------------------------------------------------ conv
+@pytest.mark.parametrize("B,T,Fq,Ci,Co", [(2, 12, 10, 64, 64), (1, 9, 7, 64, 128), (2, 5, 20, 128, 192),
+                                          (1, 6, 10, 192, 256), (1, 4, 5, 256, 256), (3, 16, 40, 128, 128)])
+def test_conv3x3_fwd_dgrad_wgrad(hip_device, B, T, Fq, Ci, Co):
+    x = rnd(B, Ci, T, Fq, seed=1).double().requires_grad_(True)
+    w = rnd(Co, Ci, 3, 3, seed=2, scale=0.1).double().requires_grad_(True)
+    y = F.conv2d(x, w, padding=1)
+    dy = rnd(B, Co, T, Fq, seed=3).double()
+    y.backward(dy)
+    xd, wd_, dyd = nhwc(x.detach().float()).to(hip_device), w.detach().float().to(hip_device), \
+        nhwc(dy.float()).to(hip_device)
+    wf, wdg = ops.conv3x3_repack(wd_)
+    close(nchw(ops.conv3x3_fwd(xd, wf)), y)
+    close(nchw(ops.conv3x3_fwd(dyd, wdg)), x.grad)
+    dw = torch.empty_like(wd_)
+    close(ops.conv3x3_wgrad(xd, dyd, dw), w.grad)
+    acc = rnd(B, T, Fq, Co, seed=4).to(hip_device)
+    ref_acc = y.detach() + nchw(acc.cpu()).double()
+    close(nchw(ops.conv3x3_fwd(xd, wf, out=acc, accumulate=True)), ref_acc)
+
+
+def test_conv3x3_first_layer(hip_device):
+    B, T, Fq = 3, 17, 80
+    mel = rnd(B, 1, Fq, T, seed=1)                          # (B,1,80,T) as the loader yields it
+    x = mel.transpose(-1, -2).double().requires_grad_(False)  # (B,1,T,80) view, what the model receives
+    w = rnd(64, 1, 3, 3, seed=2).double().requires_grad_(True)
+    y = F.conv2d(x, w, padding=1)
+    dy = rnd(B, 64, T, Fq, seed=3).double()
+    y.backward(dy)
+    xv = mel.to(hip_device).transpose(-1, -2)[:, 0]          # strided (B,T,80)
+    assert not xv.is_contiguous()
+    close(nchw(ops.conv3x3_c1_fwd(xv, w.detach().float().to(hip_device))), y)
+    dw = torch.empty(64, 1, 3, 3, device=hip_device)
+    close(ops.conv3x3_c1_wgrad(xv, nhwc(dy.float()).to(hip_device), dw), w.grad)
+
+
+# ------------------------------------------------------------------ BN / LReLU / pool
+@pytest.mark.parametrize("C,Fq,pool", [(64, 80, 1), (64, 80, 2), (128, 40, 2), (192, 20, 2), (256, 10, 4), (256, 2, 1)])
+def test_bn_lrelu_pool_block(hip_device, C, Fq, pool):
+    B, T = 2, 6
+    x = (rnd(B, C, T, Fq, seed=1) * 2 + 0.5).double().requires_grad_(True)
+    bn = torch.nn.BatchNorm2d(C).double()
+    with torch.no_grad():
+        bn.weight.copy_(rnd(C, seed=2).abs() + 0.5)
+        bn.bias.copy_(rnd(C, seed=3))
+        bn.running_mean.copy_(rnd(C, seed=4))
+        bn.running_var.copy_(rnd(C, seed=5).abs() + 0.5)
+    rm0, rv0 = bn.running_mean.clone(), bn.running_var.clone()
+    bn.train()
+    y = F.max_pool2d(F.leaky_relu(bn(x), 0.01), (1, pool)) if pool > 1 else F.leaky_relu(bn(x), 0.01)
+    dy = rnd(*y.shape, seed=6).double()
+    y.backward(dy)
+
+    xd = nhwc(x.detach().float()).to(hip_device)
+    g, b = bn.weight.detach().float().to(hip_device), bn.bias.detach().float().to(hip_device)
+    rm, rv = rm0.float().to(hip_device), rv0.float().to(hip_device)
+    st = ops.bn_train_stats(xd, g, b, rm, rv)
+    close(rm, bn.running_mean)
+    close(rv, bn.running_var)
+    close(nchw(ops.bn_act_pool_fwd(xd, st, pool=pool)), y)
+    dg, db = torch.empty(C, device=hip_device), torch.empty(C, device=hip_device)
+    dx = ops.bn_act_pool_bwd(xd, nhwc(dy.float()).to(hip_device), st, dg, db, pool=pool)
+    close(nchw(dx), x.grad, 2e-5)
+    close(dg, bn.weight.grad, 2e-5)
+    close(db, bn.bias.grad, 2e-5)
+
+    bn.eval()
+    ye = F.leaky_relu(bn(x.detach()), 0.01)
+    ste = ops.bn_eval_affine(g, b, rm, rv)
+    close(nchw(ops.bn_act_pool_fwd(xd, ste, pool=1)), ye)
+
+
+def test_bn_block_into_channel_slice(hip_device):
+    x = rnd(2, 3, 8, 256, seed=1).to(hip_device)
+    st = ops.bn_train_stats(x, torch.ones(256, device=hip_device), torch.zeros(256, device=hip_device), None, None)
+    dense = ops.bn_act_pool_fwd(x, st, pool=4)
+    wide = torch.full((2, 3, 2, 640), 7.0, device=hip_device)
+    ops.bn_act_pool_fwd(x, st, pool=4, out=wide, coff=384)
+    assert torch.equal(wide[..., 384:], dense) and (wide[..., :384] == 7).all()
+
+
+@pytest.mark.parametrize("C,Fq,pool,coff", [(64, 80, 40, 0), (128, 40, 20, 64), (192, 20, 10, 192)])
+def test_maxpool_taps(hip_device, C, Fq, pool, coff):
+    B, T = 2, 5
+    x = rnd(B, C, T, Fq, seed=1).double().requires_grad_(True)
+    y = F.max_pool2d(x, (1, pool))
+    dy = rnd(*y.shape, seed=2).double()
+    y.backward(dy)
+    xd = nhwc(x.detach().float()).to(hip_device)
+    wide = torch.zeros(B, T, 2, 640, device=hip_device)
+    ops.maxpool_fwd(xd, pool, out=wide, coff=coff)
+    assert torch.equal(nchw(wide[..., coff:coff + C].contiguous()).cpu(), y.detach().float())
+    dwide = torch.zeros(B, T, 2, 640, device=hip_device)
+    dwide[..., coff:coff + C] = nhwc(dy.float()).to(hip_device)
+    base = rnd(B, T, Fq, C, seed=3).to(hip_device)
+    dx = base.clone()
+    ops.maxpool_bwd_add(xd, dwide, dx, pool, coff=coff)
+    close(nchw(dx - base), x.grad, 1e-6)
+
+
+def test_dropout_mask_export_replay_and_rate(hip_device):
+    x = rnd(4096, 512, seed=1).to(hip_device)
+    y, mask = ops.dropout(x, 0.5, seed=123, offset=0)
+    keep = mask.float().mean().item()
+    assert abs(keep - 0.5) < 0.01
+    assert torch.equal(y, x * mask.float() * 2.0)
+    y2, _ = ops.dropout(x, 0.5, mask_in=mask)
+    assert torch.equal(y, y2)
+    y3, mask3 = ops.dropout(x, 0.5, seed=123, offset=0)
+    assert torch.equal(mask, mask3)                            # counter-based: same (seed, offset) -> same mask
+    _, mask4 = ops.dropout(x, 0.5, seed=123, offset=x.numel() // 4)
+    assert not torch.equal(mask, mask4)
+    y5, m5 = ops.dropout(x, 0.1, seed=5)
+    assert abs(m5.float().mean().item() - 0.9) < 0.01
+    torch.testing.assert_close(y5, x * m5.float() / 0.9)
+    wide = torch.zeros(4096, 640, device=hip_device)
+    ops.dropout(x[:, :256].contiguous(), 0.5, out2d=wide[:, 384:640], mask_in=mask[:, :256].contiguous())
+    assert torch.equal(wide[:, 384:640], x[:, :256] * mask[:, :256].float() * 2.0)
+
+
+def test_seq_relayout(hip_device):
+    B, T, C = 2, 7, 256
+    x = rnd(B, C, T, 2, seed=1)                               # NCHW (B,256,T,2)
+    ref = x.permute(0, 2, 1, 3).contiguous().view(B, T, 2 * C)   # model.py:93
+    wide = torch.zeros(B, T, 2, 640)
+    wide[..., 384:] = nhwc(x)
+    seq = ops.nhwc_to_seq(wide.to(hip_device), C, coff=384)
+    assert torch.equal(seq.cpu(), ref)
+    back = torch.zeros(B, T, 2, 640, device=hip_device)
+    ops.seq_to_nhwc(seq, back, C, coff=384)
+    assert torch.equal(back.cpu(), wide)
+    ops.seq_to_nhwc(seq, back, C, coff=384, accumulate=True)
+    assert torch.equal(back.cpu(), 2 * wide)
+
+
+# ------------------------------------------------------------------ LSTM
+@pytest.mark.parametrize("B,T,In,H", [(5, 7, 96, 64), (70, 4, 64, 32), (3, 11, 128, 96)])
+def test_lstm_layer_bidirectional(hip_device, B, T, In, H):
+    torch.manual_seed(0)
+    ref = torch.nn.LSTM(In, H, num_layers=1, batch_first=True, bidirectional=True).double()
+    x = rnd(B, T, In, seed=1).double().requires_grad_(True)
+    y, _ = ref(x)
+    dy = rnd(B, T, 2 * H, seed=2).double()
+    y.backward(dy)
+
+    dev = hip_device
+    xd = x.detach().float().to(dev)
+    P = {n: p.detach().float().to(dev) for n, p in ref.named_parameters()}
+    yd = torch.empty(B, T, 2 * H, device=dev)
+    gates, cbuf, whh, ysl = [], [], [], []
+    for d, sfx in enumerate(("", "_reverse")):
+        g = ops.gemm_nt(xd.view(-1, In), P["weight_ih_l0" + sfx], bias0=P["bias_ih_l0" + sfx],
+                        bias1=P["bias_hh_l0" + sfx]).view(B, T, 4 * H)
+        gates.append(g); cbuf.append(torch.empty(B, T, H, device=dev)); whh.append(P["weight_hh_l0" + sfx])
+        ysl.append(yd[:, :, d * H:(d + 1) * H])
+    ops.lstm_fwd(whh, gates, ysl, cbuf, [0, 1], B, T, H)
+    close(yd, y, 2e-5)
+
+    dyd = dy.float().to(dev)
+    whh_t = [ops.transpose2d(w) for w in whh]
+    dsl = [dyd[:, :, d * H:(d + 1) * H] for d in range(2)]
+    dcar = [torch.empty(B, H, device=dev) for _ in range(2)]
+    ops.lstm_bwd(whh_t, gates, cbuf, dsl, dcar, [0, 1], B, T, H)
+    dx = torch.empty(B, T, In, device=dev)
+    for d, sfx in enumerate(("", "_reverse")):
+        dg = gates[d].view(-1, 4 * H)
+        dwih = ops.gemm_tn(dg, xd.view(-1, In))
+        close(dwih, dict(ref.named_parameters())["weight_ih_l0" + sfx].grad, 5e-5)
+        dwhh = torch.empty(4 * H, H, device=dev)
+        ops.lstm_whh_grad(gates[d], ysl[d], dwhh, d, B, T, H)
+        close(dwhh, dict(ref.named_parameters())["weight_hh_l0" + sfx].grad, 5e-5)
+        db0, db1 = torch.empty(4 * H, device=dev), torch.empty(4 * H, device=dev)
+        ops.colsum(dg, db0, db1)
+        close(db0, dict(ref.named_parameters())["bias_ih_l0" + sfx].grad, 5e-5)
+        assert torch.equal(db0, db1)
+        ops.gemm_nt(dg, ops.transpose2d(P["weight_ih_l0" + sfx]), out=dx.view(-1, In), accumulate=(d > 0))
+    close(dx, x.grad, 5e-5)
+
+
+# ------------------------------------------------------------------ heads / loss / AdamW
+def test_heads(hip_device):
+    R, D = 777, 768
+    x = rnd(R, D, seed=1).double().requires_grad_(True)
+    for n_out in (1, 2):
+        w = rnd(n_out, D, seed=2, scale=0.05).double().requires_grad_(True)
+        b = rnd(n_out, seed=3).double().requires_grad_(True)
+        x.grad = None
+        y = (x @ w.T + b).sum(-1)
+        dy = rnd(R, seed=4).double()
+        y.backward(dy)
+        xd, wd, bd = (t.detach().float().to(hip_device) for t in (x, w, b))
+        close(ops.head_fwd(xd, wd, bd), y)
+        dw, db = torch.empty(n_out, D, device=hip_device), torch.empty(n_out, device=hip_device)
+        dx = ops.head_bwd(xd, wd, dy.float().to(hip_device), dw, db)
+        close(dx, x.grad)
+        close(dw, w.grad, 2e-5)
+        close(db, b.grad, 2e-5)
+
+
+def test_loss_matches_torch_criteria(hip_device):
+    R = 4 * 192
+    f0p = (rnd(R, seed=1) * 150 + 100).double().requires_grad_(True)
+    f0 = torch.where(rnd(R, seed=2) > -0.5, rnd(R, seed=3).abs() * 200 + 80, torch.zeros(R)).double()
+    f0[:5] = f0p.detach()[:5] + torch.tensor([0.3, -0.7, 0.999, -1.0, 1.0001], dtype=torch.double)  # both branches
+    silp = (rnd(R, seed=4) * 3).double().requires_grad_(True)
+    sil = (f0 == 0).double()
+    l1 = torch.nn.SmoothL1Loss()(f0p, f0)
+    bce = torch.nn.BCEWithLogitsLoss()(silp, sil)
+    loss = 0.1 * l1 + bce
+    loss.backward()
+    out3, d_f0, d_sil = ops.f0_sil_loss(f0p.detach().float().to(hip_device), f0.float().to(hip_device),
+                                        silp.detach().float().to(hip_device), sil.float().to(hip_device), 0.1)
+    np.testing.assert_allclose(out3.cpu().numpy(), [loss.item(), 0.1 * l1.item(), bce.item()], rtol=2e-6)
+    close(d_f0, f0p.grad, 1e-5)
+    close(d_sil, silp.grad, 1e-5)
+
+
+def test_adamw_matches_torch(hip_device):
+    n = 1003
+    p0, grads = rnd(n, seed=1), [rnd(n, seed=10 + i) for i in range(6)]
+    ref_p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref_p], lr=1e-4, weight_decay=5e-4, betas=(0.9, 0.98), eps=1e-9)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=3e-4, epochs=10, steps_per_epoch=5, pct_start=0.0,
+                                                final_div_factor=5)
+    p = p0.clone().to(hip_device)
+    m, v = torch.zeros(n, device=hip_device), torch.zeros(n, device=hip_device)
+    for i, g in enumerate(grads):
+        lr, beta1 = opt.param_groups[0]["lr"], opt.param_groups[0]["betas"][0]
+        ref_p.grad = g.clone()
+        opt.step()
+        sched.step()
+        ops.adamw_step(p, g.to(hip_device), m, v, lr, beta1, 0.98, 1e-9, 5e-4, i + 1)
+        torch.testing.assert_close(p.cpu(), ref_p.detach(), rtol=2e-6, atol=2e-8)
+        torch.testing.assert_close(m.cpu(), opt.state[ref_p]["exp_avg"], rtol=2e-6, atol=2e-8)
+        torch.testing.assert_close(v.cpu(), opt.state[ref_p]["exp_avg_sq"], rtol=2e-6, atol=1e-10)
