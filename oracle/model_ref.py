@@ -82,6 +82,22 @@ def lstm_layer_direction(x, w_ih, w_hh, b_ih, b_hh, reverse):
     return torch.stack(outs, dim=1)
 
 
+def bilstm_fused(x, state, prefix, num_layers, bidirectional):
+    """Same network through torch's stock fused LSTM op (what nn.LSTM dispatches to; oneDNN on CPU).
+    Used for the timed CPU baseline, where the explicit loop would understate the reference."""
+    flat = []
+    for layer in range(num_layers):
+        for d in range(2 if bidirectional else 1):
+            sfx = f"_l{layer}" + ("_reverse" if d else "")
+            flat += [state[f"{prefix}.weight_ih{sfx}"], state[f"{prefix}.weight_hh{sfx}"],
+                     state[f"{prefix}.bias_ih{sfx}"], state[f"{prefix}.bias_hh{sfx}"]]
+    H = flat[1].shape[1]
+    nd = 2 if bidirectional else 1
+    h0 = x.new_zeros(num_layers * nd, x.shape[0], H)
+    out, _, _ = torch._VF.lstm(x, (h0, h0.clone()), flat, True, num_layers, 0.0, False, bidirectional, True)
+    return out
+
+
 def bilstm(x, state, prefix, num_layers, bidirectional, p_drop, train, masks):
     for layer in range(num_layers):
         outs = []
@@ -97,7 +113,8 @@ def bilstm(x, state, prefix, num_layers, bidirectional, p_drop, train, masks):
 
 
 def jdcnet_forward(state: Dict[str, torch.Tensor], x: torch.Tensor, seq_cfg: dict, train: bool = False,
-                   masks=None, new_stats: Optional[dict] = None, taps: Optional[dict] = None):
+                   masks=None, new_stats: Optional[dict] = None, taps: Optional[dict] = None,
+                   fused_lstm: bool = False):
     """x (B,1,T,80) -> (classifier (B,T,num_class), detector (B,T)).
 
     ``masks``: iterator of keep-masks consumed in the order pool_block, detector_conv, then per
@@ -143,6 +160,9 @@ def jdcnet_forward(state: Dict[str, torch.Tensor], x: torch.Tensor, seq_cfg: dic
             if layer < num_layers - 1:
                 yc = _drop(yc, p_seq, train, masks)
                 yd = _drop(yd, p_seq, train, masks)
+    elif fused_lstm:
+        yc = bilstm_fused(seq_c, state, "sequence_classifier.model", num_layers, bidir)
+        yd = bilstm_fused(seq_d, state, "sequence_detector.model", num_layers, bidir)
     else:
         yc = bilstm(seq_c, state, "sequence_classifier.model", num_layers, bidir, 0.0, train, None)
         yd = bilstm(seq_d, state, "sequence_detector.model", num_layers, bidir, 0.0, train, None)

@@ -105,7 +105,8 @@ class CpuTrainer:
     """fp32 CPU restatement of ``Trainer.run`` (trainer.py:219-252), dropout disabled."""
 
     def __init__(self, state: Dict[str, torch.Tensor], seq_cfg: dict, max_lr=3e-4, total_steps=800,
-                 lambda_f0=0.1):
+                 lambda_f0=0.1, fused_lstm=False):
+        self.fused_lstm = fused_lstm
         self.state = {k: v.clone() for k, v in state.items()}
         self.names = [k for k, v in self.state.items() if v.dtype.is_floating_point and
                       not k.endswith(("running_mean", "running_var"))]
@@ -120,7 +121,7 @@ class CpuTrainer:
         live.update(params)
         new_stats = {}
         cls, det = model_ref.jdcnet_forward(live, x.transpose(-1, -2), self.seq_cfg, train=True,
-                                            new_stats=new_stats)
+                                            new_stats=new_stats, fused_lstm=self.fused_lstm)
         loss, lf0, lsil = model_ref.jdc_loss(cls, det, f0, sil, self.lam)
         loss.backward()
         lr, beta1 = one_cycle(self.k, self.total, self.max_lr)

@@ -1,0 +1,93 @@
+"""Data-parallel wiring: one process per GPU, gradients summed with RCCL over xGMI.
+
+The reference has no distributed code at all; the partition is the natural one for
+its workload: utterances are independent, weights are replicated, so each rank runs the whole
+step on its own minibatch shard and the only exchange is one sum-all-reduce of the flat gradient
+buffer per optimizer step (115.5 MB fp32), divided by the world size inside the fused AdamW
+kernel.  BatchNorm keeps per-replica statistics, exactly as N independent reference processes
+would (no SyncBN exists in the reference).
+
+The flat gradient buffer is reduced in a few large buckets on a dedicated HIP stream: ring
+all-reduce over point-to-point xGMI is per-link bound, so few large messages beat many small
+ones.  Buckets are issued in backward-completion order (sequence models first: 93 % of the
+bytes) as soon as JDCNet's backward signals them, and the optimizer waits on the last one.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str | None = None):
+    """torchrun-style rendezvous (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  Returns (rank, world, local)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(n_items: int, rank: int, world: int):
+    """Contiguous shard [lo, hi) of a global minibatch for this rank."""
+    per = n_items // world
+    return rank * per, (rank + 1) * per
+
+
+class GradientAllReduce:
+    """Sum-all-reduce of a flat gradient buffer, in buckets, on a side stream.
+
+    ``flat_grad`` is the model's flat gradient tensor (``JDCNet.flat_gradients()``);
+    ``optimizer.grad_scale`` is set to 1/world so the mean is taken inside the AdamW kernel.
+    """
+
+    def __init__(self, flat_grad: torch.Tensor, optimizer=None, group=None, bucket_bytes: int = 32 << 20,
+                 flat_param: torch.Tensor | None = None, buffers=()):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.flat_grad = flat_grad
+        n = flat_grad.numel()
+        per = max(1, bucket_bytes // 4)
+        self.buckets = [(lo, min(n, lo + per)) for lo in range(0, n, per)]
+        self._pending = []
+        self._stream = torch.cuda.Stream(device=flat_grad.device) if flat_grad.is_cuda else None
+        if optimizer is not None:
+            optimizer.grad_scale = 1.0 / self.world
+        if self.world > 1:
+            if flat_param is not None:
+                dist.broadcast(flat_param.data, src=0, group=group)     # identical replicas at step 0
+            for b in buffers:
+                dist.broadcast(b, src=0, group=group)
+
+    def reduce_range(self, lo: int, hi: int):
+        """Start reducing gradient elements [lo, hi) (they must be final)."""
+        if self.world == 1:
+            return
+        chunk = self.flat_grad[lo:hi]
+        if self._stream is not None:
+            self._stream.wait_stream(torch.cuda.current_stream(self.flat_grad.device))
+            with torch.cuda.stream(self._stream):
+                self._pending.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self._pending.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """Reduce whatever has not been issued yet and make the compute stream wait for all of it."""
+        if self.world == 1:
+            return
+        if not self._pending:
+            for lo, hi in self.buckets:
+                self.reduce_range(lo, hi)
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+        if self._stream is not None:
+            torch.cuda.current_stream(self.flat_grad.device).wait_stream(self._stream)

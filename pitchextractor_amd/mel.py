@@ -86,13 +86,15 @@ class MelSpectrogram:
             raise TypeError("wave must be float32")
         if waves.stride(-1) != 1:
             waves = waves.contiguous()
-        lib = _lib.load()
+        from . import ops
         plan = self._get_plan(waves.device)
+        n_valid = min(self.num_frames(waves.shape[1]), out_frames)
         with torch.cuda.device(waves.device):
-            _lib.check(lib.pe_mel_forward(plan, waves.data_ptr(), waves.shape[0], waves.shape[1],
-                                          waves.stride(0), out.data_ptr(), *strides, out_frames,
-                                          log_mode, LOG_EPS, MEL_MEAN, MEL_STD, pad_value,
-                                          _lib.stream_ptr()), "pe_mel_forward")
+            # algorithmic bytes: 300 new samples read + n_mels floats written per frame
+            ops._call("pe_mel_forward", plan, waves.data_ptr(), waves.shape[0], waves.shape[1],
+                      waves.stride(0), out.data_ptr(), *strides, out_frames, log_mode, LOG_EPS, MEL_MEAN,
+                      MEL_STD, pad_value, _lib.stream_ptr(),
+                      work=float(waves.shape[0] * n_valid * 4 * (self.hop_length + self.n_mels)))
         return out
 
     def __call__(self, wave: torch.Tensor) -> torch.Tensor:

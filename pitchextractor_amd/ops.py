@@ -53,9 +53,38 @@ def workspace(nbytes: int, device) -> torch.Tensor:
     return buf
 
 
-def _call(name, *args):
+class KernelTimer:
+    """Optional HIP-event timing of every C-ABI call (bench.py): events are recorded on the stream
+    the kernels are launched on and read back after the timed region, so nothing synchronises."""
+
+    def __init__(self):
+        self.records = {}
+
+    def add(self, name, start, end, work):
+        self.records.setdefault(name, []).append((start, end, work))
+
+    def summary(self):
+        out = {}
+        for name, recs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b, _ in recs]
+            out[name] = dict(calls=len(recs), total_ms=float(sum(ms)), avg_ms=float(sum(ms) / len(ms)),
+                             work=float(sum(w for _, _, w in recs)))
+        return out
+
+
+TIMER: KernelTimer | None = None
+
+
+def _call(name, *args, work=0.0):
     lib = _lib.load()
+    if TIMER is None:
+        _lib.check(getattr(lib, name)(*args), name)
+        return
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
     _lib.check(getattr(lib, name)(*args), name)
+    b.record()
+    TIMER.add(name, a, b, work)
 
 
 def _s():
@@ -77,7 +106,7 @@ def gemm_nt(A, B, bias0=None, bias1=None, out=None, accumulate=False):
         if b is not None:
             _chk(_dense(b, "bias").numel() == N, "bias size")
     _call("pe_gemm_nt", A.data_ptr(), lda, B.data_ptr(), ldb, out.data_ptr(), ldc, M, N, K,
-          _lib.ptr(bias0), _lib.ptr(bias1), int(bool(accumulate)), _s())
+          _lib.ptr(bias0), _lib.ptr(bias1), int(bool(accumulate)), _s(), work=2.0 * M * N * K)
     return out
 
 
@@ -95,7 +124,7 @@ def gemm_tn(A, B, out=None, accumulate=False):
     need = lib.pe_gemm_tn_workspace_bytes(M, N, K)
     ws = workspace(need, A.device)
     _call("pe_gemm_tn", A.data_ptr(), lda, B.data_ptr(), ldb, out.data_ptr(), ldc, M, N, K,
-          int(bool(accumulate)), ws.data_ptr(), ws.numel(), _s())
+          int(bool(accumulate)), ws.data_ptr(), ws.numel(), _s(), work=2.0 * M * N * K)
     return out
 
 
@@ -134,7 +163,7 @@ def conv3x3_fwd(x, w_packed, out=None, accumulate=False):
         out = torch.empty((B, T, F, N), dtype=torch.float32, device=x.device)
     _chk(_dense(out, "out").shape == (B, T, F, N), "conv3x3_fwd: out shape")
     _call("pe_conv3x3_fwd", x.data_ptr(), w_packed.data_ptr(), out.data_ptr(), B, T, F, Cc, N,
-          int(bool(accumulate)), _s())
+          int(bool(accumulate)), _s(), work=2.0 * B * T * F * N * 9 * Cc)
     return out
 
 
@@ -150,7 +179,7 @@ def conv3x3_wgrad(x, dy, dw):
     lib = _lib.load()
     ws = workspace(lib.pe_conv3x3_wgrad_workspace_bytes(B, T, F, Ci, Co), x.device)
     _call("pe_conv3x3_wgrad", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, T, F, Ci, Co,
-          ws.data_ptr(), ws.numel(), _s())
+          ws.data_ptr(), ws.numel(), _s(), work=2.0 * B * T * F * Co * 9 * Ci)
     return dw
 
 
@@ -352,7 +381,7 @@ def lstm_fwd(whh, gates, y_slices, cbuf, reverse, B, T, H):
         _chk(ldy in (None, ys.stride(1)), "all y slices share ldy")
         ldy = ys.stride(1)
     _call("pe_lstm_fwd", n, _ptr_array(whh), _ptr_array(gates), _ptr_array(y_slices), _ptr_array(cbuf),
-          _int_array(reverse), ldy, B, T, H, _s())
+          _int_array(reverse), ldy, B, T, H, _s(), work=2.0 * n * B * (T - 1) * 4 * H * H)
 
 
 def lstm_bwd(whh_t, gates, cbuf, dy_slices, dcarry, reverse, B, T, H):
@@ -370,7 +399,7 @@ def lstm_bwd(whh_t, gates, cbuf, dy_slices, dcarry, reverse, B, T, H):
         _chk(ld in (None, d.stride(1)), "all dy slices share ld")
         ld = d.stride(1)
     _call("pe_lstm_bwd", n, _ptr_array(whh_t), _ptr_array(gates), _ptr_array(cbuf), _ptr_array(dy_slices),
-          _ptr_array(dcarry), _int_array(reverse), ld, B, T, H, _s())
+          _ptr_array(dcarry), _int_array(reverse), ld, B, T, H, _s(), work=2.0 * n * B * (T - 1) * 4 * H * H)
 
 
 def lstm_whh_grad(dgates, y_slice, dwhh, reverse, B, T, H):
@@ -381,7 +410,7 @@ def lstm_whh_grad(dgates, y_slice, dwhh, reverse, B, T, H):
     lib = _lib.load()
     ws = workspace(lib.pe_lstm_whh_grad_workspace_bytes(B, T, H), dgates.device)
     _call("pe_lstm_whh_grad", dgates.data_ptr(), ys.data_ptr(), ys.stride(1), dwhh.data_ptr(), B, T, H,
-          int(bool(reverse)), ws.data_ptr(), ws.numel(), _s())
+          int(bool(reverse)), ws.data_ptr(), ws.numel(), _s(), work=2.0 * B * T * 4 * H * H)
     return dwhh
 
 

@@ -148,3 +148,15 @@ def test_collate_contract():
     assert mels.shape == (3, 1, 80, 192) and f0s.shape == (3, 192) and sils.shape == (3, 192)
     assert (mels[0, 0, :, 161:] == 0).all() and (mels[2, 0, :, 100:] == 0).all() and (mels[1] == 2).all()
     assert (f0s[2, 100:] == 0).all() and (sils == 0).all()      # padded frames: f0 = 0, is_silence = 0
+
+
+def test_fused_lstm_baseline_path_equals_explicit_loop():
+    """bench.py's cpu_baseline uses torch's stock fused LSTM op; it must be the same function."""
+    state = model_ref.seeded_state(4, hidden_size=32, num_layers=2)
+    x = golden_input(8, B=1, T=24)
+    cfg = dict(SEQ_CFG, hidden_size=32, num_layers=2)
+    with torch.no_grad():
+        a = model_ref.jdcnet_forward(state, x, cfg)
+        b = model_ref.jdcnet_forward(state, x, cfg, fused_lstm=True)
+    for u, v in zip(a, b):
+        np.testing.assert_allclose(u.numpy(), v.numpy(), rtol=1e-4, atol=1e-5)
