@@ -35,12 +35,29 @@ MFMA_F32_PEAK_TFLOPS = 157.3                    # MI355X_MICROARCH.md: exact-f32
 HBM_PEAK_GBPS = 8000.0
 
 
+def host_cores():
+    """CPU cores this process may actually use (affinity mask and cgroup quota, not the host total)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 32))
+
+
 def cpu_baseline(n_steps=3, batch=4):
     """Reference-equivalent fp32 CPU trainer (oracle port) on a bounded sample, host cores stated."""
     from oracle import mel_ref, model_ref, train_ref
     from pitchextractor_amd import synthetic
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
+    print(f"[bench] cpu_baseline on {cores} threads ...", file=sys.stderr, flush=True)
     state = model_ref.seeded_state(21)
     cfg = dict(SEQ_CFG, dropout=0.0)
     tr = train_ref.CpuTrainer(state, cfg, fused_lstm=True)   # stock fused LSTM op, as nn.LSTM uses
@@ -52,7 +69,11 @@ def cpu_baseline(n_steps=3, batch=4):
         mels[i, 0, :, :lm.shape[1]] = lm
     t_mel = time.perf_counter() - t_mel0
     b = (torch.from_numpy(mels), torch.from_numpy(f0), torch.from_numpy(sil))
+    t0 = time.perf_counter()
     tr.run(b)                                   # warm-up
+    warm = time.perf_counter() - t0
+    if warm > 10.0:                             # keep the whole baseline within ~30 s of CPU work
+        n_steps = 1
     times = []
     for _ in range(n_steps):
         t0 = time.perf_counter()
@@ -118,8 +139,12 @@ def main():
         torch.cuda.synchronize(dev)
 
     last = None
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
+        t_w = time.perf_counter()
         last = tr.run(batch)
+        if rank == 0:
+            print(f"[bench] warmup {i}: {time.perf_counter() - t_w:.3f} s loss {last['loss']:.4f}", file=sys.stderr,
+                  flush=True)
     barrier()
     ops.TIMER = ops.KernelTimer()
     t0 = time.perf_counter()
@@ -128,6 +153,9 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     timer, ops.TIMER = ops.TIMER, None
+    if rank == 0:
+        print(f"[bench] timed {args.steps} steps: {elapsed / args.steps * 1e3:.1f} ms/step", file=sys.stderr,
+              flush=True)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
