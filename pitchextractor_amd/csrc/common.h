@@ -25,3 +25,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define PE_WAVE 64
+
+// Sum `n` strided doubles with one wave: lane l takes elements l, l+64, ...; result valid in lane 0.
+__device__ __forceinline__ double pe_wave_strided_sum(const double* base, long stride, int n) {
+  const int lane = threadIdx.x & 63;
+  double s = 0.0;
+  for (int z = lane; z < n; z += 64) s += base[(long)z * stride];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  return s;
+}

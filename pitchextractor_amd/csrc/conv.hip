@@ -91,9 +91,10 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restr
   const int kb = blockIdx.y * k_per_split;
   const int ke = min(P, kb + k_per_split);
   KRowLoader<BM> al{dy, (long)Cout, Cout, 0};
-  ShiftedPixelLoader<BN> bl{x, T, F, Cin, tap / 3 - 1, tap % 3 - 1, 0};
-  al.init(m0);
-  bl.init(n0);
+  ShiftedPixelLoader<BN> bl;
+  bl.p = x; bl.T = T; bl.F = F; bl.C = Cin; bl.dt = tap / 3 - 1; bl.df = tap % 3 - 1;
+  al.init(m0, kb);
+  bl.init(n0, kb);
   f32x16 acc[BM / 64][BN / 64];
 #pragma unroll
   for (int i = 0; i < BM / 64; ++i)
@@ -216,11 +217,14 @@ __global__ __launch_bounds__(256) void conv3x3_c1_wgrad_kernel(const float* __re
 }
 
 __global__ void c1_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int nblocks) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);            // one wave per output element
   if (i >= 576) return;
+  const int lane = threadIdx.x & 63;
   double s = 0.0;
-  for (int z = 0; z < nblocks; ++z) s += (double)partial[(long)z * 576 + i];
-  dw[i] = (float)s;
+  for (int z = lane; z < nblocks; z += 64) s += (double)partial[(long)z * 576 + i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) dw[i] = (float)s;
 }
 
 constexpr int kC1WgradBlocks = 2048;
@@ -294,7 +298,7 @@ extern "C" int pe_conv3x3_c1_wgrad(const float* x, long sb, long st, long sf, co
   hipLaunchKernelGGL(conv3x3_c1_wgrad_kernel, dim3(kC1WgradBlocks), dim3(256), 0, pe_stream(stream), x, sb, st, sf,
                      dy, workspace, B, T, F);
   PE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(c1_wgrad_reduce_kernel, dim3(3), dim3(256), 0, pe_stream(stream), workspace, dw_oihw,
+  hipLaunchKernelGGL(c1_wgrad_reduce_kernel, dim3(144), dim3(256), 0, pe_stream(stream), workspace, dw_oihw,
                      kC1WgradBlocks);
   PE_LAUNCH_CHECK();
   return PE_OK;

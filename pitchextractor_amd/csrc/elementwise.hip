@@ -60,13 +60,12 @@ __global__ void bn_stats_finalize_kernel(const double* __restrict__ partial, int
                                          float* __restrict__ running_var, float* __restrict__ mean_out,
                                          float* __restrict__ invstd_out, float* __restrict__ scale,
                                          float* __restrict__ shift) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  // one wave per channel (4 channels per 256-thread block)
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= C) return;
-  double s1 = 0, s2 = 0;
-  for (int z = 0; z < nparts; ++z) {
-    s1 += partial[(long)z * 2 * C + c];
-    s2 += partial[(long)z * 2 * C + C + c];
-  }
+  const double s1 = pe_wave_strided_sum(partial + c, 2L * C, nparts);
+  const double s2 = pe_wave_strided_sum(partial + C + c, 2L * C, nparts);
+  if ((threadIdx.x & 63) != 0) return;
   const double n = (double)n_pix;
   const double mean = s1 / n;
   double var = s2 / n - mean * mean;
@@ -200,13 +199,11 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const BnBwdArgs a, 
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nparts, long n_pix, int C,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
                                        float* __restrict__ c1, float* __restrict__ c2) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= C) return;
-  double s1 = 0, s2 = 0;
-  for (int z = 0; z < nparts; ++z) {
-    s1 += partial[(long)z * 2 * C + c];
-    s2 += partial[(long)z * 2 * C + C + c];
-  }
+  const double s1 = pe_wave_strided_sum(partial + c, 2L * C, nparts);
+  const double s2 = pe_wave_strided_sum(partial + C + c, 2L * C, nparts);
+  if ((threadIdx.x & 63) != 0) return;
   dbeta[c] = (float)s1;
   dgamma[c] = (float)s2;
   c1[c] = (float)(s1 / (double)n_pix);
@@ -410,7 +407,7 @@ extern "C" int pe_bn_train_stats(const float* x, long n_pix, int C, const float*
   double* partial = reinterpret_cast<double*>(workspace);
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(grid), dim3(256), reduce_lds(C), st, x, n_pix, C, partial);
   PE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(pe_cdiv(C, 64)), dim3(64), 0, st, partial, grid, n_pix, C, gamma,
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(pe_cdiv(C, 4)), dim3(256), 0, st, partial, grid, n_pix, C, gamma,
                      beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
   PE_LAUNCH_CHECK();
   return PE_OK;
@@ -453,7 +450,7 @@ extern "C" int pe_bn_act_pool_bwd(const float* x, const float* dy, const float* 
   const int grid = reduce_grid(a.n_in_pix, C);
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(grid), dim3(256), reduce_lds(C), st, a, partial);
   PE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pe_cdiv(C, 64)), dim3(64), 0, st, partial, grid, a.n_in_pix, C,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pe_cdiv(C, 4)), dim3(256), 0, st, partial, grid, a.n_in_pix, C,
                      dgamma, dbeta, c1, c2);
   PE_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(a.n_in_pix * (C / 4))), dim3(256), 0, st, a, c1, c2, dx);

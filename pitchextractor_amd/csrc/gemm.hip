@@ -61,8 +61,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(KRowLoader<BM> al, KRowLoa
   const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
   const int kb = blockIdx.y * k_per_split;
   const int ke = min(K, kb + k_per_split);
-  al.init(m0);
-  bl.init(n0);
+  al.init(m0, kb);
+  bl.init(n0, kb);
   f32x16 acc[BM / 64][BN / 64];
 #pragma unroll
   for (int i = 0; i < BM / 64; ++i)

@@ -197,7 +197,7 @@ struct KRowLoader {           // plain [K][cols] matrix
   long ld;
   int cols;
   int col0;
-  __device__ __forceinline__ void init(int first_col) { col0 = first_col + TnGeom<COLS>::col4(); }
+  __device__ __forceinline__ void init(int first_col, int /*k_begin*/) { col0 = first_col + TnGeom<COLS>::col4(); }
   __device__ __forceinline__ float4 load(int slot, int k0, int k_end) const {
     const int k = k0 + TnGeom<COLS>::krow(slot);
     if (k < k_end && col0 < cols) return *reinterpret_cast<const float4*>(p + (long)k * ld + col0);
@@ -210,16 +210,29 @@ struct ShiftedPixelLoader {   // [B*T*F][C] channels-last tensor read at pixel +
   const float* p;
   int T, F, C, dt, df;
   int col0;
-  __device__ __forceinline__ void init(int first_col) { col0 = first_col + TnGeom<COLS>::col4(); }
-  __device__ __forceinline__ float4 load(int slot, int k0, int k_end) const {
-    const int k = k0 + TnGeom<COLS>::krow(slot);
-    if (k < k_end && col0 < C) {
-      const int f = k % F, t = (k / F) % T;
-      const int tt = t + dt, ff = f + df;
-      if (tt >= 0 && tt < T && ff >= 0 && ff < F)
-        return *reinterpret_cast<const float4*>(p + ((long)k + dt * F + df) * C + col0);
+  // (t, f) of each slot's current pixel row, advanced by 32 pixels per k-tile: no div/mod in the loop
+  int t_[TnGeom<COLS>::SLOTS], f_[TnGeom<COLS>::SLOTS];
+  __device__ __forceinline__ void init(int first_col, int k_begin) {
+    col0 = first_col + TnGeom<COLS>::col4();
+#pragma unroll
+    for (int i = 0; i < TnGeom<COLS>::SLOTS; ++i) {
+      const int k = k_begin + TnGeom<COLS>::krow(i);
+      f_[i] = k % F;
+      t_[i] = (k / F) % T;
     }
-    return make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // must be called once per slot per k-tile, k-tiles in increasing order starting at k_begin
+  __device__ __forceinline__ float4 load(int slot, int k0, int k_end) {
+    const int k = k0 + TnGeom<COLS>::krow(slot);
+    const int tt = t_[slot] + dt, ff = f_[slot] + df;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < k_end && col0 < C && tt >= 0 && tt < T && ff >= 0 && ff < F)
+      v = *reinterpret_cast<const float4*>(p + ((long)k + dt * F + df) * C + col0);
+    int f = f_[slot] + kBK, t = t_[slot];
+    while (f >= F) { f -= F; ++t; }
+    while (t >= T) t -= T;
+    f_[slot] = f; t_[slot] = t;
+    return v;
   }
 };
 
@@ -229,14 +242,22 @@ struct ShiftedTimeLoader {    // [B][T][ld] sequence read at time t + dt (zero o
   long ld;
   int T, dt, cols;
   int col0;
-  __device__ __forceinline__ void init(int first_col) { col0 = first_col + TnGeom<COLS>::col4(); }
-  __device__ __forceinline__ float4 load(int slot, int k0, int k_end) const {
+  int t_[TnGeom<COLS>::SLOTS];
+  __device__ __forceinline__ void init(int first_col, int k_begin) {
+    col0 = first_col + TnGeom<COLS>::col4();
+#pragma unroll
+    for (int i = 0; i < TnGeom<COLS>::SLOTS; ++i) t_[i] = (k_begin + TnGeom<COLS>::krow(i)) % T;
+  }
+  __device__ __forceinline__ float4 load(int slot, int k0, int k_end) {
     const int k = k0 + TnGeom<COLS>::krow(slot);
-    if (k < k_end && col0 < cols) {
-      const int t = k % T + dt;
-      if (t >= 0 && t < T) return *reinterpret_cast<const float4*>(p + ((long)k + dt) * ld + col0);
-    }
-    return make_float4(0.f, 0.f, 0.f, 0.f);
+    const int t = t_[slot] + dt;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < k_end && col0 < cols && t >= 0 && t < T)
+      v = *reinterpret_cast<const float4*>(p + ((long)k + dt) * ld + col0);
+    int tn = t_[slot] + kBK;
+    while (tn >= T) tn -= T;
+    t_[slot] = tn;
+    return v;
   }
 };
 

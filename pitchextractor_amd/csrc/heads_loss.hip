@@ -74,10 +74,10 @@ __global__ __launch_bounds__(256) void head_bwd_dw_partial_kernel(const float* _
 
 __global__ void head_bwd_dw_final_kernel(const double* __restrict__ partial, int nparts, int D, int n_out,
                                          float* __restrict__ dw, float* __restrict__ db) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);            // one wave per column
   if (c > D) return;
-  double s = 0;
-  for (int z = 0; z < nparts; ++z) s += partial[(long)z * (D + 1) + c];
+  const double s = pe_wave_strided_sum(partial + c, (long)(D + 1), nparts);
+  if ((threadIdx.x & 63) != 0) return;
   for (int o = 0; o < n_out; ++o) {
     if (c < D) dw[(long)o * D + c] = (float)s;
     else db[o] = (float)s;
@@ -194,7 +194,7 @@ extern "C" int pe_head_bwd(const float* x, long ldx, const float* w, const float
   hipLaunchKernelGGL(head_bwd_dw_partial_kernel, dim3(pe_cdiv(D + 1, 256), parts), dim3(256), 0, st, x, ldx, dy, R, D,
                      partial);
   PE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(head_bwd_dw_final_kernel, dim3(pe_cdiv(D + 1, 256)), dim3(256), 0, st, partial, parts, D, n_out,
+  hipLaunchKernelGGL(head_bwd_dw_final_kernel, dim3(pe_cdiv(D + 1, 4)), dim3(256), 0, st, partial, parts, D, n_out,
                      dw, db);
   PE_LAUNCH_CHECK();
   return PE_OK;

@@ -202,8 +202,8 @@ __global__ __launch_bounds__(256) void lstm_whh_grad_kernel(KRowLoader<BM> al, S
   const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
   const int kb = blockIdx.y * k_per_split;
   const int ke = min(K, kb + k_per_split);
-  al.init(m0);
-  bl.init(n0);
+  al.init(m0, kb);
+  bl.init(n0, kb);
   f32x16 acc[BM / 64][BN / 64];
 #pragma unroll
   for (int i = 0; i < BM / 64; ++i)
@@ -254,10 +254,10 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 
 __global__ void colsum_final_kernel(const double* __restrict__ partial, int nparts, int cols, float* out0,
                                     float* out1) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);            // one wave per column
   if (c >= cols) return;
-  double s = 0;
-  for (int z = 0; z < nparts; ++z) s += partial[(long)z * cols + c];
+  const double s = pe_wave_strided_sum(partial + c, (long)cols, nparts);
+  if ((threadIdx.x & 63) != 0) return;
   out0[c] = (float)s;
   if (out1) out1[c] = (float)s;
 }
@@ -324,7 +324,8 @@ extern "C" int pe_lstm_whh_grad(const float* dgates, const float* y, long ldy, f
   const size_t need = (size_t)splits * M * N * sizeof(float);
   if (!workspace || workspace_bytes < need) return PE_E_WORKSPACE;
   KRowLoader<128> al{dgates, (long)M, M, 0};
-  ShiftedTimeLoader<128> bl{y, ldy, T, reverse ? 1 : -1, N, 0};
+  ShiftedTimeLoader<128> bl;
+  bl.p = y; bl.ld = ldy; bl.T = T; bl.dt = reverse ? 1 : -1; bl.cols = N; bl.col0 = 0;
   const int tm = pe_cdiv(M, 128), tn = pe_cdiv(N, 128);
   hipStream_t st = pe_stream(stream);
   hipLaunchKernelGGL((lstm_whh_grad_kernel<128, 128>), dim3(tm * tn, splits), dim3(256), 0, st, al, bl, workspace,
@@ -349,7 +350,7 @@ extern "C" int pe_colsum(const float* x, long rows, int cols, long ld, float* ou
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(pe_cdiv(cols, 256), parts), dim3(256), 0, st, x, rows, cols, ld,
                      partial);
   PE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(pe_cdiv(cols, 256)), dim3(256), 0, st, partial, parts, cols, out0,
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(pe_cdiv(cols, 4)), dim3(256), 0, st, partial, parts, cols, out0,
                      out1);
   PE_LAUNCH_CHECK();
   return PE_OK;
