@@ -61,6 +61,14 @@ int pe_mel_forward(const pe_mel_plan* plan, const float* wave, int batch, int n_
                    long wave_stride, float* out, long out_sb, long out_sm, long out_st,
                    int out_frames, int log_mode, float log_eps, float mean, float std,
                    float pad_value, void* stream);
+/* Ragged batch: utterance b has n_samples[b] <= max_samples samples (device int array) and, when
+ * frame_start != NULL, output frame t shows source frame t + frame_start[b] -- the random crop of
+ * meldataset.py:668-672 applied on the frame axis without recomputing anything.  Items with
+ * n_samples[b] <= n_fft/2 produce padding only. */
+int pe_mel_forward_ragged(const pe_mel_plan* plan, const float* wave, int batch, int max_samples,
+                          long wave_stride, const int* n_samples, const int* frame_start, float* out,
+                          long out_sb, long out_sm, long out_st, int out_frames, int log_mode,
+                          float log_eps, float mean, float std, float pad_value, void* stream);
 
 
 /* ---- dense fp32 GEMMs on the MFMA engine -----------------------------------

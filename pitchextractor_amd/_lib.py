@@ -38,6 +38,7 @@ PROTOTYPES = {
     "pe_mel_plan_destroy": (_i, [_p]),
     "pe_mel_num_frames": (_i, [_p, _i]),
     "pe_mel_forward": (_i, [_p, _p, _i, _i, _l, _p, _l, _l, _l, _i, _i, _f, _f, _f, _f, _p]),
+    "pe_mel_forward_ragged": (_i, [_p, _p, _i, _i, _l, _p, _p, _p, _l, _l, _l, _i, _i, _f, _f, _f, _f, _p]),
     "pe_gemm_nt": (_i, [_p, _l, _p, _l, _p, _l, _i, _i, _i, _p, _p, _i, _p]),
     "pe_gemm_tn_workspace_bytes": (_z, [_i, _i, _i]),
     "pe_gemm_tn": (_i, [_p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _p, _z, _p]),

@@ -45,6 +45,8 @@ struct MelArgs {
   const float* fb_w;           // [nnz]
   int nnz;
   int audio_len;               // (FB-1)*hop + 1024, padded to a multiple of 4
+  const int* n_samples_arr;    // optional [batch]: per-utterance length (ragged batches)
+  const int* frame_start;      // optional [batch]: output frame t shows source frame t + frame_start[b]
 };
 
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
@@ -87,14 +89,18 @@ __global__ __launch_bounds__(256) void mel_fwd_kernel(const MelArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int b = blockIdx.y;
-  const int f0 = blockIdx.x * FB;
   const int hop = a.hop, n_mels = a.n_mels;
+  const int n_samples = a.n_samples_arr ? a.n_samples_arr[b] : a.n_samples;
+  // reflect padding needs more than n_fft/2 samples; shorter items come out as padding only
+  const int n_valid = n_samples > kHalf ? 1 + n_samples / hop : 0;
+  const int f_out0 = blockIdx.x * FB;                       // first output frame of this block
+  const int f0 = f_out0 + (a.frame_start ? max(a.frame_start[b], 0) : 0);   // first source frame
 
-  if (f0 < a.n_valid) {
+  if (f0 < n_valid) {
     // ---- stage the audio chunk (reflect padding resolved here) and the filterbank
     const float* wsrc = a.wave + (long)b * a.wave_stride;
     const long base = (long)f0 * hop - kHalf;
-    const long N = a.n_samples;
+    const long N = n_samples;
     for (int j = tid; j < a.audio_len; j += 256) {
       long g = base + j;
       if (g < 0) g = -g;
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(256) void mel_fwd_kernel(const MelArgs a) {
 
     for (int it = 0; it < FB / 4; ++it) {
       const int fi = it * 4 + wv;
-      const bool valid = (f0 + fi) < a.n_valid;         // wave-uniform
+      const bool valid = (f0 + fi) < n_valid;           // wave-uniform
       float2 v[8];
       if (valid) {
         // pass 1: radix-8 over a, lane = m = 8b+c, x[n = 64a + m]
@@ -200,9 +206,9 @@ __global__ __launch_bounds__(256) void mel_fwd_kernel(const MelArgs a) {
   for (int idx = tid; idx < n_mels * FB; idx += 256) {
     const int m = mel_fastest ? idx % n_mels : idx / FB;
     const int fo = mel_fastest ? idx / n_mels : idx % FB;
-    const int frame = f0 + fo;
+    const int frame = f_out0 + fo;
     if (frame < a.out_frames) {
-      const float val = (frame < a.n_valid) ? s_out[m * (FB + 1) + fo] : a.pad_value;
+      const float val = (f0 + fo < n_valid) ? s_out[m * (FB + 1) + fo] : a.pad_value;
       dst[(long)m * a.out_sm + (long)frame * a.out_st] = val;
     }
   }
@@ -331,17 +337,18 @@ extern "C" int pe_mel_num_frames(const pe_mel_plan* plan, int n_samples) {
   return 1 + n_samples / plan->hop;
 }
 
-extern "C" int pe_mel_forward(const pe_mel_plan* plan, const float* wave, int batch, int n_samples,
-                              long wave_stride, float* out, long out_sb, long out_sm, long out_st,
-                              int out_frames, int log_mode, float log_eps, float mean, float std,
-                              float pad_value, void* stream) {
+static int mel_launch(const pe_mel_plan* plan, const float* wave, int batch, int n_samples, long wave_stride,
+                      const int* n_samples_arr, const int* frame_start, float* out, long out_sb, long out_sm,
+                      long out_st, int out_frames, int log_mode, float log_eps, float mean, float std,
+                      float pad_value, void* stream) {
   if (!plan || !wave || !out || batch < 0 || out_frames < 0) return PE_E_ARG;
   // reflect padding needs n_fft/2 < n_samples (torch.stft raises otherwise)
-  if (n_samples <= kHalf || wave_stride < n_samples || std == 0.0f) return PE_E_ARG;
+  if ((!n_samples_arr && n_samples <= kHalf) || wave_stride < n_samples || std == 0.0f) return PE_E_ARG;
   if (batch == 0 || out_frames == 0) return PE_OK;
   if (batch > 65535) return PE_E_UNSUPPORTED;
 
   MelArgs a;
+  a.n_samples_arr = n_samples_arr; a.frame_start = frame_start;
   a.wave = wave; a.wave_stride = wave_stride; a.n_samples = n_samples; a.hop = plan->hop;
   a.n_mels = plan->n_mels; a.n_valid = 1 + n_samples / plan->hop; a.out_frames = out_frames;
   a.out = out; a.out_sb = out_sb; a.out_sm = out_sm; a.out_st = out_st;
@@ -358,4 +365,21 @@ extern "C" int pe_mel_forward(const pe_mel_plan* plan, const float* wave, int ba
   hipLaunchKernelGGL(mel_fwd_kernel<kFB>, grid, dim3(256), lds, pe_stream(stream), a);
   PE_LAUNCH_CHECK();
   return PE_OK;
+}
+
+extern "C" int pe_mel_forward(const pe_mel_plan* plan, const float* wave, int batch, int n_samples,
+                              long wave_stride, float* out, long out_sb, long out_sm, long out_st,
+                              int out_frames, int log_mode, float log_eps, float mean, float std,
+                              float pad_value, void* stream) {
+  return mel_launch(plan, wave, batch, n_samples, wave_stride, nullptr, nullptr, out, out_sb, out_sm, out_st,
+                    out_frames, log_mode, log_eps, mean, std, pad_value, stream);
+}
+
+extern "C" int pe_mel_forward_ragged(const pe_mel_plan* plan, const float* wave, int batch, int max_samples,
+                                     long wave_stride, const int* n_samples, const int* frame_start, float* out,
+                                     long out_sb, long out_sm, long out_st, int out_frames, int log_mode,
+                                     float log_eps, float mean, float std, float pad_value, void* stream) {
+  if (!n_samples) return PE_E_ARG;
+  return mel_launch(plan, wave, batch, max_samples, wave_stride, n_samples, frame_start, out, out_sb, out_sm,
+                    out_st, out_frames, log_mode, log_eps, mean, std, pad_value, stream);
 }

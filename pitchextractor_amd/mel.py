@@ -123,3 +123,29 @@ class MelSpectrogram:
             out = torch.empty((B, 1, self.n_mels, max_frames), dtype=torch.float32, device=waves.device)
         self._run(waves, out, (out.stride(0), out.stride(2), out.stride(3)), max_frames, 1, 0.0)
         return out
+
+    def log_mel_ragged(self, waves: torch.Tensor, lengths: torch.Tensor, frame_start: torch.Tensor | None = None,
+                       max_frames: int = MAX_MEL_LENGTH, out: torch.Tensor | None = None) -> torch.Tensor:
+        """Ragged batch: ``waves`` (B, Nmax) zero-padded rows, ``lengths`` (B,) int32 sample counts,
+        ``frame_start`` (B,) int32 first frame kept per item (meldataset.py:668-672 random crop).
+        Returns (B, 1, n_mels, max_frames) normalised log-mel; frames past an item's end are 0."""
+        from . import ops
+        if not (waves.is_cuda and lengths.is_cuda and waves.dtype == torch.float32 and waves.dim() == 2):
+            raise RuntimeError("log_mel_ragged needs float32 (B, N) device audio and device lengths")
+        if lengths.dtype != torch.int32 or lengths.numel() != waves.shape[0] or not lengths.is_contiguous():
+            raise ValueError("lengths must be a contiguous int32 tensor of size B")
+        if frame_start is not None and (frame_start.dtype != torch.int32 or frame_start.numel() != waves.shape[0]
+                                        or not frame_start.is_cuda or not frame_start.is_contiguous()):
+            raise ValueError("frame_start must be a contiguous int32 device tensor of size B")
+        if waves.stride(1) != 1:
+            waves = waves.contiguous()
+        B = waves.shape[0]
+        if out is None:
+            out = torch.empty((B, 1, self.n_mels, max_frames), dtype=torch.float32, device=waves.device)
+        plan = self._get_plan(waves.device)
+        with torch.cuda.device(waves.device):
+            ops._call("pe_mel_forward_ragged", plan, waves.data_ptr(), B, waves.shape[1], waves.stride(0),
+                      lengths.data_ptr(), _lib.ptr(frame_start), out.data_ptr(), out.stride(0), out.stride(2),
+                      out.stride(3), max_frames, 1, LOG_EPS, MEL_MEAN, MEL_STD, 0.0, _lib.stream_ptr(),
+                      work=float(B * max_frames * 4 * (self.hop_length + self.n_mels)))
+        return out

@@ -1,0 +1,367 @@
+"""Data layer drop-in for the reference's ``meldataset.py`` with the mel transform on the GPU.
+
+Public surface kept: ``DEFAULT_MEL_PARAMS``, ``MelDataset`` (same constructor keywords,
+``to_melspec``, ``mean/std = -4/4``, ``max_mel_length = 192``, ``path|label`` list lines),
+``Collater`` and ``build_dataloader(path_list, validation, batch_size, num_workers, device,
+collate_config, dataset_config)`` yielding ``(mels (B,1,80,192), f0s (B,192), is_silences (B,192))``.
+
+What moved: in the reference every item runs the mel transform on the CPU inside a DataLoader
+worker (meldataset.py:644).  Here workers only read audio and labels; the batch's raw audio goes
+to HBM once and ONE launch of the fused mel kernel does framing + FFT + mel + log + the random
+192-frame crop (meldataset.py:668-672, applied as a per-item frame offset) + zero padding
+(meldataset.py:806-816).  All index arithmetic -- segment pre-crop (meldataset.py:178-201), F0
+alignment (f0_backends.py:788-806), crop offsets -- is reproduced exactly and runs on the host.
+
+Out of scope here: the F0 tracker backends and the WORLD / pitch-shift
+augmentation need packages that are not installable offline.  F0 labels therefore come from the
+reference's cache files (``<wav>_f0*.npy``; the legacy ``<wav>_f0.npy`` too) or from an
+``f0_provider`` callable; an item with neither fails loudly, as the reference does when no
+backend is usable (meldataset.py:80-88).  Resampling (meldataset.py:621-627) is not implemented:
+files must already be at the target rate.
+"""
+from __future__ import annotations
+
+import glob
+import logging
+import math
+import os
+import random
+import struct
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+
+from .mel import DEFAULT_MEL_PARAMS, MAX_MEL_LENGTH, MEL_MEAN, MEL_STD, LOG_EPS, MelSpectrogram
+
+logger = logging.getLogger(__name__)
+logger.setLevel(logging.DEBUG)
+
+np.random.seed(1)      # meldataset.py:31-32
+random.seed(1)
+
+
+# --------------------------------------------------------------------------- host-side arithmetic
+def align_length(values, target_frames: int) -> np.ndarray:
+    """``F0Extractor.align_length`` (f0_backends.py:788-806): float64 linear interpolation to
+    ``target_frames`` points, then zero each frame whose nearest (round-half-even) source frame is 0."""
+    values = np.asarray(values, dtype=np.float64)
+    if target_frames <= 0:
+        return np.zeros((0,), dtype=np.float32)
+    if values.size == target_frames:
+        return values.astype(np.float32)
+    if values.size == 0:
+        return np.zeros((target_frames,), dtype=np.float32)
+    last = values.size - 1
+    grid = np.linspace(0.0, last, num=target_frames)
+    out = np.interp(grid, np.linspace(0.0, last, num=values.size), values)
+    zeros = values == 0.0
+    if np.any(zeros):
+        out[zeros[np.clip(np.round(grid).astype(int), 0, last)]] = 0.0
+    return out.astype(np.float32)
+
+
+def segment_plan(total_frames: int, source_sr: int, target_sr: int, hop: int, win: int, target_frames: int,
+                 rng=random):
+    """Pre-crop of meldataset.py:178-201 -> (start_frame, num_frames or None, use_full_file)."""
+    if target_frames > 0 and source_sr and total_frames > 0:
+        requested = (target_frames * hop) / float(target_sr) + max(win, hop) / float(target_sr)
+        seg = int(np.ceil(requested * float(source_sr)))
+        if seg > 0 and seg < total_frames:
+            max_start = max(0, total_frames - seg)
+            start = rng.randint(0, max_start) if max_start > 0 else 0
+            return start, seg, False
+        if seg > 0:
+            return 0, seg, True
+    return 0, None, True
+
+
+def read_wav(path, start: int = 0, frames: int | None = None):
+    """Minimal RIFF/WAVE reader (PCM 8/16/24/32-bit and IEEE float32/64) -> (float32 [n, ch] or [n], sr).
+    Stands in for ``soundfile`` (absent from this image); uses it when importable."""
+    try:
+        import soundfile as sf  # pragma: no cover - optional
+        with sf.SoundFile(path, mode="r") as f:
+            if start:
+                f.seek(int(start))
+            data = f.read(frames=-1 if frames is None else int(frames), dtype="float32", always_2d=False)
+            return np.asarray(data, dtype=np.float32), f.samplerate
+    except ImportError:
+        pass
+    with open(path, "rb") as fh:
+        riff, _, wave_id = struct.unpack("<4sI4s", fh.read(12))
+        if riff != b"RIFF" or wave_id != b"WAVE":
+            raise RuntimeError(f"Failed to load audio file '{path}': not a RIFF/WAVE file")
+        fmt = None
+        while True:
+            head = fh.read(8)
+            if len(head) < 8:
+                raise RuntimeError(f"Failed to load audio file '{path}': no data chunk")
+            cid, size = struct.unpack("<4sI", head)
+            if cid == b"fmt ":
+                raw = fh.read(size + (size & 1))
+                tag, ch, sr, _, align, bits = struct.unpack("<HHIIHH", raw[:16])
+                if tag == 0xFFFE and size >= 26:
+                    tag = struct.unpack("<H", raw[24:26])[0]
+                fmt = (tag, ch, sr, align, bits)
+            elif cid == b"data":
+                if fmt is None:
+                    raise RuntimeError(f"Failed to load audio file '{path}': data before fmt")
+                tag, ch, sr, align, bits = fmt
+                total = size // align
+                start = min(int(start or 0), total)
+                n = total - start if frames is None else min(int(frames), total - start)
+                fh.seek(start * align, 1)
+                buf = fh.read(n * align)
+                if tag == 3:
+                    data = np.frombuffer(buf, dtype="<f4" if bits == 32 else "<f8").astype(np.float32)
+                elif tag == 1 and bits == 16:
+                    data = np.frombuffer(buf, dtype="<i2").astype(np.float32) / 32768.0
+                elif tag == 1 and bits == 32:
+                    data = np.frombuffer(buf, dtype="<i4").astype(np.float32) / 2147483648.0
+                elif tag == 1 and bits == 8:
+                    data = (np.frombuffer(buf, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
+                elif tag == 1 and bits == 24:
+                    b = np.frombuffer(buf, dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+                    v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+                    data = (np.where(v >= 1 << 23, v - (1 << 24), v)).astype(np.float32) / 8388608.0
+                else:
+                    raise RuntimeError(f"Failed to load audio file '{path}': unsupported format {tag}/{bits}")
+                return (data.reshape(-1, ch) if ch > 1 else data), sr
+            else:
+                fh.seek(size + (size & 1), 1)
+
+
+def wav_info(path):
+    """(frames, sample_rate, channels) without reading the samples."""
+    with open(path, "rb") as fh:
+        riff, _, wave_id = struct.unpack("<4sI4s", fh.read(12))
+        if riff != b"RIFF" or wave_id != b"WAVE":
+            raise RuntimeError("not a RIFF/WAVE file")
+        fmt = None
+        while True:
+            head = fh.read(8)
+            if len(head) < 8:
+                raise RuntimeError("no data chunk")
+            cid, size = struct.unpack("<4sI", head)
+            if cid == b"fmt ":
+                raw = fh.read(size + (size & 1))
+                _, ch, sr, _, align, _ = struct.unpack("<HHIIHH", raw[:16])
+                fmt = (ch, sr, align)
+            elif cid == b"data":
+                ch, sr, align = fmt
+                return size // align, sr, ch
+            else:
+                fh.seek(size + (size & 1), 1)
+
+
+# --------------------------------------------------------------------------- dataset
+class MelDataset(torch.utils.data.Dataset):
+    def __init__(self, data_list, sr=DEFAULT_MEL_PARAMS["sample_rate"], mel_params=None, f0_params=None,
+                 data_augmentation=False, validation=False, verbose=True, synthetic_data=None,
+                 f0_provider=None):
+        self.verbose = verbose
+        self.data_list = [line[:-1].split("|")[0] for line in data_list]        # meldataset.py:55-56
+
+        mel_params = dict(mel_params or {})
+        if "win_len" in mel_params and "win_length" not in mel_params:
+            mel_params["win_length"] = mel_params.pop("win_len")                # meldataset.py:59-60
+        self.mel_params = DEFAULT_MEL_PARAMS.copy()
+        self.mel_params.update(mel_params)
+        self.sr = sr if sr is not None else self.mel_params.get("sample_rate", DEFAULT_MEL_PARAMS["sample_rate"])
+        self.mel_params["sample_rate"] = self.sr
+        if self.verbose:
+            print(f"[MelDataset] Using mel-spectrogram parameters: {self.mel_params}")
+        self.to_melspec = MelSpectrogram(**self.mel_params)                     # HIP transform, (N,) -> (80, L)
+
+        self.f0_params = f0_params or {}
+        self.f0_provider = f0_provider
+        self.f0_cache_glob = "_f0*.npy"
+        self.mean, self.std = MEL_MEAN, MEL_STD
+        self.data_augmentation = data_augmentation and (not validation)
+        self.max_mel_length = MAX_MEL_LENGTH
+        self.zero_value = float(self.f0_params.get("zero_fill_value", 0.0))
+        self.bad_F0 = int(self.f0_params.get("bad_f0_threshold", 5))
+        self.requires_cuda_backend = False
+        self._audio_metadata_cache = {}
+        self._invalid_paths = set()
+        if synthetic_data and synthetic_data.get("enabled", False) and not validation:
+            logger.warning("synthetic_data augmentation (WORLD / pitch-shift) needs pyworld/librosa, which are "
+                           "not available: disabled")
+        self.synthetic_enabled = False
+
+    def __len__(self):
+        return len(self.data_list)
+
+    # ---- labels ---------------------------------------------------------------------------
+    def _load_cached_f0(self, path):
+        cands = sorted(glob.glob(glob.escape(path) + self.f0_cache_glob))
+        for c in cands:
+            try:
+                return np.load(c).astype(np.float32)
+            except (OSError, ValueError):
+                continue
+        return None
+
+    def _f0_for(self, path, waveform, start_sample, expected_frames):
+        cached = self._load_cached_f0(path)
+        if cached is not None:
+            if expected_frames is None:
+                return cached
+            hop = max(int(self.mel_params["hop_length"]), 1)
+            lo = max(0, int(math.floor(start_sample / float(hop))))              # meldataset.py:532-537
+            if lo >= cached.shape[0]:
+                return np.zeros((0,), dtype=np.float32)
+            return cached[lo:min(cached.shape[0], lo + int(expected_frames) + 4)]
+        if self.f0_provider is not None:
+            return np.asarray(self.f0_provider(path, waveform, self.sr), dtype=np.float32)
+        raise RuntimeError(f"no F0 labels for {path}: neither a '<wav>_f0*.npy' cache nor an f0_provider "
+                           "(the reference's tracker backends are outside this build)")
+
+    # ---- one item -------------------------------------------------------------------------
+    def _metadata(self, path):
+        md = self._audio_metadata_cache.get(path)
+        if md is None:
+            frames, sr, ch = wav_info(path)
+            md = {"frames": frames, "sample_rate": sr, "channels": ch}
+            self._audio_metadata_cache[path] = md
+        return md
+
+    def path_to_wave_and_label(self, path):
+        """Everything of meldataset.py:178-245 + :629-677 except the mel transform itself.
+        Returns (waveform f32 (N,), f0 (L,), is_silence (L,), crop_start) with L = min(mel_len, 192)."""
+        md = self._metadata(path)
+        hop = int(self.mel_params["hop_length"])
+        win = int(self.mel_params.get("win_length") or self.mel_params.get("n_fft", hop))
+        start, seg, full = segment_plan(int(md["frames"]), md["sample_rate"], self.sr, hop, win,
+                                        int(self.max_mel_length))
+        wave, wave_sr = read_wav(path, start, seg)
+        if wave.ndim > 1:
+            wave = np.mean(wave, axis=-1)
+        wave = wave.astype(np.float32)
+        if wave_sr != self.sr:
+            raise NotImplementedError(f"{path}: sample rate {wave_sr} != {self.sr}; resampling is not on the HIP "
+                                      "path yet (SURVEY N1)")
+        start_sample = 0 if full else int(round(start / float(md["sample_rate"]) * self.sr))
+        expected = None if full else int(np.ceil(len(wave) / max(hop, 1))) + 2
+        f0 = self._f0_for(path, wave, start_sample, expected)
+        if self.data_augmentation:
+            wave = (0.5 + 0.5 * np.random.random()) * wave                        # meldataset.py:232-234
+            wave = wave.astype(np.float32)
+        mel_len = 1 + len(wave) // hop
+        f0 = align_length(f0, mel_len)
+        sil = (f0 == 0).astype(np.float32)
+        crop = 0
+        if mel_len > self.max_mel_length:
+            crop = int(np.random.randint(0, mel_len - self.max_mel_length))       # meldataset.py:668-672
+            f0 = f0[crop:crop + self.max_mel_length]
+            sil = sil[crop:crop + self.max_mel_length]
+        f0 = np.where(np.isnan(f0), np.float32(self.zero_value), f0).astype(np.float32)
+        return wave, f0, sil, crop
+
+    def __getitem__(self, idx):
+        total = len(self.data_list)
+        if total == 0:
+            raise IndexError("MelDataset is empty")
+        for attempt in range(total):
+            path = self.data_list[(idx + attempt) % total]
+            if path in self._invalid_paths:
+                continue
+            try:
+                wave, f0, sil, crop = self.path_to_wave_and_label(path)
+            except (FileNotFoundError, RuntimeError, OSError, ValueError, struct.error) as exc:
+                if isinstance(exc, NotImplementedError):
+                    raise
+                self._invalid_paths.add(path)
+                logger.warning("[MelDataset] Skipping unreadable audio file: %s (%s)", path, exc)
+                continue
+            return torch.from_numpy(wave), torch.from_numpy(f0), torch.from_numpy(sil), crop
+        raise RuntimeError("No valid audio files could be loaded from the dataset")
+
+    def path_to_mel_and_label(self, path, device="cuda"):
+        """Reference-shaped single item: (mel (80, L<=192) normalised log-mel on the device, f0, is_silence)."""
+        wave, f0, sil, crop = self.path_to_wave_and_label(path)
+        mel = self.to_melspec(torch.from_numpy(wave).to(device))
+        mel = (torch.log(LOG_EPS + mel) - self.mean) / self.std
+        return mel[:, crop:crop + self.max_mel_length], torch.from_numpy(f0), torch.from_numpy(sil)
+
+
+class Collater(object):
+    """Zero-pads items to 192 frames (meldataset.py:790-826).
+
+    Accepts the reference's ``(mel (80,L), f0, is_silence)`` items, or this build's raw-audio items
+    ``(wave (N,), f0, is_silence, crop_start)``; for the latter it returns host tensors
+    ``(waves (B,Nmax), lengths, crop_starts, f0s, is_silences)`` for the device mel stage."""
+
+    def __init__(self, return_wave=False):
+        self.return_wave = return_wave
+        self.min_mel_length = MAX_MEL_LENGTH
+        self.max_mel_length = MAX_MEL_LENGTH
+
+    def __call__(self, batch):
+        B = len(batch)
+        L = self.max_mel_length
+        f0s = torch.zeros((B, L)).float()
+        sils = torch.zeros((B, L)).float()
+        if len(batch[0]) == 3:
+            n_mels = batch[0][0].size(0)
+            mels = torch.zeros((B, n_mels, L), dtype=torch.float32, device=batch[0][0].device)
+            for i, (mel, f0, sil) in enumerate(batch):
+                n = mel.size(1)
+                mels[i, :, :n] = mel
+                f0s[i, :n] = f0
+                sils[i, :n] = sil
+            return mels.unsqueeze(1), f0s, sils
+        n_max = max(int(item[0].shape[0]) for item in batch)
+        waves = torch.zeros((B, n_max), dtype=torch.float32)
+        lengths = torch.zeros((B,), dtype=torch.int32)
+        crops = torch.zeros((B,), dtype=torch.int32)
+        for i, (wave, f0, sil, crop) in enumerate(batch):
+            n = wave.shape[0]
+            waves[i, :n] = wave
+            lengths[i] = n
+            crops[i] = int(crop)
+            f0s[i, :f0.shape[0]] = f0
+            sils[i, :sil.shape[0]] = sil
+        return waves, lengths, crops, f0s, sils
+
+
+class DeviceMelLoader:
+    """Iterates a host DataLoader of raw-audio batches and yields the reference's batch tuple
+    ``(mels (B,1,80,192), f0s, is_silences)`` with the mel computed on the GPU in one launch."""
+
+    def __init__(self, loader: DataLoader, mel: MelSpectrogram, device):
+        self.loader, self.mel, self.device = loader, mel, torch.device(device)
+        self.dataset = loader.dataset
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        for waves, lengths, crops, f0s, sils in self.loader:
+            waves = waves.to(self.device, non_blocking=True)
+            lengths = lengths.to(self.device, non_blocking=True)
+            crops = crops.to(self.device, non_blocking=True)
+            mels = self.mel.log_mel_ragged(waves, lengths, crops, max_frames=MAX_MEL_LENGTH)
+            yield mels, f0s.to(self.device, non_blocking=True), sils.to(self.device, non_blocking=True)
+
+
+def build_dataloader(path_list, validation=False, batch_size=4, num_workers=1, device="cpu", collate_config=None,
+                     dataset_config=None):
+    dataset_config = dict(dataset_config or {})
+    dataloader_options = dataset_config.pop("dataloader", {}) or {}
+    if torch.device(device).type != "cuda":
+        raise RuntimeError("build_dataloader (HIP path): device must be a HIP ('cuda') device; the mel stage has "
+                           "no CPU fallback")
+    dataset = MelDataset(path_list, validation=validation, **dataset_config)
+    collate_fn = Collater(**(collate_config or {}))
+    kwargs = dict(batch_size=batch_size, shuffle=(not validation), num_workers=num_workers,
+                  drop_last=(not validation), collate_fn=collate_fn, pin_memory=True)
+    start_method = dataloader_options.get("start_method")
+    if start_method and num_workers > 0:
+        kwargs["multiprocessing_context"] = torch.multiprocessing.get_context(start_method)
+    if dataloader_options.get("persistent_workers") is not None and num_workers > 0:
+        kwargs["persistent_workers"] = bool(dataloader_options["persistent_workers"])
+    if dataloader_options.get("prefetch_factor") is not None and num_workers > 0:
+        kwargs["prefetch_factor"] = int(dataloader_options["prefetch_factor"])
+    return DeviceMelLoader(DataLoader(dataset, **kwargs), dataset.to_melspec, device)

@@ -1,0 +1,115 @@
+"""Host-side data-layer arithmetic (bit-exact: indices, interpolation, padding) -- no GPU needed."""
+import random
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import train_ref
+from pitchextractor_amd import meldataset as md
+from pitchextractor_amd import synthetic
+
+
+def write_wav(path, data, sr, fmt="pcm16"):
+    data = np.asarray(data)
+    ch = 1 if data.ndim == 1 else data.shape[1]
+    if fmt == "pcm16":
+        raw = (np.clip(data, -1, 1) * 32767).astype("<i2").tobytes(); tag, bits = 1, 16
+    elif fmt == "float32":
+        raw = data.astype("<f4").tobytes(); tag, bits = 3, 32
+    else:
+        raise ValueError(fmt)
+    align = ch * bits // 8
+    with open(path, "wb") as fh:
+        fh.write(b"RIFF" + struct.pack("<I", 36 + len(raw)) + b"WAVE")
+        fh.write(b"fmt " + struct.pack("<IHHIIHH", 16, tag, ch, sr, sr * align, align, bits))
+        fh.write(b"data" + struct.pack("<I", len(raw)) + raw)
+
+
+def test_align_length_matches_reference_golden(golden_dir):
+    D = np.load(golden_dir / "data_golden.npz")
+    for n in (159, 161, 163, 200, 7, 1):
+        np.testing.assert_array_equal(md.align_length(D[f"align_in_{n}"], 161), D[f"align_out_{n}"])
+    np.testing.assert_array_equal(md.align_length([0, 0, 100, 110, 120, 0, 0, 130, 140, 150], 7), D["align_probe"])
+    assert md.align_length(np.zeros(0), 5).tolist() == [0] * 5 and md.align_length([1.0, 2.0], 0).shape == (0,)
+
+
+def test_segment_plan_arithmetic():
+    # 58 624 samples @24 kHz, 107 722 @44.1 kHz
+    rng = random.Random(3)
+    s, seg, full = md.segment_plan(200000, 24000, 24000, 300, 1024, 192, rng)
+    assert seg == 58624 and not full and 0 <= s <= 200000 - 58624
+    _, seg44, _ = md.segment_plan(500000, 44100, 24000, 300, 1024, 192, rng)
+    assert seg44 == 107722
+    assert md.segment_plan(48000, 24000, 24000, 300, 1024, 192, rng) == (0, 58624, True)   # short file: whole
+    assert md.segment_plan(0, 24000, 24000, 300, 1024, 192, rng) == (0, None, True)
+    # same draws as the reference's random.randint(0, total - segment)
+    r1, r2 = random.Random(1), random.Random(1)
+    assert md.segment_plan(100000, 24000, 24000, 300, 1024, 192, r1)[0] == r2.randint(0, 100000 - 58624)
+
+
+@pytest.mark.parametrize("fmt", ["pcm16", "float32"])
+def test_wav_reader_roundtrip(tmp_path, fmt):
+    wave, _, _ = synthetic.utterance(0, duration=0.5)
+    p = tmp_path / "a.wav"
+    write_wav(p, wave, 24000, fmt)
+    assert md.wav_info(p) == (12000, 24000, 1)
+    data, sr = md.read_wav(p)
+    assert sr == 24000 and data.shape == (12000,)
+    tol = 1e-7 if fmt == "float32" else 1e-4        # 16-bit quantisation
+    assert np.abs(data - wave).max() <= tol
+    part, _ = md.read_wav(p, start=1000, frames=500)
+    np.testing.assert_array_equal(part, data[1000:1500])
+    stereo = np.stack([wave, -wave], axis=1)
+    write_wav(p, stereo, 24000, fmt)
+    d2, _ = md.read_wav(p)
+    assert d2.shape == (12000, 2) and md.wav_info(p) == (12000, 24000, 2)
+
+
+def test_dataset_item_and_collater(tmp_path):
+    rng = np.random.default_rng(0)
+    lines = []
+    for i, dur in enumerate((2.0, 3.0, 0.9)):
+        wave, f0, _ = synthetic.utterance(i, duration=dur)
+        p = tmp_path / f"u{i}.wav"
+        write_wav(p, wave, 24000, "float32")
+        np.save(str(p) + "_f0.npy", f0[: len(f0) - (i % 2)])          # legacy cache name, one frame short
+        lines.append(f"{p}|0\n")
+    ds = md.MelDataset.__new__(md.MelDataset)
+    # construct without the HIP transform (CPU test): exercise everything except to_melspec
+    ds.verbose = False
+    ds.data_list = [l[:-1].split("|")[0] for l in lines]
+    ds.mel_params = dict(md.DEFAULT_MEL_PARAMS); ds.sr = 24000
+    ds.f0_params = {}; ds.f0_provider = None; ds.f0_cache_glob = "_f0*.npy"
+    ds.data_augmentation = False; ds.max_mel_length = 192; ds.zero_value = 0.0
+    ds._audio_metadata_cache = {}; ds._invalid_paths = set()
+    items = [ds[i] for i in range(3)]
+    w0, f0_0, s0, c0 = items[0]
+    assert w0.shape == (48000,) and f0_0.shape == (161,) and c0 == 0
+    w1, f0_1, s1, c1 = items[1]
+    assert w1.shape == (58624,)                                       # pre-cropped segment
+    assert f0_1.shape == (192,) and 0 <= c1 < 196 - 192 + 1
+    assert torch.equal(s1, (f0_1 == 0).float())
+    w2, f0_2, _, _ = items[2]
+    assert f0_2.shape == (1 + 21600 // 300,)
+    waves, lengths, crops, f0s, sils = md.Collater()(items)
+    assert waves.shape == (3, 58624) and lengths.tolist() == [48000, 58624, 21600]
+    assert f0s.shape == (3, 192) and (f0s[0, 161:] == 0).all() and (sils[0, 161:] == 0).all()
+    # reference-shaped items go through the same padding as the oracle's collate
+    mel_items = [(torch.ones(80, L) * (i + 1), torch.full((L,), 100.0), torch.zeros(L)) for i, L in enumerate((161, 192, 100))]
+    mels, f0b, silb = md.Collater()(mel_items)
+    rm, rf, rs = train_ref.collate([(m.numpy(), f.numpy(), s.numpy()) for m, f, s in mel_items])
+    np.testing.assert_array_equal(mels.numpy(), rm)
+    np.testing.assert_array_equal(f0b.numpy(), rf)
+    np.testing.assert_array_equal(silb.numpy(), rs)
+
+
+def test_missing_labels_fail_loudly(tmp_path):
+    wave, _, _ = synthetic.utterance(0, duration=1.0)
+    p = tmp_path / "x.wav"
+    write_wav(p, wave, 24000)
+    ds = md.MelDataset.__new__(md.MelDataset)
+    ds.f0_cache_glob = "_f0*.npy"; ds.f0_provider = None; ds.mel_params = dict(md.DEFAULT_MEL_PARAMS); ds.sr = 24000
+    with pytest.raises(RuntimeError):
+        ds._f0_for(str(p), wave, 0, None)
