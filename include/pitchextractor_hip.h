@@ -176,6 +176,30 @@ int pe_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   float beta1, float beta2, float eps, float weight_decay, double bias_correction1,
                   double bias_correction2, float grad_scale, void* stream);
 
+/* ---- Transformer temporal head (model.py:178-193,229-241,253-255) ---------------------------
+ * pe_bgemm: batched 64x64-tiled fp32 MFMA GEMM over `batch` matrices; matrix b of operand X lives
+ *   at X + (b / inner) * x_outer + (b % inner) * x_inner (e.g. batch item / head inside the packed
+ *   QKV projection).  mode 0: C = alpha A B^T (A [M][K], B [N][K]); 1: C = alpha A B (B [K][N]);
+ *   2: C = alpha A^T B (A [K][M], B [K][N]).
+ * pe_softmax_fwd: s[row][:L] = softmax(scale * s[row][:L]) in place; pe_softmax_bwd: dp <- ds.
+ * pe_layernorm_fwd: z = a (+ b) (+ pe[row % period]); y = LN(z) * gamma + beta (eps inside the
+ *   sqrt); z_out (optional) keeps z for the backward; D in {256, 512, 768, 1024}.
+ * pe_gelu_*: exact erf GELU (activation="gelu") and its derivative. */
+int pe_bgemm(int mode, const float* A, long lda, long a_outer, long a_inner, const float* B, long ldb,
+             long b_outer, long b_inner, float* C, long ldc, long c_outer, long c_inner, int inner, int batch,
+             int M, int N, int K, float alpha, int accumulate, void* stream);
+int pe_softmax_fwd(float* s, long rows, int L, float scale, void* stream);
+int pe_softmax_bwd(const float* p, float* dp, long rows, int L, float scale, void* stream);
+int pe_layernorm_fwd(const float* a, const float* b, const float* pe, int period, const float* gamma,
+                     const float* beta, float eps, float* z_out, float* y, float* mean, float* rstd, long rows,
+                     int D, void* stream);
+size_t pe_layernorm_bwd_workspace_bytes(int D);
+int pe_layernorm_bwd(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
+                     float* dz, float* dgamma, float* dbeta, long rows, int D, void* workspace,
+                     size_t workspace_bytes, void* stream);
+int pe_gelu_fwd(const float* x, float* y, long n, void* stream);
+int pe_gelu_bwd(const float* x, const float* dy, float* dx, long n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -112,6 +112,35 @@ def bilstm(x, state, prefix, num_layers, bidirectional, p_drop, train, masks):
     return x
 
 
+def transformer_head(x, state, prefix, seq_cfg, train, masks):
+    """SequenceModel(model_type="transformer") (reference model.py:229-241,253-255): x + pe -> LayerNorm ->
+    N post-norm encoder layers (MHA, residual, LN, Linear-GELU-Linear, residual, LN).  Dropout masks are
+    consumed per layer in the order attention-probs, dropout1, feed-forward, dropout2."""
+    B, T, D = x.shape
+    H = seq_cfg.get("nhead", 8)
+    dh = D // H
+    p = seq_cfg.get("dropout", 0.3) if (train and masks is not None) else 0.0
+    pe = state[f"{prefix}.pos_encoding.pe"][0, :T].to(x.dtype)
+    x = F.layer_norm(x + pe, (D,), state[f"{prefix}.layer_norm.weight"], state[f"{prefix}.layer_norm.bias"], 1e-5)
+    for i in range(seq_cfg.get("num_layers", 2)):
+        L = f"{prefix}.model.layers.{i}"
+        qkv = x @ state[f"{L}.self_attn.in_proj_weight"].T + state[f"{L}.self_attn.in_proj_bias"]
+        q, k, v = (t.reshape(B, T, H, dh).transpose(1, 2) for t in qkv.split(D, dim=-1))     # (B,H,T,dh)
+        probs = torch.softmax((q @ k.transpose(-1, -2)) / (dh ** 0.5), dim=-1)
+        probs = _drop(probs.reshape(B * H * T, T), p, train, masks).reshape(B, H, T, T)
+        o = (probs @ v).transpose(1, 2).reshape(B, T, D)
+        sa = o @ state[f"{L}.self_attn.out_proj.weight"].T + state[f"{L}.self_attn.out_proj.bias"]
+        sa = _drop(sa.reshape(B * T, D), p, train, masks).reshape(B, T, D)
+        x = F.layer_norm(x + sa, (D,), state[f"{L}.norm1.weight"], state[f"{L}.norm1.bias"], 1e-5)
+        hdn = x @ state[f"{L}.linear1.weight"].T + state[f"{L}.linear1.bias"]
+        act = 0.5 * hdn * (1.0 + torch.erf(hdn / (2.0 ** 0.5)))
+        act = _drop(act.reshape(B * T, -1), p, train, masks).reshape(B, T, -1)
+        ff = act @ state[f"{L}.linear2.weight"].T + state[f"{L}.linear2.bias"]
+        ff = _drop(ff.reshape(B * T, D), p, train, masks).reshape(B, T, D)
+        x = F.layer_norm(x + ff, (D,), state[f"{L}.norm2.weight"], state[f"{L}.norm2.bias"], 1e-5)
+    return x
+
+
 def jdcnet_forward(state: Dict[str, torch.Tensor], x: torch.Tensor, seq_cfg: dict, train: bool = False,
                    masks=None, new_stats: Optional[dict] = None, taps: Optional[dict] = None,
                    fused_lstm: bool = False):
@@ -148,8 +177,16 @@ def jdcnet_forward(state: Dict[str, torch.Tensor], x: torch.Tensor, seq_cfg: dic
 
     seq_c = pb.permute(0, 2, 1, 3).reshape(-1, T, 512)
     seq_d = det.permute(0, 2, 1, 3).reshape(-1, T, 512)
-    if seq_cfg.get("model_type", "bilstm").lower() != "bilstm":
-        raise NotImplementedError("oracle: only the bilstm head is restated so far")
+    if seq_cfg.get("model_type", "bilstm").lower() == "transformer":
+        # the HIP path runs the classifier branch to the end, then the detector branch
+        yc = transformer_head(seq_c, state, "sequence_classifier", seq_cfg, train, masks)
+        yd = transformer_head(seq_d, state, "sequence_detector", seq_cfg, train, masks)
+        cls = yc @ state["classifier.weight"].T + state["classifier.bias"]
+        dlog = yd @ state["detector.weight"].T + state["detector.bias"]
+        if taps is not None:
+            taps.update(convblock_out=convblock, resblock1_out=rb1, resblock2_out=rb2, resblock3_out=rb3,
+                        poolblock_out=pb, detector_feat=det, seq_classifier_out=yc, seq_detector_out=yd)
+        return cls, dlog.sum(dim=-1)
     # the HIP path draws LSTM masks layer by layer for (classifier, detector); mirror that order
     if masks is not None and train and p_seq > 0:
         yc, yd = seq_c, seq_d
@@ -198,7 +235,8 @@ def jdc_loss(f0_pred, sil_pred, f0, sil, lambda_f0=0.1):
 
 # --------------------------------------------------------------------------- deterministic weights
 def seeded_state(seed: int, num_class: int = 1, hidden_size: int = 384, num_layers: int = 4,
-                 bidirectional: bool = True, dtype=torch.float32) -> Dict[str, torch.Tensor]:
+                 bidirectional: bool = True, dtype=torch.float32, model_type: str = "bilstm", nhead: int = 8,
+                 dim_feedforward: int = 1536, max_len: int = 2048) -> Dict[str, torch.Tensor]:
     """A full JDCNet(+BiLSTM) state_dict drawn from ``numpy.random.default_rng(seed)``: the same
     numbers whatever the torch version, so fixtures only have to store outputs."""
     import numpy as np
@@ -226,6 +264,36 @@ def seeded_state(seed: int, num_class: int = 1, hidden_size: int = 384, num_laye
     bn("pool_block.0", 256)
     conv("detector_conv.0", 256, 640, 1); bn("detector_conv.1", 256)
     nd = 2 if bidirectional else 1
+    if model_type == "transformer":
+        import math
+        D = 512
+        pe = torch.zeros(max_len, D)
+        pos = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+        div = torch.exp(torch.arange(0, D, 2).float() * (-math.log(10000.0) / D))
+        pe[:, 0::2] = torch.sin(pos * div)
+        pe[:, 1::2] = torch.cos(pos * div)
+        for branch in ("sequence_classifier", "sequence_detector"):
+            st[f"{branch}.pos_encoding.pe"] = pe.unsqueeze(0).to(dtype)
+            for i in range(num_layers):
+                L = f"{branch}.model.layers.{i}"
+                st[f"{L}.self_attn.in_proj_weight"] = normal((3 * D, D), D ** -0.5)
+                st[f"{L}.self_attn.in_proj_bias"] = normal((3 * D,), 0.1)
+                st[f"{L}.self_attn.out_proj.weight"] = normal((D, D), D ** -0.5)
+                st[f"{L}.self_attn.out_proj.bias"] = normal((D,), 0.1)
+                st[f"{L}.linear1.weight"] = normal((dim_feedforward, D), D ** -0.5)
+                st[f"{L}.linear1.bias"] = normal((dim_feedforward,), 0.1)
+                st[f"{L}.linear2.weight"] = normal((D, dim_feedforward), dim_feedforward ** -0.5)
+                st[f"{L}.linear2.bias"] = normal((D,), 0.1)
+                for nm in ("norm1", "norm2"):
+                    st[f"{L}.{nm}.weight"] = torch.from_numpy(rng.uniform(0.5, 1.5, D).astype(np.float32)).to(dtype)
+                    st[f"{L}.{nm}.bias"] = normal((D,), 0.1)
+            st[f"{branch}.layer_norm.weight"] = torch.from_numpy(rng.uniform(0.5, 1.5, D).astype(np.float32)).to(dtype)
+            st[f"{branch}.layer_norm.bias"] = normal((D,), 0.1)
+        st["classifier.weight"] = normal((num_class, D), D ** -0.5)
+        st["classifier.bias"] = normal((num_class,), 0.1)
+        st["detector.weight"] = normal((2, D), D ** -0.5)
+        st["detector.bias"] = normal((2,), 0.1)
+        return st
     for branch in ("sequence_classifier", "sequence_detector"):
         for layer in range(num_layers):
             in_sz = 512 if layer == 0 else hidden_size * nd

@@ -70,6 +70,14 @@ PROTOTYPES = {
     "pe_head_bwd_workspace_bytes": (_z, [_i]),
     "pe_head_bwd": (_i, [_p, _l, _p, _p, _i, _p, _l, _p, _p, _l, _i, _p, _z, _p]),
     "pe_f0_sil_loss": (_i, [_p, _p, _p, _p, _f, _l, _f, _p, _p, _p, _p]),
+    "pe_bgemm": (_i, [_i, _p, _l, _l, _l, _p, _l, _l, _l, _p, _l, _l, _l, _i, _i, _i, _i, _i, _f, _i, _p]),
+    "pe_softmax_fwd": (_i, [_p, _l, _i, _f, _p]),
+    "pe_softmax_bwd": (_i, [_p, _p, _l, _i, _f, _p]),
+    "pe_layernorm_fwd": (_i, [_p, _p, _p, _i, _p, _p, _f, _p, _p, _p, _p, _l, _i, _p]),
+    "pe_layernorm_bwd_workspace_bytes": (_z, [_i]),
+    "pe_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _l, _i, _p, _z, _p]),
+    "pe_gelu_fwd": (_i, [_p, _p, _l, _p]),
+    "pe_gelu_bwd": (_i, [_p, _p, _p, _l, _p]),
     "pe_adamw_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _d, _d, _f, _p]),
 }
 

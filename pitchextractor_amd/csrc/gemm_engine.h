@@ -309,6 +309,45 @@ __device__ __forceinline__ void tn_mainloop(AL& al, BL& bl, int k_begin, int k_e
   }
 }
 
+// ------------------------------------------------------------------ NN main loop (64 x 64 tile)
+// C[m][n] = sum_k A[m][k] * B[k][n]: A k-contiguous (NT-style image [64][36], ds_read_b128),
+// B k-major (TN-style image [32][64], ds_read_b32).  Waves 2 x 2, one 32x32 MFMA tile each.
+// Within an 8-wide k block MFMA j takes k = {j, 4 + j} for the two lane halves, on both operands.
+template <class AL, class BL>
+__device__ __forceinline__ void nn_mainloop_64(AL& al, BL& bl, int K, float* As, float* Bs, f32x16& acc) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm = wv >> 1, wn = wv & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int nk = (K + kBK - 1) / kBK;
+  float4 ra[2], rb[2];
+  ra[0] = al.load(0, 0); ra[1] = al.load(1, 0);
+  rb[0] = bl.load(0, 0, K); rb[1] = bl.load(1, 0, K);
+  const int sta = (tid >> 3) * kLdsStride + (tid & 7) * 4;
+  const int stb = (tid / TnGeom<64>::TPR) * 64 + TnGeom<64>::col4();
+  const float* a_rd = As + (wm * 32 + r) * kLdsStride + h * 4;
+  const float* b_rd = Bs + (h * 4) * 64 + wn * 32 + r;
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    *reinterpret_cast<float4*>(As + sta) = ra[0];
+    *reinterpret_cast<float4*>(As + sta + 32 * kLdsStride) = ra[1];
+    *reinterpret_cast<float4*>(Bs + stb) = rb[0];
+    *reinterpret_cast<float4*>(Bs + stb + TnGeom<64>::ROWS * 64) = rb[1];
+    __syncthreads();
+    if (kt + 1 < nk) {
+      ra[0] = al.load(0, kt + 1); ra[1] = al.load(1, kt + 1);
+      rb[0] = bl.load(0, (kt + 1) * kBK, K); rb[1] = bl.load(1, (kt + 1) * kBK, K);
+    }
+#pragma unroll
+    for (int k8 = 0; k8 < kBK / 8; ++k8) {
+      const float4 fa = *reinterpret_cast<const float4*>(a_rd + k8 * 8);
+      acc = mfma32(fa.x, b_rd[(k8 * 8 + 0) * 64], acc);
+      acc = mfma32(fa.y, b_rd[(k8 * 8 + 1) * 64], acc);
+      acc = mfma32(fa.z, b_rd[(k8 * 8 + 2) * 64], acc);
+      acc = mfma32(fa.w, b_rd[(k8 * 8 + 3) * 64], acc);
+    }
+  }
+}
+
 // Visit the accumulators of a TN tile: fn(row_in_tile, col_in_tile, value).
 template <int BM, int BN, class FN>
 __device__ __forceinline__ void tn_for_each_acc(const f32x16 (&acc)[BM / 64][BN / 64], FN&& fn) {

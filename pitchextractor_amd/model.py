@@ -91,6 +91,57 @@ class _LSTMWeights(nn.Module):
                 getattr(self, "bias_ih" + sfx), getattr(self, "bias_hh" + sfx))
 
 
+class SinusoidalPositionalEncoding(nn.Module):
+    """Buffer-only module: ``pe`` (1, max_len, d_model) exactly as model.py:181-190 builds it (it is
+    part of the checkpoint).  The add is fused into the first LayerNorm kernel."""
+
+    def __init__(self, d_model, max_len=2000):
+        super().__init__()
+        pe = torch.zeros(max_len, d_model)
+        position = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
+        pe[:, 0::2] = torch.sin(position * div_term)
+        pe[:, 1::2] = torch.cos(position * div_term)
+        self.register_buffer("pe", pe.unsqueeze(0))
+
+
+class _LayerNorm(nn.Module):
+    def __init__(self, d, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(d))
+        self.bias = nn.Parameter(torch.zeros(d))
+
+
+class _SelfAttention(nn.Module):
+    def __init__(self, d, nhead):
+        super().__init__()
+        self.embed_dim, self.num_heads = d, nhead
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * d, d))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d))
+        self.out_proj = _Linear(d, d)
+
+
+class _EncoderLayer(nn.Module):
+    """Parameters of nn.TransformerEncoderLayer(d, nhead, ff, dropout, batch_first, activation='gelu'),
+    post-norm (norm_first=False), in torch's registration order."""
+
+    def __init__(self, d, nhead, ff, dropout):
+        super().__init__()
+        self.p = dropout
+        self.self_attn = _SelfAttention(d, nhead)
+        self.linear1 = _Linear(d, ff)
+        self.linear2 = _Linear(ff, d)
+        self.norm1 = _LayerNorm(d)
+        self.norm2 = _LayerNorm(d)
+
+
+class _Encoder(nn.Module):
+    def __init__(self, d, nhead, ff, dropout, num_layers):
+        super().__init__()
+        self.layers = nn.ModuleList([_EncoderLayer(d, nhead, ff, dropout) for _ in range(num_layers)])
+
+
 class SequenceModel(nn.Module):
     """Temporal block of model.py:196-256.  ``bilstm`` runs on the HIP recurrence kernels."""
 
@@ -105,7 +156,14 @@ class SequenceModel(nn.Module):
             self.model = _LSTMWeights(input_size, hidden_size, num_layers, bidirectional)
             self._output_dim = hidden_size * (2 if bidirectional else 1)
         elif self.model_type == "transformer":
-            raise NotImplementedError("sequence_model.model_type='transformer' is not on the HIP path yet")
+            if input_size not in (256, 512, 768, 1024) or input_size % nhead or (input_size // nhead) % 4:
+                raise NotImplementedError("transformer head: d_model must be 256/512/768/1024 and divide by nhead")
+            self.dropout = dropout
+            self.nhead, self.dim_feedforward = nhead, dim_feedforward
+            self.pos_encoding = SinusoidalPositionalEncoding(input_size, max_len=max_len)
+            self.model = _Encoder(input_size, nhead, dim_feedforward, dropout, num_layers)
+            self.layer_norm = _LayerNorm(input_size)
+            self._output_dim = input_size
         else:
             raise ValueError(f"Unsupported sequence model type: {model_type}")
 
@@ -273,6 +331,97 @@ def _lstm_backward(models, saved, dys, grads):
     return dys
 
 
+def _tf_forward(sm, x, train, need_grad, drop: _DropoutCfg):
+    """SequenceModel(transformer).forward (model.py:253-255) for one branch.  x [B,T,D] -> [B,T,D]."""
+    B, T, D = x.shape
+    H = sm.nhead
+    dh = D // H
+    R = B * T
+    p = sm.dropout if train else 0.0
+    scale = 1.0 / math.sqrt(dh)
+    saved = _Ctx()
+    saved.layers = []
+    pe = sm.pos_encoding.pe[0, :T]
+    y, saved.ln0 = ops.layernorm_fwd(x.reshape(R, D), sm.layer_norm.weight, sm.layer_norm.bias, pe=pe.contiguous(),
+                                     eps=sm.layer_norm.eps)
+    for lyr in sm.model.layers:
+        c = _Ctx()
+        att = lyr.self_attn
+        c.x = y
+        c.qkv = ops.gemm_nt(y, att.in_proj_weight, bias0=att.in_proj_bias)               # [R, 3D]
+        qv, kv, vv = c.qkv[:, 0:D], c.qkv[:, D:2 * D], c.qkv[:, 2 * D:3 * D]
+        hview = (3 * D, T * 3 * D, dh)                                                     # (ld, per batch, per head)
+        c.P = torch.empty((B * H * T, T), dtype=torch.float32, device=x.device)
+        pview = (T, H * T * T, T * T)
+        ops.bgemm(0, qv, hview, kv, hview, c.P, pview, H, B * H, T, T, dh)
+        ops.softmax_fwd_(c.P, scale)
+        c.Pd, c.mask_p = _dropout(drop, c.P, p)
+        c.o = torch.empty((R, D), dtype=torch.float32, device=x.device)
+        ops.bgemm(1, c.Pd, pview, vv, hview, c.o, (D, T * D, dh), H, B * H, T, dh, T)
+        sa = ops.gemm_nt(c.o, att.out_proj.weight, bias0=att.out_proj.bias)
+        sa, c.mask1 = _dropout(drop, sa, p)
+        x1, c.ln1 = ops.layernorm_fwd(y, lyr.norm1.weight, lyr.norm1.bias, b2d=sa, eps=lyr.norm1.eps)
+        c.x1 = x1
+        c.h = ops.gemm_nt(x1, lyr.linear1.weight, bias0=lyr.linear1.bias)                  # [R, FF]
+        a = ops.gelu_fwd(c.h)
+        c.a, c.mask_f = _dropout(drop, a, p)
+        ff = ops.gemm_nt(c.a, lyr.linear2.weight, bias0=lyr.linear2.bias)
+        ff, c.mask2 = _dropout(drop, ff, p)
+        y, c.ln2 = ops.layernorm_fwd(x1, lyr.norm2.weight, lyr.norm2.bias, b2d=ff, eps=lyr.norm2.eps)
+        saved.layers.append(c)
+    saved.p, saved.shape = p, (B, T, D)
+    return y.view(B, T, D), (saved if need_grad else None)
+
+
+def _tf_backward(sm, saved, dy, g):
+    B, T, D = saved.shape
+    H = sm.nhead
+    dh = D // H
+    R = B * T
+    p = saved.p
+    scale = 1.0 / math.sqrt(dh)
+    dy = dy.reshape(R, D)
+    hview = (3 * D, T * 3 * D, dh)
+    pview = (T, H * T * T, T * T)
+    for lyr, c in zip(reversed(list(sm.model.layers)), reversed(saved.layers)):
+        att = lyr.self_attn
+        # y = LN2(x1 + dropout2(ff))
+        dsum = ops.layernorm_bwd(dy, c.ln2, lyr.norm2.weight, g[lyr.norm2.weight], g[lyr.norm2.bias])
+        dff = _dropout_bwd(dsum, p, c.mask2)
+        ops.gemm_tn(dff, c.a, out=g[lyr.linear2.weight])
+        ops.colsum(dff, g[lyr.linear2.bias])
+        da = ops.gemm_nt(dff, ops.transpose2d(lyr.linear2.weight))
+        da = _dropout_bwd(da, p, c.mask_f)
+        dh_ = ops.gelu_bwd(c.h, da, out=da)
+        ops.gemm_tn(dh_, c.x1, out=g[lyr.linear1.weight])
+        ops.colsum(dh_, g[lyr.linear1.bias])
+        dx1 = ops.gemm_nt(dh_, ops.transpose2d(lyr.linear1.weight))
+        ops.copy2d(dsum, dx1, accumulate=True)                                             # residual branch
+        # x1 = LN1(x + dropout1(sa))
+        dsum1 = ops.layernorm_bwd(dx1, c.ln1, lyr.norm1.weight, g[lyr.norm1.weight], g[lyr.norm1.bias])
+        dsa = _dropout_bwd(dsum1, p, c.mask1)
+        ops.gemm_tn(dsa, c.o, out=g[att.out_proj.weight])
+        ops.colsum(dsa, g[att.out_proj.bias])
+        do = ops.gemm_nt(dsa, ops.transpose2d(att.out_proj.weight))                        # [R, D] merged heads
+        qv, kv, vv = c.qkv[:, 0:D], c.qkv[:, D:2 * D], c.qkv[:, 2 * D:3 * D]
+        dqkv = torch.empty_like(c.qkv)
+        dq, dk, dv = dqkv[:, 0:D], dqkv[:, D:2 * D], dqkv[:, 2 * D:3 * D]
+        oview = (D, T * D, dh)
+        ops.bgemm(2, c.Pd, pview, do, oview, dv, hview, H, B * H, T, dh, T)                # dV = Pd^T dO
+        dP = torch.empty_like(c.P)
+        ops.bgemm(0, do, oview, vv, hview, dP, pview, H, B * H, T, T, dh)                  # dPd = dO V^T
+        dP = _dropout_bwd(dP, p, c.mask_p)
+        ops.softmax_bwd_(c.P, dP, scale)                                                   # dP <- dS (incl. 1/sqrt(dh))
+        ops.bgemm(1, dP, pview, kv, hview, dq, hview, H, B * H, T, dh, T)                  # dQ = dS K
+        ops.bgemm(2, dP, pview, qv, hview, dk, hview, H, B * H, T, dh, T)                  # dK = dS^T Q
+        ops.gemm_tn(dqkv, c.x, out=g[att.in_proj_weight])
+        ops.colsum(dqkv, g[att.in_proj_bias])
+        dy = ops.gemm_nt(dqkv, ops.transpose2d(att.in_proj_weight))
+        ops.copy2d(dsum1, dy, accumulate=True)
+    dx = ops.layernorm_bwd(dy, saved.ln0, sm.layer_norm.weight, g[sm.layer_norm.weight], g[sm.layer_norm.bias])
+    return dx.view(B, T, D)
+
+
 class _JDCFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, x, _anchor, need_grad):
@@ -331,6 +480,9 @@ class JDCNet(nn.Module):
                 nn.init.constant_(m.bias, 0)
             elif isinstance(m, _Conv):
                 nn.init.xavier_normal_(m.weight)
+            elif isinstance(m, _SelfAttention):
+                nn.init.xavier_uniform_(m.in_proj_weight)
+                nn.init.constant_(m.in_proj_bias, 0)
             elif isinstance(m, _LSTMWeights):
                 for p in m.parameters():
                     if p.dim() >= 2:
@@ -438,7 +590,11 @@ class JDCNet(nn.Module):
         seq_d = ops.nhwc_to_seq(ddrop.view(B, T, 2, 256), 256)
 
         models = [self.sequence_classifier, self.sequence_detector]
-        (yc, yd), s.lstm = _lstm_forward(models, [seq_c, seq_d], train, need_grad, self.dropout_cfg)
+        if models[0].model_type == "bilstm":
+            (yc, yd), s.lstm = _lstm_forward(models, [seq_c, seq_d], train, need_grad, self.dropout_cfg)
+        else:
+            yc, s.tf_c = _tf_forward(models[0], seq_c, train, need_grad, self.dropout_cfg)
+            yd, s.tf_d = _tf_forward(models[1], seq_d, train, need_grad, self.dropout_cfg)
         s.yc, s.yd = yc, yd
         D = yc.shape[-1]
         if self.num_class == 1:
@@ -473,7 +629,11 @@ class JDCNet(nn.Module):
         dyd = ops.head_bwd(s.yd.view(-1, D), det.weight, d_det.view(-1), g[det.weight], g[det.bias])
 
         models = [self.sequence_classifier, self.sequence_detector]
-        dseq_c, dseq_d = _lstm_backward(models, s.lstm, [dyc.view(B, T, D), dyd.view(B, T, D)], g)
+        if models[0].model_type == "bilstm":
+            dseq_c, dseq_d = _lstm_backward(models, s.lstm, [dyc.view(B, T, D), dyd.view(B, T, D)], g)
+        else:
+            dseq_d = _tf_backward(models[1], s.tf_d, dyd.view(B, T, D), g)
+            dseq_c = _tf_backward(models[0], s.tf_c, dyc.view(B, T, D), g)
 
         # detector branch (model.py:103-112)
         p_blk = self.block_dropout

@@ -476,3 +476,101 @@ def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_d
     bc2 = 1.0 - float(beta2) ** int(step)
     _call("pe_adamw_step", param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), n,
           float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), bc1, bc2, float(grad_scale), _s())
+
+
+# ------------------------------------------------------------------ transformer pieces
+def bgemm(mode, A, a_view, B, b_view, C, c_view, inner, batch, M, N, K, alpha=1.0, accumulate=False):
+    """Batched 64x64-tiled GEMM.  ``*_view`` = (ld, outer_stride, inner_stride) in elements; matrix b
+    of an operand starts at element (b // inner) * outer + (b % inner) * inner_stride of its tensor
+    (tensors may be views: the data pointer carries any extra offset)."""
+    for t, n in ((A, "A"), (B, "B"), (C, "C")):
+        _f32c(t, n)
+
+    def _extent(view, rows, cols):
+        ld, so, si = view
+        return ((batch - 1) // inner) * so + ((batch - 1) % inner if batch > 0 else 0) * si + (rows - 1) * ld + cols
+
+    a_rows, a_cols = (M, K) if mode != 2 else (K, M)
+    b_rows, b_cols = (N, K) if mode == 0 else (K, N)
+    for t, view, r, c, n in ((A, a_view, a_rows, a_cols, "A"), (B, b_view, b_rows, b_cols, "B"),
+                             (C, c_view, M, N, "C")):
+        avail = t.untyped_storage().nbytes() // 4 - t.storage_offset()
+        _chk(_extent(view, r, c) <= avail, f"bgemm: operand {n} exceeds its storage")
+    _call("pe_bgemm", int(mode), A.data_ptr(), *map(int, a_view), B.data_ptr(), *map(int, b_view), C.data_ptr(),
+          *map(int, c_view), int(inner), int(batch), int(M), int(N), int(K), float(alpha), int(bool(accumulate)),
+          _s(), work=2.0 * batch * M * N * K)
+    return C
+
+
+def softmax_fwd_(s2d, scale):
+    rows, L, ld = _rows2d(s2d, "scores")
+    _chk(ld == L, "softmax: dense rows")
+    _call("pe_softmax_fwd", s2d.data_ptr(), rows, L, float(scale), _s())
+    return s2d
+
+
+def softmax_bwd_(p2d, dp2d, scale):
+    rows, L, ld = _rows2d(p2d, "p")
+    r2, L2, ld2 = _rows2d(dp2d, "dp")
+    _chk((rows, L, ld) == (r2, L2, ld2) and ld == L, "softmax_bwd: shapes")
+    _call("pe_softmax_bwd", p2d.data_ptr(), dp2d.data_ptr(), rows, L, float(scale), _s())
+    return dp2d
+
+
+class LnState:
+    def __init__(self, z, mean, rstd):
+        self.z, self.mean, self.rstd = z, mean, rstd
+
+
+def layernorm_fwd(a2d, gamma, beta, b2d=None, pe=None, eps=1e-5, keep_z=True):
+    """y = LN(a + b + pe[row % period]); returns (y, LnState).  ``pe`` is [period, D] contiguous."""
+    a2d = _dense(a2d, "a")
+    R, D = a2d.shape
+    if b2d is not None:
+        _chk(_dense(b2d, "b").shape == (R, D), "layernorm: b shape")
+    period = 0
+    if pe is not None:
+        _chk(_dense(pe, "pe").dim() == 2 and pe.shape[1] == D, "layernorm: pe shape")
+        period = pe.shape[0]
+    _chk(_dense(gamma, "gamma").numel() == D and _dense(beta, "beta").numel() == D, "layernorm: affine size")
+    need_z = keep_z and (b2d is not None or pe is not None)
+    z = torch.empty_like(a2d) if need_z else None
+    y = torch.empty_like(a2d)
+    mean = torch.empty((R,), dtype=torch.float32, device=a2d.device)
+    rstd = torch.empty((R,), dtype=torch.float32, device=a2d.device)
+    _call("pe_layernorm_fwd", a2d.data_ptr(), _lib.ptr(b2d), _lib.ptr(pe), period, gamma.data_ptr(), beta.data_ptr(),
+          float(eps), _lib.ptr(z), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), R, D, _s())
+    return y, LnState(z if need_z else (a2d if keep_z else None), mean, rstd)
+
+
+def layernorm_bwd(dy2d, st: LnState, gamma, dgamma, dbeta, dz=None):
+    dy2d = _dense(dy2d, "dy")
+    R, D = dy2d.shape
+    _chk(_dense(st.z, "z").shape == (R, D), "layernorm_bwd: z shape")
+    if dz is None:
+        dz = torch.empty_like(dy2d)
+    _chk(_dense(dz, "dz").shape == (R, D), "layernorm_bwd: dz shape")
+    _chk(_dense(dgamma, "dgamma").numel() == D and _dense(dbeta, "dbeta").numel() == D, "layernorm_bwd: grads")
+    lib = _lib.load()
+    ws = workspace(lib.pe_layernorm_bwd_workspace_bytes(D), dy2d.device)
+    _call("pe_layernorm_bwd", dy2d.data_ptr(), st.z.data_ptr(), st.mean.data_ptr(), st.rstd.data_ptr(),
+          gamma.data_ptr(), dz.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), R, D, ws.data_ptr(), ws.numel(), _s())
+    return dz
+
+
+def gelu_fwd(x, out=None):
+    x = _dense(x, "x")
+    if out is None:
+        out = torch.empty_like(x)
+    _chk(_dense(out, "out").numel() == x.numel(), "gelu: out size")
+    _call("pe_gelu_fwd", x.data_ptr(), out.data_ptr(), x.numel(), _s())
+    return out
+
+
+def gelu_bwd(x, dy, out=None):
+    x, dy = _dense(x, "x"), _dense(dy, "dy")
+    _chk(x.numel() == dy.numel(), "gelu_bwd: sizes")
+    if out is None:
+        out = torch.empty_like(x)
+    _call("pe_gelu_bwd", x.data_ptr(), dy.data_ptr(), out.data_ptr(), x.numel(), _s())
+    return out

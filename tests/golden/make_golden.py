@@ -27,6 +27,8 @@ sys.path.insert(0, str(ROOT))
 from oracle import mel_ref, model_ref  # noqa: E402
 from pitchextractor_amd import synthetic  # noqa: E402
 
+TF_CFG = {"model_type": "transformer", "num_layers": 4, "dropout": 0.0, "nhead": 8,
+          "dim_feedforward": 1536, "max_len": 2048}
 SEQ_CFG = {"model_type": "bilstm", "num_layers": 4, "dropout": 0.0, "nhead": 8,
            "dim_feedforward": 1536, "max_len": 2048}
 
@@ -71,9 +73,14 @@ def tap_summary(t):
 def make_model_goldens(ref_model_mod):
     out = {}
     for tag, num_class, hidden, dtype in (("nc1", 1, 384, torch.float32), ("nc360", 360, 64, torch.float32),
-                                          ("nc1_f64", 1, 384, torch.float64)):
-        state = model_ref.seeded_state(11, num_class=num_class, hidden_size=hidden)
-        cfg = dict(SEQ_CFG, hidden_size=hidden)
+                                          ("nc1_f64", 1, 384, torch.float64), ("tf", 1, 0, torch.float32),
+                                          ("tf_f64", 1, 0, torch.float64)):
+        if tag.startswith("tf"):
+            state = model_ref.seeded_state(11, num_class=num_class, model_type="transformer")
+            cfg = dict(TF_CFG)
+        else:
+            state = model_ref.seeded_state(11, num_class=num_class, hidden_size=hidden)
+            cfg = dict(SEQ_CFG, hidden_size=hidden)
         net = ref_model_mod.JDCNet(num_class=num_class, sequence_model_config=dict(cfg))
         missing = net.load_state_dict(state, strict=True)
         assert not missing.missing_keys and not missing.unexpected_keys
@@ -83,12 +90,12 @@ def make_model_goldens(ref_model_mod):
         f0, sil = golden_targets(3)
         f0, sil = f0.to(dtype), sil.to(dtype)
 
-        # eval-mode forward (running statistics)
+        # eval-mode forward (running statistics); grad stays enabled so nn.TransformerEncoder takes its
+        # ordinary path rather than the fused inference fast path (SURVEY A7 caveat)
         net.eval()
-        with torch.no_grad():
-            cls_e, det_e = net(x)
-        out[f"{tag}_eval_cls"] = cls_e.numpy()
-        out[f"{tag}_eval_det"] = det_e.numpy()
+        cls_e, det_e = net(x)
+        out[f"{tag}_eval_cls"] = cls_e.detach().numpy()
+        out[f"{tag}_eval_det"] = det_e.detach().numpy()
 
         # train-mode forward/backward with all dropout rates 0
         net.train()
@@ -120,7 +127,12 @@ def make_model_goldens(ref_model_mod):
             for n in ("conv_block.0.weight", "conv_block.1.weight", "res_block2.conv.3.weight",
                       "res_block3.conv1by1.weight", "detector_conv.0.weight",
                       "sequence_classifier.model.weight_hh_l0", "sequence_detector.model.weight_ih_l3_reverse",
-                      "sequence_classifier.model.bias_ih_l2", "classifier.weight", "detector.bias"):
+                      "sequence_classifier.model.bias_ih_l2", "classifier.weight", "detector.bias",
+                      "sequence_classifier.model.layers.0.self_attn.in_proj_weight",
+                      "sequence_detector.model.layers.3.linear2.weight",
+                      "sequence_classifier.model.layers.2.norm1.weight", "sequence_detector.layer_norm.bias"):
+                if n not in dict(net.named_parameters()):
+                    continue
                 g = dict(net.named_parameters())[n].grad.flatten()
                 idx = torch.linspace(0, g.numel() - 1, min(32, g.numel())).long()
                 out[f"{tag}_grad_{n}"] = g[idx].numpy()

@@ -160,3 +160,36 @@ def test_fused_lstm_baseline_path_equals_explicit_loop():
         b = model_ref.jdcnet_forward(state, x, cfg, fused_lstm=True)
     for u, v in zip(a, b):
         np.testing.assert_allclose(u.numpy(), v.numpy(), rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------ Transformer head
+def _tf_pass(dtype):
+    from tests.golden.make_golden import TF_CFG
+    state = {k: (v.to(dtype) if v.dtype.is_floating_point else v)
+             for k, v in model_ref.seeded_state(11, model_type="transformer").items()}
+    params = {k: v.clone().requires_grad_(True) for k, v in state.items() if v.dtype.is_floating_point
+              and not k.endswith(("running_mean", "running_var", "pos_encoding.pe"))}
+    live = dict(state)
+    live.update(params)
+    cls, det = model_ref.jdcnet_forward(live, golden_input(3).to(dtype), dict(TF_CFG), train=True)
+    f0, sil = (t.to(dtype) for t in golden_targets(3))
+    loss, lf0, lsil = model_ref.jdc_loss(cls, det, f0, sil, 0.1)
+    loss.backward()
+    return dict(cls=cls, det=det, loss=(loss.item(), lf0.item(), lsil.item()), params=params)
+
+
+def test_transformer_head_matches_reference_float64(G):
+    run = _tf_pass(torch.float64)
+    np.testing.assert_allclose(run["cls"].detach().numpy(), G["tf_f64_train_cls"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(run["det"].detach().numpy(), G["tf_f64_train_det"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(run["loss"], G["tf_f64_loss"], rtol=1e-12)
+    _check_grads(G, "tf_f64", run, 1e-9, 1e-7, 1e-9)
+
+
+def test_transformer_eval_forward_matches_reference(G):
+    from tests.golden.make_golden import TF_CFG
+    state = model_ref.seeded_state(11, model_type="transformer")
+    with torch.no_grad():
+        cls, det = model_ref.jdcnet_forward(state, golden_input(3), dict(TF_CFG))
+    np.testing.assert_allclose(cls.numpy(), G["tf_eval_cls"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(det.numpy(), G["tf_eval_det"], rtol=2e-4, atol=2e-5)

@@ -1,0 +1,165 @@
+"""Transformer temporal head on the HIP path: each new op vs a PyTorch fp64 reference, then the whole
+JDCNet(model_type="transformer") vs the reference's golden vectors (float64) and the oracle with
+replayed dropout masks."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import model_ref
+from pitchextractor_amd import ops
+from pitchextractor_amd.model import JDCNet
+from tests.golden.make_golden import TF_CFG, golden_input, golden_targets
+from tests.test_ops_gpu import close, rnd
+
+pytestmark = pytest.mark.gpu
+
+
+def test_batched_attention_products(hip_device):
+    B, H, T, dh = 3, 8, 192, 64
+    D = H * dh
+    qkv = rnd(B * T, 3 * D, seed=1).to(hip_device)
+    q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    hview, pview, oview = (3 * D, T * 3 * D, dh), (T, H * T * T, T * T), (D, T * D, dh)
+    heads = lambda t: t.cpu().double().view(B, T, H, dh).transpose(1, 2)          # (B,H,T,dh)
+    S = torch.empty(B * H * T, T, device=hip_device)
+    ops.bgemm(0, q, hview, k, hview, S, pview, H, B * H, T, T, dh, alpha=0.5)
+    close(S.view(B, H, T, T), 0.5 * heads(q) @ heads(k).transpose(-1, -2))
+    P = torch.softmax(rnd(B * H * T, T, seed=2), dim=-1).to(hip_device)
+    O = torch.empty(B * T, D, device=hip_device)
+    ops.bgemm(1, P, pview, v, hview, O, oview, H, B * H, T, dh, T)
+    refO = (P.cpu().double().view(B, H, T, T) @ heads(v)).transpose(1, 2).reshape(B * T, D)
+    close(O, refO)
+    dO = rnd(B * T, D, seed=3).to(hip_device)
+    dqkv = torch.zeros_like(qkv)
+    ops.bgemm(2, P, pview, dO, oview, dqkv[:, 2 * D:], hview, H, B * H, T, dh, T)
+    ref_dv = (P.cpu().double().view(B, H, T, T).transpose(-1, -2) @ heads(dO)).transpose(1, 2).reshape(B * T, D)
+    close(dqkv[:, 2 * D:], ref_dv)
+    assert (dqkv[:, :2 * D] == 0).all()
+    acc = rnd(B * T, D, seed=4).to(hip_device)
+    ref_acc = acc.cpu().double() + refO
+    ops.bgemm(1, P, pview, v, hview, acc, oview, H, B * H, T, dh, T, accumulate=True)
+    close(acc, ref_acc)
+
+
+def test_softmax_fwd_bwd(hip_device):
+    s = (rnd(500, 192, seed=1) * 4).double().requires_grad_(True)
+    p = torch.softmax(s * 0.125, dim=-1)
+    dp = rnd(500, 192, seed=2).double()
+    p.backward(dp)
+    sd = s.detach().float().to(hip_device)
+    ops.softmax_fwd_(sd, 0.125)
+    close(sd, p)
+    dpd = dp.float().to(hip_device)
+    ops.softmax_bwd_(sd, dpd, 0.125)
+    close(dpd, s.grad)
+    odd = (rnd(7, 100, seed=3)).to(hip_device)                 # row length not a multiple of 64
+    ref = torch.softmax(odd.cpu().double(), dim=-1)
+    close(ops.softmax_fwd_(odd, 1.0), ref)
+
+
+@pytest.mark.parametrize("D", [256, 512, 768])
+def test_layernorm_fwd_bwd(hip_device, D):
+    R, T = 333, 37
+    a = rnd(R, D, seed=1).double().requires_grad_(True)
+    b = rnd(R, D, seed=2).double().requires_grad_(True)
+    pe = rnd(T, D, seed=3).double()
+    g = (rnd(D, seed=4).abs() + 0.5).double().requires_grad_(True)
+    be = rnd(D, seed=5).double().requires_grad_(True)
+    z = a + b + pe[torch.arange(R) % T]
+    y = F.layer_norm(z, (D,), g, be, 1e-5)
+    dy = rnd(R, D, seed=6).double()
+    y.backward(dy)
+    dev = hip_device
+    f = lambda t: t.detach().float().to(dev)
+    yd, st = ops.layernorm_fwd(f(a), f(g), f(be), b2d=f(b), pe=f(pe))
+    close(yd, y)
+    close(st.z, z.detach())
+    dg, db = torch.empty(D, device=dev), torch.empty(D, device=dev)
+    dz = ops.layernorm_bwd(f(dy), st, f(g), dg, db)
+    close(dz, a.grad, 2e-5)
+    close(dg, g.grad, 2e-5)
+    close(db, be.grad, 2e-5)
+    y2, st2 = ops.layernorm_fwd(f(a), f(g), f(be))              # no residual: z is the input itself
+    close(y2, F.layer_norm(a.detach(), (D,), g.detach(), be.detach(), 1e-5))
+    assert st2.z.data_ptr() != 0
+
+
+def test_gelu_exact(hip_device):
+    x = (rnd(1000, 1536, seed=1) * 2).double().requires_grad_(True)
+    y = F.gelu(x)                                                  # erf form
+    dy = rnd(1000, 1536, seed=2).double()
+    y.backward(dy)
+    xd = x.detach().float().to(hip_device)
+    close(ops.gelu_fwd(xd), y)
+    close(ops.gelu_bwd(xd, dy.float().to(hip_device)), x.grad)
+
+
+# ------------------------------------------------------------------ whole model
+def build(state, device, dropout=0.0):
+    net = JDCNet(num_class=1, sequence_model_config=dict(TF_CFG, dropout=dropout))
+    net.load_state_dict(state, strict=True)
+    return net.to(device)
+
+
+@pytest.fixture(scope="module")
+def G(golden_dir):
+    return np.load(golden_dir / "model_golden.npz")
+
+
+def _rel(got, ref):
+    got = np.asarray(got.detach().cpu().double()); ref = np.asarray(ref, dtype=np.float64)
+    return np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30)
+
+
+def test_transformer_eval_matches_reference(G, hip_device):
+    net = build(model_ref.seeded_state(11, model_type="transformer"), hip_device).eval()
+    with torch.no_grad():
+        cls, det = net(golden_input(3).to(hip_device))
+    assert _rel(cls, G["tf_eval_cls"]) <= 1e-4 and _rel(det, G["tf_eval_det"]) <= 1e-4
+
+
+def test_transformer_train_step_matches_reference_float64(G, hip_device):
+    net = build(model_ref.seeded_state(11, model_type="transformer"), hip_device).train()
+    net.block_dropout = 0.0
+    f0, sil = (t.to(hip_device) for t in golden_targets(3))
+    cls, det = net(golden_input(3).to(hip_device))
+    out3, d_f0, d_sil = ops.f0_sil_loss(cls.detach().reshape(-1), f0.reshape(-1), det.detach().reshape(-1),
+                                        sil.reshape(-1), 0.1)
+    torch.autograd.backward([cls, det], [d_f0.view_as(cls), d_sil.view_as(det)])
+    assert _rel(cls, G["tf_f64_train_cls"]) <= 1e-4 and _rel(det, G["tf_f64_train_det"]) <= 1e-4
+    np.testing.assert_allclose(out3.cpu().numpy(), G["tf_f64_loss"], rtol=1e-5)
+    names = [str(n) for n in G["tf_f64_grad_names"]]
+    assert names == [n for n, _ in net.named_parameters()]
+    norms = dict(zip(names, G["tf_f64_grad_norms"]))
+    bad = [(n, p.grad.double().norm().item(), norms[n]) for n, p in net.named_parameters()
+           if abs(p.grad.double().norm().item() - norms[n]) > 2e-3 * norms[n] + 1e-9]
+    assert not bad, bad
+    for key in G.files:
+        if key.startswith("tf_f64_grad_") and not key.endswith(("_grad_names", "_grad_norms")):
+            n = key[len("tf_f64_grad_"):]
+            g = dict(net.named_parameters())[n].grad.flatten().cpu()
+            idx = torch.linspace(0, g.numel() - 1, min(32, g.numel())).long()
+            assert np.abs(g[idx].numpy() - G[key]).max() <= 5e-3 * np.abs(G[key]).max() + 1e-9, n
+
+
+def test_transformer_dropout_masks_replayed_in_oracle(hip_device):
+    state = model_ref.seeded_state(11, model_type="transformer", num_layers=2)
+    cfg = dict(TF_CFG, num_layers=2, dropout=0.1)
+    net = JDCNet(num_class=1, sequence_model_config=dict(cfg))
+    net.load_state_dict(state)
+    net = net.to(hip_device).train()
+    net.keep_last_context = True
+    net.dropout_cfg.seed = 5
+    x = golden_input(6)
+    cls, det = net(x.to(hip_device))
+    s = net.last_context
+    masks = [s.mask_pool.cpu(), s.mask_det.cpu()]
+    for tf in (s.tf_c, s.tf_d):
+        for c in tf.layers:
+            masks += [c.mask_p.cpu(), c.mask1.cpu(), c.mask_f.cpu(), c.mask2.cpu()]
+    st64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in state.items()}
+    rc, rd = model_ref.jdcnet_forward(st64, x.double(), cfg, train=True, masks=iter(masks))
+    assert _rel(cls, rc.detach().numpy()) <= 1e-4 and _rel(det, rd.detach().numpy()) <= 1e-4
