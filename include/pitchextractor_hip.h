@@ -149,6 +149,18 @@ int pe_lstm_fwd(int ncells, const float* const* whh, float* const* gates, float*
 int pe_lstm_bwd(int ncells, const float* const* whh_t, float* const* gates, const float* const* cbuf,
                 const float* const* dy, float* const* dcarry, const int* reverse, long lddy, int B, int T,
                 int H, void* stream);
+/* Persistent variants: one launch for all T steps, W_hh slice resident in registers, group barriers
+ * between steps (agent-scope release/acquire).  `sync` = pe_lstm_persistent_sync_bytes() of device
+ * memory, zero-initialised once by the caller; word 0 is a sticky error flag (non-zero = a bounded
+ * spin timed out: results invalid).  Only when pe_lstm_persistent_supported() returns 1. */
+size_t pe_lstm_persistent_sync_bytes(int ncells, int B);
+int pe_lstm_persistent_supported(int ncells, int B, int H);
+int pe_lstm_fwd_persistent(int ncells, const float* const* whh, float* const* gates, float* const* y,
+                           float* const* cbuf, const int* reverse, long ldy, int B, int T, int H,
+                           unsigned* sync, void* stream);
+int pe_lstm_bwd_persistent(int ncells, const float* const* whh_t, float* const* gates,
+                           const float* const* cbuf, const float* const* dy, const int* reverse, long lddy,
+                           int B, int T, int H, unsigned* sync, void* stream);
 size_t pe_lstm_whh_grad_workspace_bytes(int B, int T, int H);
 int pe_lstm_whh_grad(const float* dgates, const float* y, long ldy, float* dwhh, int B, int T, int H,
                      int reverse, float* workspace, size_t workspace_bytes, void* stream);

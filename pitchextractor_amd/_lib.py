@@ -62,6 +62,10 @@ PROTOTYPES = {
     "pe_copy2d": (_i, [_p, _l, _p, _l, _l, _i, _i, _p]),
     "pe_lstm_fwd": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _p]),
     "pe_lstm_bwd": (_i, [_i, _pp, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _p]),
+    "pe_lstm_persistent_sync_bytes": (_z, [_i, _i]),
+    "pe_lstm_persistent_supported": (_i, [_i, _i, _i]),
+    "pe_lstm_fwd_persistent": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _p, _p]),
+    "pe_lstm_bwd_persistent": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _p, _p]),
     "pe_lstm_whh_grad_workspace_bytes": (_z, [_i, _i, _i]),
     "pe_lstm_whh_grad": (_i, [_p, _p, _l, _p, _i, _i, _i, _i, _p, _z, _p]),
     "pe_colsum_workspace_bytes": (_z, [_i]),

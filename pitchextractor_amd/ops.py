@@ -366,6 +366,35 @@ def _int_array(vals):
     return arr
 
 
+_SYNC: dict = {}
+USE_PERSISTENT_LSTM = True
+
+
+def _lstm_sync(ncells, B, device):
+    """Zero-initialised barrier words for the persistent LSTM kernels (word 0 = sticky error flag)."""
+    lib = _lib.load()
+    need = lib.pe_lstm_persistent_sync_bytes(4, max(B, 1024)) // 4
+    key = torch.device(device)
+    buf = _SYNC.get(key)
+    if buf is None or buf.numel() < need:
+        buf = torch.zeros(need, dtype=torch.int32, device=key)
+        _SYNC[key] = buf
+    return buf
+
+
+def persistent_lstm_error(device) -> bool:
+    """True if a persistent-LSTM group barrier ever timed out on this device (results invalid)."""
+    buf = _SYNC.get(torch.device(device))
+    return bool(buf is not None and int(buf[0].item()) != 0)
+
+
+def _persistent_ok(ncells, B, H, device):
+    if not USE_PERSISTENT_LSTM:
+        return False
+    with torch.cuda.device(device):
+        return bool(_lib.load().pe_lstm_persistent_supported(ncells, B, H))
+
+
 def lstm_fwd(whh, gates, y_slices, cbuf, reverse, B, T, H):
     """Advance len(whh) cells through all T steps.  y_slices[i] is a view [B,T,H] into a dense
     [B,T,ldy] output (ldy = 2H for bidirectional)."""
@@ -380,6 +409,13 @@ def lstm_fwd(whh, gates, y_slices, cbuf, reverse, B, T, H):
         _chk(ys.shape == (B, T, H) and ys.stride(2) == 1 and ys.stride(0) == T * ys.stride(1), "y slice layout")
         _chk(ldy in (None, ys.stride(1)), "all y slices share ldy")
         ldy = ys.stride(1)
+    dev = gates[0].device
+    if _persistent_ok(n, B, H, dev):
+        sync = _lstm_sync(n, B, dev)
+        _call("pe_lstm_fwd_persistent", n, _ptr_array(whh), _ptr_array(gates), _ptr_array(y_slices),
+              _ptr_array(cbuf), _int_array(reverse), ldy, B, T, H, sync.data_ptr(), _s(),
+              work=2.0 * n * B * (T - 1) * 4 * H * H)
+        return
     _call("pe_lstm_fwd", n, _ptr_array(whh), _ptr_array(gates), _ptr_array(y_slices), _ptr_array(cbuf),
           _int_array(reverse), ldy, B, T, H, _s(), work=2.0 * n * B * (T - 1) * 4 * H * H)
 
@@ -398,6 +434,13 @@ def lstm_bwd(whh_t, gates, cbuf, dy_slices, dcarry, reverse, B, T, H):
         _chk(d.shape == (B, T, H) and d.stride(2) == 1 and d.stride(0) == T * d.stride(1), "dy slice layout")
         _chk(ld in (None, d.stride(1)), "all dy slices share ld")
         ld = d.stride(1)
+    dev = gates[0].device
+    if _persistent_ok(n, B, H, dev):
+        sync = _lstm_sync(n, B, dev)
+        _call("pe_lstm_bwd_persistent", n, _ptr_array(whh_t), _ptr_array(gates), _ptr_array(cbuf),
+              _ptr_array(dy_slices), _int_array(reverse), ld, B, T, H, sync.data_ptr(), _s(),
+              work=2.0 * n * B * (T - 1) * 4 * H * H)
+        return
     _call("pe_lstm_bwd", n, _ptr_array(whh_t), _ptr_array(gates), _ptr_array(cbuf), _ptr_array(dy_slices),
           _ptr_array(dcarry), _int_array(reverse), ld, B, T, H, _s(), work=2.0 * n * B * (T - 1) * 4 * H * H)
 

@@ -171,6 +171,9 @@ class Trainer(object):
         self.optimizer.step()
         self.scheduler.step()
         loss, loss_f0, loss_sil = out3.tolist()            # one device->host copy for all three scalars
+        if ops.persistent_lstm_error(x.device):
+            raise RuntimeError("persistent LSTM kernel: a group barrier timed out (workgroups not co-resident?); "
+                               "set pitchextractor_amd.ops.USE_PERSISTENT_LSTM = False")
         return {"loss": loss, "f0": loss_f0, "sil": loss_sil}
 
     def _train_epoch(self):

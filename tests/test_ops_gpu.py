@@ -216,8 +216,10 @@ def test_seq_relayout(hip_device):
 
 
 # ------------------------------------------------------------------ LSTM
-@pytest.mark.parametrize("B,T,In,H", [(5, 7, 96, 64), (70, 4, 64, 32), (3, 11, 128, 96)])
-def test_lstm_layer_bidirectional(hip_device, B, T, In, H):
+@pytest.mark.parametrize("persistent", [False, True])
+@pytest.mark.parametrize("B,T,In,H", [(5, 7, 96, 64), (70, 4, 64, 32), (3, 11, 128, 96), (130, 9, 64, 384)])
+def test_lstm_layer_bidirectional(hip_device, B, T, In, H, persistent, monkeypatch):
+    monkeypatch.setattr(ops, "USE_PERSISTENT_LSTM", persistent)
     torch.manual_seed(0)
     ref = torch.nn.LSTM(In, H, num_layers=1, batch_first=True, bidirectional=True).double()
     x = rnd(B, T, In, seed=1).double().requires_grad_(True)
@@ -257,6 +259,7 @@ def test_lstm_layer_bidirectional(hip_device, B, T, In, H):
         assert torch.equal(db0, db1)
         ops.gemm_nt(dg, ops.transpose2d(P["weight_ih_l0" + sfx]), out=dx.view(-1, In), accumulate=(d > 0))
     close(dx, x.grad, 5e-5)
+    assert not ops.persistent_lstm_error(dev)
 
 
 # ------------------------------------------------------------------ heads / loss / AdamW
