@@ -1,31 +1,39 @@
 // Persistent LSTM recurrence: ONE launch walks all T time steps of a layer for up to 4 cells.
 //
-// Why: with one launch per step every workgroup re-reads its W_hh slice (196 KB) from L2/MALL each
-// step -- 56 MB per step chip-wide -- and pays a kernel boundary; the step ran at 32 us against 10 us
-// of MFMA time.  Here the W_hh slice lives in VGPRs for the whole sequence (192 registers per lane),
-// only h_{t-1} (98 KB per workgroup) moves per step, and the step boundary is a group barrier among
-// the 12 workgroups that share (cell, batch tile) -- different batch rows never interact.
+// Measured on MI355X (tools/bench_lstm.py, B=256, H=384, 4 cells): with one launch per step the
+// step takes 32 us against 12 us of MFMA time; an ablation showed the rest is latency that a
+// launch-per-step structure cannot hide -- 5.5 us of uncoalesced operand loads, ~10 us of
+// epilogue (x-projection loads, gate stores, store drain) and ~6 us of step boundary.  This kernel
+// keeps the W_hh slice in VGPRs for the whole sequence and software-pipelines two independent
+// 32-row half tiles per workgroup so every wait overlaps the other half's MFMA phase:
 //
-// Workgroup = (cell, 64 batch rows, 32 hidden units x 4 gates); its 4 waves split K = H four ways
-// (wave w: k in [w*H/4, (w+1)*H/4)), each lane half taking a contiguous H/8 run so A operands load as
-// float4.  Partial 64x128 tiles are summed through LDS, the cell update is fused, c stays in registers.
+//   workgroup = (cell, 64 batch rows, 32 hidden units x 4 gates), 4 waves splitting K four ways;
+//   per step and half:  wait(h_{t-1} of this half published by the 12 workgroups of the group)
+//                       -> coalesced h_{t-1} rows -> LDS -> per-lane MFMA operands
+//                       -> 192 MFMAs per wave -> partial tiles summed through LDS
+//                       -> fused cell update, 16-byte stores -> arrive(group counter).
 //
-// Cross-workgroup visibility follows the agent-scope release/acquire recipe of the CDNA guide
-// (Guideline 16): every storing wave drains vmcnt, workgroup barrier, lane 0 release fence + drain +
-// relaxed agent atomic add; consumer polls relaxed, then one acquire fence + drain + barrier, then
-// plain loads.  Every written 128-byte line is written whole by one workgroup.  Spins are bounded;
-// on timeout a sticky error word is set and all waits fall through.  Counters are zeroed by a
-// memset node in front of every launch.  The grid (<= 192 workgroups, 1 per CU) must be fully
-// resident: the host refuses the launch when the device has fewer CUs than workgroups.
+// Different batch rows never interact, so a "group" is the NJ = H/32 workgroups sharing
+// (cell, batch tile, half).  Visibility follows the CDNA guide's Guideline 16, form R1: the
+// handed-off payload (h_t forward, dgates_t backward) is stored write-through (sc1, 16 B per
+// lane, every 128-byte line written whole by one workgroup), every storing wave drains vmcnt,
+// workgroup barrier, ONE lane does a relaxed agent-scope atomic add; the consumer polls that
+// counter relaxed, then a workgroup barrier; every load of handed-off bytes is itself an sc1 load
+// (L1-bypassing), which replaces the acquire fence (guide: Valid forms, first table row).  Spins are bounded (sticky error word, all later waits fall through); counters are
+// zeroed by a memset node in front of every launch; the grid (<= 192 workgroups at one per CU)
+// must be co-resident, so the host refuses shapes that exceed the device's CU count.
 #include "gemm_engine.h"
 
 namespace {
 using namespace pe;
 
 constexpr int kMaxCells = 4;
-constexpr int kRs = 132;                 // padded row stride of the 64 x 128 partial tiles
-constexpr unsigned kSpinLimit = 4000000; // ~ seconds; a healthy wait is tens of microseconds
+constexpr int kRs = 132;                 // row stride of the 32 x 128 partial tiles (forward)
+constexpr int kRb = 36;                  // row stride of the 32 x 32 partial tiles (backward)
+constexpr unsigned kSpinLimit = 4000000; // a healthy wait is microseconds
 constexpr int kCtrStride = 32;           // one counter per 128-byte line
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct PFwdCells {
   const float* whh[kMaxCells];
@@ -45,17 +53,34 @@ struct PBwdCells {
 
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// Group barrier: `members` workgroups add 1 each; wait until the counter reaches `target`.
-__device__ __forceinline__ void group_barrier(unsigned* ctr, unsigned target, unsigned* err) {
+// 16-byte write-through (sc1) store: the data leaves for memory, no release fence needed later.
+__device__ __forceinline__ void store_sc1(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, float4 v) {
+  u32x4 d = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+  __builtin_amdgcn_raw_buffer_store_b128(d, rs, byte_off, 0, 16 /* sc1 */);
+}
+
+// arrive: all of this workgroup's payload stores are complete, then one relaxed agent-scope add
+__device__ __forceinline__ void group_arrive(unsigned* ctr) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave
   __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// 16-byte sc1 load of handed-off data: served by L2 / memory, never by this CU's (possibly stale) L1
+__device__ __forceinline__ float4 load_sc1(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+  const u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16 /* sc1 */);
+  return make_float4(__uint_as_float(d.x), __uint_as_float(d.y), __uint_as_float(d.z), __uint_as_float(d.w));
+}
+
+// wait: one lane polls the counter (an sc1 load) until the group has arrived, then the workgroup
+// barrier releases the other waves.  Every load of handed-off bytes in these kernels is an sc1 load and
+// every such byte was stored sc1 and drained before the producer's atomic add (guide, Valid forms,
+// first table row), so no L1 invalidate is needed; the wavefront-scope fence only pins compiler order.
+__device__ __forceinline__ void group_wait(unsigned* ctr, unsigned target, unsigned* err) {
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned spins = 0;
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_s_sleep(1);
       if ((++spins & 63u) == 0u) {
         if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
         if (spins > kSpinLimit) {
@@ -64,18 +89,22 @@ __device__ __forceinline__ void group_barrier(unsigned* ctr, unsigned target, un
         }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   __syncthreads();
 }
 
+// --------------------------------------------------------------------------------------- forward
 template <int H>
 __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_kernel(const PFwdCells cells, int B, int T, long ldy,
-                                                                     unsigned* sync) {
+                                                                     unsigned y_bytes, unsigned* sync) {
   constexpr int KQ = H / 4, KH = KQ / 2, NV = KH / 4, NJ = H / 32;
+  constexpr int ASTR = H + 4;                       // LDS row stride of the staged h rows
+  constexpr int ROW4 = H / 4;                       // float4 per row
   static_assert(H % 32 == 0, "hidden size is a multiple of 32");
-  extern __shared__ __attribute__((aligned(16))) float red[];          // [4][64][kRs]
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                                 // [32][ASTR]
+  float* red = smem + 32 * ASTR;                    // [4][32][kRs]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const int nbt = (B + 63) / 64;
@@ -86,9 +115,10 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_kernel(const PFwdC
   float* gates = cells.gates[cell];
   float* cb = cells.c[cell];
   unsigned* err = sync;
-  unsigned* ctr = sync + kCtrStride * (1 + cell * nbt + bt);
+  unsigned* ctr = sync + kCtrStride * (1 + (cell * nbt + bt) * 2);
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(y, 0, y_bytes, 0x00020000);
 
-  // W_hh slice of this wave / lane: rows {g*H + j0 + r}, k = wv*KQ + hh*KH + s, kept in registers
+  // W_hh slice of this wave / lane: rows {g*H + j0 + r}, k = wv*KQ + hh*KH + s
   float bw[4][KH];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
@@ -99,98 +129,153 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_kernel(const PFwdC
       bw[g][4 * v] = t4.x; bw[g][4 * v + 1] = t4.y; bw[g][4 * v + 2] = t4.z; bw[g][4 * v + 3] = t4.w;
     }
   }
-  const int jj = tid & 31, bgrp = tid >> 5;
-  float creg[8];
+  const int prow = tid >> 3, pq = tid & 7;          // cell-update item: row prow, hidden units j0 + 4 pq .. +3
+  float4 creg[2];
+  creg[0] = creg[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // Software pipeline over items (step, half): while item i runs its MFMAs, the h rows of item i+1
+  // (published a half-phase ago by the group) are already in flight into `stage`.
+  constexpr int NST = (32 * ROW4) / 256;
+  float4 stage[NST];
+  auto fetch = [&](int step_n, int hf_n) {            // wait for + load h_{t-1} rows of item (step_n, hf_n)
+    const int tn_ = rev ? T - 1 - step_n : step_n;
+    const int tpn = rev ? tn_ + 1 : tn_ - 1;
+    group_wait(ctr + kCtrStride * hf_n, (unsigned)(NJ * step_n), err);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) creg[i] = 0.f;
+    for (int v = 0; v < NST; ++v) {
+      const int idx = tid + 256 * v;
+      const int row = idx / ROW4, c4 = idx - row * ROW4;
+      stage[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (b0 + 32 * hf_n + row < B)
+        stage[v] = load_sc1(yrs, (unsigned)((((long)(b0 + 32 * hf_n + row) * T + tpn) * ldy + c4 * 4) * 4));
+    }
+  };
 
   for (int step = 0; step < T; ++step) {
     const int t = rev ? T - 1 - step : step;
-    const int tp = rev ? t + 1 : t - 1;
-    f32x16 acc[2][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int hf = 0; hf < 2; ++hf) {
+      const int rb0 = b0 + 32 * hf;
+      const int pb = rb0 + prow;
+      const long prow_i = (long)pb * T + t;
+      float4 xp[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        xp[g] = pb < B ? *reinterpret_cast<const float4*>(gates + prow_i * 4 * H + g * H + j0 + 4 * pq)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+      f32x16 acc[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc[i][g][q] = 0.f;
-    if (step > 0) {
-      float av[2][KH];
+        for (int q = 0; q < 16; ++q) acc[g][q] = 0.f;
+      if (step > 0) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = b0 + i * 32 + r;
-        const float* src = y + ((long)row * T + tp) * ldy + wv * KQ + hh * KH;
+        for (int v = 0; v < NST; ++v) {
+          const int idx = tid + 256 * v;
+          const int row = idx / ROW4, c4 = idx - row * ROW4;
+          *reinterpret_cast<float4*>(As + row * ASTR + c4 * 4) = stage[v];
+        }
+        __syncthreads();
+      }
+      // next item's operand rows: (step, 1) after (step, 0); (step + 1, 0) after (step, 1)
+      {
+        const int step_n = hf == 0 ? step : step + 1, hf_n = hf ^ 1;
+        if (step_n > 0 && step_n < T) fetch(step_n, hf_n);
+      }
+      if (step > 0) {
+        // operands come out of LDS in two chunks to keep the live register set small
+        constexpr int AC = (NV % 2 == 0) ? NV / 2 : NV;
+        const float* asrc = As + r * ASTR + wv * KQ + hh * KH;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-          float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (row < B) t4 = *reinterpret_cast<const float4*>(src + 4 * v);
-          av[i][4 * v] = t4.x; av[i][4 * v + 1] = t4.y; av[i][4 * v + 2] = t4.z; av[i][4 * v + 3] = t4.w;
+        for (int ch = 0; ch < NV / AC; ++ch) {
+          float av[4 * AC];
+#pragma unroll
+          for (int v = 0; v < AC; ++v) {
+            const float4 t4 = *reinterpret_cast<const float4*>(asrc + 4 * (ch * AC + v));
+            av[4 * v] = t4.x; av[4 * v + 1] = t4.y; av[4 * v + 2] = t4.z; av[4 * v + 3] = t4.w;
+          }
+#pragma unroll
+          for (int s = 0; s < 4 * AC; ++s)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = mfma32(av[s], bw[g][ch * 4 * AC + s], acc[g]);
         }
       }
-#pragma unroll
-      for (int s = 0; s < KH; ++s)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) acc[i][g] = mfma32(av[i][s], bw[g][s], acc[i][g]);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-          const int row = i * 32 + (q & 3) + 8 * (q >> 2) + 4 * hh;
-          red[(wv * 64 + row) * kRs + g * 32 + r] = acc[i][g][q];
+          const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
+          red[(wv * 32 + row) * kRs + g * 32 + r] = acc[g][q];
         }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int bl_ = bgrp + 8 * i;
-      const int b = b0 + bl_;
-      if (b < B) {
-        const long rowi = (long)b * T + t;
-        float* gp = gates + rowi * 4 * H + j0 + jj;
-        float pre[4];
+      __syncthreads();
+      if (pb < B) {
+        float4 pre[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const float* rp = red + bl_ * kRs + g * 32 + jj;
-          pre[g] = ((rp[0] + rp[64 * kRs]) + (rp[2 * 64 * kRs] + rp[3 * 64 * kRs])) + gp[g * H];
+          const float* rp = red + prow * kRs + g * 32 + 4 * pq;
+          const float4 p0 = *reinterpret_cast<const float4*>(rp);
+          const float4 p1 = *reinterpret_cast<const float4*>(rp + 32 * kRs);
+          const float4 p2 = *reinterpret_cast<const float4*>(rp + 2 * 32 * kRs);
+          const float4 p3 = *reinterpret_cast<const float4*>(rp + 3 * 32 * kRs);
+          pre[g].x = ((p0.x + p1.x) + (p2.x + p3.x)) + xp[g].x;
+          pre[g].y = ((p0.y + p1.y) + (p2.y + p3.y)) + xp[g].y;
+          pre[g].z = ((p0.z + p1.z) + (p2.z + p3.z)) + xp[g].z;
+          pre[g].w = ((p0.w + p1.w) + (p2.w + p3.w)) + xp[g].w;
         }
-        const float gi = sigm(pre[0]), gf = sigm(pre[1]), gg = tanhf(pre[2]), go = sigm(pre[3]);
-        const float cn = gf * creg[i] + gi * gg;
-        creg[i] = cn;
-        gp[0] = gi; gp[H] = gf; gp[2 * H] = gg; gp[3 * H] = go;
-        cb[rowi * H + j0 + jj] = cn;
-        y[rowi * ldy + j0 + jj] = go * tanhf(cn);
+        const float4 gi = make_float4(sigm(pre[0].x), sigm(pre[0].y), sigm(pre[0].z), sigm(pre[0].w));
+        const float4 gf = make_float4(sigm(pre[1].x), sigm(pre[1].y), sigm(pre[1].z), sigm(pre[1].w));
+        const float4 gg = make_float4(tanhf(pre[2].x), tanhf(pre[2].y), tanhf(pre[2].z), tanhf(pre[2].w));
+        const float4 go = make_float4(sigm(pre[3].x), sigm(pre[3].y), sigm(pre[3].z), sigm(pre[3].w));
+        float4 cn;
+        cn.x = gf.x * creg[hf].x + gi.x * gg.x;
+        cn.y = gf.y * creg[hf].y + gi.y * gg.y;
+        cn.z = gf.z * creg[hf].z + gi.z * gg.z;
+        cn.w = gf.w * creg[hf].w + gi.w * gg.w;
+        creg[hf] = cn;
+        const float4 hv = make_float4(go.x * tanhf(cn.x), go.y * tanhf(cn.y), go.z * tanhf(cn.z), go.w * tanhf(cn.w));
+        // h_t first and write-through: it is what the other workgroups wait for
+        store_sc1(yrs, (unsigned)((prow_i * ldy + j0 + 4 * pq) * 4), hv);
+        float* gp = gates + prow_i * 4 * H + j0 + 4 * pq;
+        *reinterpret_cast<float4*>(gp) = gi;
+        *reinterpret_cast<float4*>(gp + H) = gf;
+        *reinterpret_cast<float4*>(gp + 2 * H) = gg;
+        *reinterpret_cast<float4*>(gp + 3 * H) = go;
+        *reinterpret_cast<float4*>(cb + prow_i * H + j0 + 4 * pq) = cn;
       }
+      group_arrive(ctr + kCtrStride * hf);          // (its barrier also frees As / red for the next item)
     }
-    if (step + 1 < T) group_barrier(ctr, (unsigned)(NJ * (step + 1)), err);
   }
 }
 
-// Backward: dh_t = dY_t + dgates_{t+1} . W_hh  (K = 4H: wave w owns gate block w, lane halves take
-// H/2 contiguous k each, streamed in chunks of CH).  W_hh^T slice (rows j0 + r) stays in registers.
+// --------------------------------------------------------------------------------------- backward
+// dh_t = dY_t + dgates_{t+1} . W_hh  (K = 4H: wave w owns gate block w; each lane half takes H/2
+// contiguous k, streamed through LDS in chunks of CH per lane).  W_hh^T rows j0 + r stay in registers.
 template <int H>
 __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_kernel(const PBwdCells cells, int B, int T, long lddy,
-                                                                     unsigned* sync) {
-  constexpr int KH = H / 2, NJ = H / 32;
-  constexpr int CH = (KH % 48 == 0) ? 48 : 16;           // A-operand chunk (values per lane per row tile)
+                                                                     unsigned g_bytes, unsigned* sync) {
+  constexpr int KH = H / 2, NJ = H / 32, K = 4 * H;
+  constexpr int CH = (KH % 48 == 0) ? 48 : 16;      // k per lane per chunk
   constexpr int NCH = KH / CH;
-  static_assert(KH % CH == 0, "chunking");
-  extern __shared__ __attribute__((aligned(16))) float red[];          // [4][64][33]
+  constexpr int CW = 8 * CH;                        // staged floats per row per chunk (4 waves x 2 halves)
+  constexpr int ASTR = CW + 4;
+  constexpr int ROW4 = CW / 4;
+  constexpr int NLD = (32 * ROW4) / 256;            // float4 per thread per chunk
+  static_assert(KH % CH == 0 && (32 * ROW4) % 256 == 0, "chunking");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As0 = smem;                                // [2][32][ASTR]
+  float* red = smem + 2 * 32 * ASTR;                // [4][32][kRb]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const int nbt = (B + 63) / 64;
   const int jt = blockIdx.x % NJ, bt = (blockIdx.x / NJ) % nbt, cell = blockIdx.x / (NJ * nbt);
   const int j0 = jt * 32, b0 = bt * 64;
   const int rev = cells.reverse[cell];
-  const int K = 4 * H;
   float* gates = cells.gates[cell];
   const float* cb = cells.c[cell];
   const float* dy = cells.dy[cell];
   unsigned* err = sync;
-  unsigned* ctr = sync + kCtrStride * (1 + cell * nbt + bt);
+  unsigned* ctr = sync + kCtrStride * (1 + (cell * nbt + bt) * 2);
+  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(gates, 0, g_bytes, 0x00020000);
 
   float bw[KH];
   {
@@ -201,72 +286,137 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_kernel(const PBwdC
       bw[4 * v] = t4.x; bw[4 * v + 1] = t4.y; bw[4 * v + 2] = t4.z; bw[4 * v + 3] = t4.w;
     }
   }
-  const int jj = tid & 31, bgrp = tid >> 5;
-  float dcar[8];
+  const int prow = tid >> 3, pq = tid & 7;
+  float4 dcar[2];
+  dcar[0] = dcar[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // staged column c of a chunk <-> global k:  seg = c / CH = wave*2 + half,
+  //                                           k = (seg >> 1)*H + (seg & 1)*KH + chunk*CH + c % CH
+  // `stage` always holds the chunk that is committed next; across items it carries chunk 0 of the
+  // next (step, half), fetched behind that item's group wait while this item still computes.
+  float4 stage[NLD];
+  auto load_chunk = [&](int rb0_, int tn_, int c) {
+    int tid_o = tid;
+    asm volatile("" : "+v"(tid_o));                   // keep the address math inside the loop (no hoist + spill)
 #pragma unroll
-  for (int i = 0; i < 8; ++i) dcar[i] = 0.f;
+    for (int v = 0; v < NLD; ++v) {
+      const int idx = tid_o + 256 * v;
+      const int row = idx / ROW4, c4 = idx - row * ROW4;
+      const int seg = (c4 * 4) / CH, e = c4 * 4 - seg * CH;
+      const int k = (seg >> 1) * H + (seg & 1) * KH + c * CH + e;
+      stage[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (rb0_ + row < B) stage[v] = load_sc1(grs, (unsigned)((((long)(rb0_ + row) * T + tn_) * K + k) * 4));
+    }
+  };
+  auto fetch_next = [&](int step, int hf) {          // (step, 0) -> (step, 1) -> (step + 1, 0)
+    const int step_n = hf == 0 ? step : step + 1, hf_n = hf ^ 1;
+    if (step_n > 0 && step_n < T) {
+      const int t_n = rev ? step_n : T - 1 - step_n;
+      group_wait(ctr + kCtrStride * hf_n, (unsigned)(NJ * step_n), err);
+      load_chunk(b0 + 32 * hf_n, rev ? t_n - 1 : t_n + 1, 0);
+    }
+  };
 
   for (int step = 0; step < T; ++step) {
     const int t = rev ? step : T - 1 - step;
     const int tn = rev ? t - 1 : t + 1;
     const int tp = rev ? t + 1 : t - 1;
-    f32x16 acc[2];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) { acc[0][q] = 0.f; acc[1][q] = 0.f; }
-    if (step > 0) {
+    for (int hf = 0; hf < 2; ++hf) {
+      const int rb0 = b0 + 32 * hf;
+      const int pb = rb0 + prow;
+      const long prow_i = (long)pb * T + t;
+      const int j = j0 + 4 * pq;
+      // inputs of the gate-gradient update, issued before the MFMA phase
+      float4 in_dy = make_float4(0.f, 0.f, 0.f, 0.f), in_c = in_dy, in_cp = in_dy;
+      float4 in_g[4];
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        float av[2][CH];
+      for (int g = 0; g < 4; ++g) in_g[g] = in_dy;
+      const bool has_prev = rev ? (tp < T) : (tp >= 0);
+      if (pb < B) {
+        in_dy = *reinterpret_cast<const float4*>(dy + prow_i * lddy + j);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int row = b0 + i * 32 + r;
-          const float* src = gates + ((long)row * T + tn) * K + wv * H + hh * KH + c * CH;
+        for (int g = 0; g < 4; ++g) in_g[g] = *reinterpret_cast<const float4*>(gates + prow_i * K + g * H + j);
+        in_c = *reinterpret_cast<const float4*>(cb + prow_i * H + j);
+        if (has_prev) in_cp = *reinterpret_cast<const float4*>(cb + ((long)pb * T + tp) * H + j);
+      }
+      f32x16 acc;
 #pragma unroll
-          for (int v = 0; v < CH / 4; ++v) {
-            float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < B) t4 = *reinterpret_cast<const float4*>(src + 4 * v);
-            av[i][4 * v] = t4.x; av[i][4 * v + 1] = t4.y; av[i][4 * v + 2] = t4.z; av[i][4 * v + 3] = t4.w;
+      for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+      if (step > 0) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          float* cur = As0 + (c & 1) * 32 * ASTR;
+          int tid_c = tid;
+          asm volatile("" : "+v"(tid_c));
+#pragma unroll
+          for (int v = 0; v < NLD; ++v) {
+            const int idx = tid_c + 256 * v;
+            const int row = idx / ROW4, c4 = idx - row * ROW4;
+            *reinterpret_cast<float4*>(cur + row * ASTR + c4 * 4) = stage[v];
+          }
+          __syncthreads();
+          if (c + 1 < NCH) load_chunk(rb0, tn, c + 1);
+          else fetch_next(step, hf);
+          constexpr int AC = (CH / 4) % 2 == 0 ? CH / 8 : CH / 4;     // float4 per operand sub-chunk
+          const float* asrc = cur + r * ASTR + (wv * 2 + hh) * CH;
+#pragma unroll
+          for (int sc = 0; sc < (CH / 4) / AC; ++sc) {
+            float av[4 * AC];
+#pragma unroll
+            for (int v = 0; v < AC; ++v) {
+              const float4 t4 = *reinterpret_cast<const float4*>(asrc + 4 * (sc * AC + v));
+              av[4 * v] = t4.x; av[4 * v + 1] = t4.y; av[4 * v + 2] = t4.z; av[4 * v + 3] = t4.w;
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 4 * AC; ++s2) acc = mfma32(av[s2], bw[c * CH + sc * 4 * AC + s2], acc);
           }
         }
-#pragma unroll
-        for (int s = 0; s < CH; ++s) {
-          acc[0] = mfma32(av[0][s], bw[c * CH + s], acc[0]);
-          acc[1] = mfma32(av[1][s], bw[c * CH + s], acc[1]);
-        }
+      } else {
+        fetch_next(step, hf);
       }
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const int row = i * 32 + (q & 3) + 8 * (q >> 2) + 4 * hh;
-        red[(wv * 64 + row) * 33 + r] = acc[i][q];
+        const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
+        red[(wv * 32 + row) * kRb + r] = acc[q];
       }
-    __syncthreads();
+      __syncthreads();
+      if (pb < B) {
+        const float* rp = red + prow * kRb + 4 * pq;
+        const float4 p0 = *reinterpret_cast<const float4*>(rp);
+        const float4 p1 = *reinterpret_cast<const float4*>(rp + 32 * kRb);
+        const float4 p2 = *reinterpret_cast<const float4*>(rp + 2 * 32 * kRb);
+        const float4 p3 = *reinterpret_cast<const float4*>(rp + 3 * 32 * kRb);
+        const float dhv[4] = {in_dy.x + ((p0.x + p1.x) + (p2.x + p3.x)), in_dy.y + ((p0.y + p1.y) + (p2.y + p3.y)),
+                              in_dy.z + ((p0.z + p1.z) + (p2.z + p3.z)), in_dy.w + ((p0.w + p1.w) + (p2.w + p3.w))};
+        const float gi[4] = {in_g[0].x, in_g[0].y, in_g[0].z, in_g[0].w};
+        const float gf[4] = {in_g[1].x, in_g[1].y, in_g[1].z, in_g[1].w};
+        const float gg[4] = {in_g[2].x, in_g[2].y, in_g[2].z, in_g[2].w};
+        const float go[4] = {in_g[3].x, in_g[3].y, in_g[3].z, in_g[3].w};
+        const float cn[4] = {in_c.x, in_c.y, in_c.z, in_c.w};
+        const float cp[4] = {in_cp.x, in_cp.y, in_cp.z, in_cp.w};
+        float dcv[4] = {dcar[hf].x, dcar[hf].y, dcar[hf].z, dcar[hf].w};
+        float oi[4], of[4], og[4], oo[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int bl_ = bgrp + 8 * i;
-      const int b = b0 + bl_;
-      if (b < B) {
-        const long rowi = (long)b * T + t;
-        const int j = j0 + jj;
-        const float* rp = red + bl_ * 33 + jj;
-        const float dh = dy[rowi * lddy + j] + ((rp[0] + rp[64 * 33]) + (rp[2 * 64 * 33] + rp[3 * 64 * 33]));
-        float* gp = gates + rowi * K + j;
-        const float gi = gp[0], gf = gp[H], gg = gp[2 * H], go = gp[3 * H];
-        const float cn = cb[rowi * H + j];
-        const bool has_prev = rev ? (tp < T) : (tp >= 0);
-        const float cprev = has_prev ? cb[((long)b * T + tp) * H + j] : 0.f;
-        const float tc = tanhf(cn);
-        const float dc = dh * go * (1.f - tc * tc) + dcar[i];
-        gp[0] = dc * gg * gi * (1.f - gi);
-        gp[H] = dc * cprev * gf * (1.f - gf);
-        gp[2 * H] = dc * gi * (1.f - gg * gg);
-        gp[3 * H] = dh * tc * go * (1.f - go);
-        dcar[i] = dc * gf;
+        for (int e = 0; e < 4; ++e) {
+          const float tc = tanhf(cn[e]);
+          const float dc = dhv[e] * go[e] * (1.f - tc * tc) + dcv[e];
+          oi[e] = dc * gg[e] * gi[e] * (1.f - gi[e]);
+          of[e] = dc * cp[e] * gf[e] * (1.f - gf[e]);
+          og[e] = dc * gi[e] * (1.f - gg[e] * gg[e]);
+          oo[e] = dhv[e] * tc * go[e] * (1.f - go[e]);
+          dcv[e] = dc * gf[e];
+        }
+        dcar[hf] = make_float4(dcv[0], dcv[1], dcv[2], dcv[3]);
+        // dgates_t feed the next step of every workgroup in the group: write-through
+        const unsigned off = (unsigned)((prow_i * K + j) * 4);
+        store_sc1(grs, off, make_float4(oi[0], oi[1], oi[2], oi[3]));
+        store_sc1(grs, off + (unsigned)(H * 4), make_float4(of[0], of[1], of[2], of[3]));
+        store_sc1(grs, off + (unsigned)(2 * H * 4), make_float4(og[0], og[1], og[2], og[3]));
+        store_sc1(grs, off + (unsigned)(3 * H * 4), make_float4(oo[0], oo[1], oo[2], oo[3]));
       }
+      group_arrive(ctr + kCtrStride * hf);
     }
-    if (step + 1 < T) group_barrier(ctr, (unsigned)(NJ * (step + 1)), err);
   }
 }
 
@@ -281,30 +431,47 @@ int device_cus() {
   return cus;
 }
 
-constexpr size_t kFwdLds = (size_t)4 * 64 * kRs * sizeof(float);
-constexpr size_t kBwdLds = (size_t)4 * 64 * 33 * sizeof(float);
+template <int H>
+constexpr size_t fwd_lds() { return (size_t)(32 * (H + 4) + 4 * 32 * kRs) * sizeof(float); }
+
+template <int H>
+constexpr size_t bwd_lds() {
+  constexpr int KH = H / 2;
+  constexpr int CH = (KH % 48 == 0) ? 48 : 16;
+  return (size_t)(2 * 32 * (8 * CH + 4) + 4 * 32 * kRb) * sizeof(float);
+}
 
 template <int H>
 int launch_fwd(const PFwdCells& cells, int grid, int B, int T, long ldy, unsigned* sync, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
     PE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_persistent_kernel<H>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLds));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds<H>()));
     attr = true;
   }
-  hipLaunchKernelGGL(lstm_fwd_persistent_kernel<H>, dim3(grid), dim3(256), kFwdLds, st, cells, B, T, ldy, sync);
+  const unsigned y_bytes = (unsigned)((size_t)B * T * ldy * sizeof(float));
+  hipLaunchKernelGGL(lstm_fwd_persistent_kernel<H>, dim3(grid), dim3(256), fwd_lds<H>(), st, cells, B, T, ldy, y_bytes,
+                     sync);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }
 
 template <int H>
 int launch_bwd(const PBwdCells& cells, int grid, int B, int T, long lddy, unsigned* sync, hipStream_t st) {
-  hipLaunchKernelGGL(lstm_bwd_persistent_kernel<H>, dim3(grid), dim3(256), kBwdLds, st, cells, B, T, lddy, sync);
+  static bool attr = false;
+  if (!attr) {
+    PE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_persistent_kernel<H>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds<H>()));
+    attr = true;
+  }
+  const unsigned g_bytes = (unsigned)((size_t)B * T * 4 * H * sizeof(float));
+  hipLaunchKernelGGL(lstm_bwd_persistent_kernel<H>, dim3(grid), dim3(256), bwd_lds<H>(), st, cells, B, T, lddy,
+                     g_bytes, sync);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }
 
-int sync_words(int ncells, int B) { return kCtrStride * (1 + ncells * ((B + 63) / 64)); }
+int sync_words(int ncells, int B) { return kCtrStride * (1 + 2 * ncells * ((B + 63) / 64)); }
 
 }  // namespace
 
@@ -312,8 +479,8 @@ extern "C" size_t pe_lstm_persistent_sync_bytes(int ncells, int B) {
   return (size_t)sync_words(ncells, B) * sizeof(unsigned);
 }
 
-// 1 if the persistent kernels can run this shape on the current device (hidden size instantiated and
-// the whole grid co-resident at one workgroup per CU), else 0.
+// 1 if the persistent kernels can run this shape on the current device (hidden size instantiated,
+// and the whole grid is co-resident at one workgroup per CU), else 0.
 extern "C" int pe_lstm_persistent_supported(int ncells, int B, int H) {
   if (ncells < 1 || ncells > kMaxCells || B <= 0) return 0;
   if (!(H == 32 || H == 64 || H == 96 || H == 384)) return 0;
@@ -326,6 +493,7 @@ extern "C" int pe_lstm_fwd_persistent(int ncells, const float* const* whh, float
                                       unsigned* sync, void* stream) {
   if (!whh || !gates || !y || !cbuf || !reverse || !sync || T <= 0) return PE_E_ARG;
   if (!pe_lstm_persistent_supported(ncells, B, H) || (ldy & 3)) return PE_E_UNSUPPORTED;
+  if ((size_t)B * T * ldy * sizeof(float) >= (1ull << 32)) return PE_E_UNSUPPORTED;      // 32-bit buffer offsets
   PFwdCells cells{};
   for (int i = 0; i < ncells; ++i) {
     if (!whh[i] || !gates[i] || !y[i] || !cbuf[i]) return PE_E_ARG;
@@ -350,6 +518,7 @@ extern "C" int pe_lstm_bwd_persistent(int ncells, const float* const* whh_t, flo
                                       long lddy, int B, int T, int H, unsigned* sync, void* stream) {
   if (!whh_t || !gates || !cbuf || !dy || !reverse || !sync || T <= 0) return PE_E_ARG;
   if (!pe_lstm_persistent_supported(ncells, B, H) || (lddy & 3)) return PE_E_UNSUPPORTED;
+  if ((size_t)B * T * 4 * H * sizeof(float) >= (1ull << 32)) return PE_E_UNSUPPORTED;
   PBwdCells cells{};
   for (int i = 0; i < ncells; ++i) {
     if (!whh_t[i] || !gates[i] || !cbuf[i] || !dy[i]) return PE_E_ARG;
