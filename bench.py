@@ -51,6 +51,16 @@ def host_cores():
     return max(1, min(n, 32))
 
 
+def pmc_traffic():
+    """HBM bytes per conv3x3_kernel launch from the committed rocprofv3 --pmc passes (separate runs of
+    this same command; FETCH_SIZE doubled per the gfx950 correction) -- None when absent."""
+    try:
+        d = json.loads((ROOT / "profiles" / "pmc_r01_traffic.json").read_text())
+        return d["conv3x3_kernel_all_tiles"]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(n_steps=3, batch=4):
     """Reference-equivalent fp32 CPU trainer (oracle port) on a bounded sample, host cores stated."""
     from oracle import mel_ref, model_ref, train_ref
@@ -118,6 +128,7 @@ def main():
     if world > 1:
         buffers = [b for b in net.buffers() if b.dtype.is_floating_point]
         dp = pdist.GradientAllReduce(net.flat_gradients(), opt, flat_param=net.flat_parameters, buffers=buffers)
+        net.attach_data_parallel(dp)            # buckets go out as backward finalises them
     crit = {"l1": torch.nn.SmoothL1Loss(), "ce": torch.nn.BCEWithLogitsLoss()}
     log = logging.getLogger("bench")
     tr = Trainer(model=net, criterion=crit, optimizer=opt, scheduler=sched, device=str(dev),
@@ -171,7 +182,7 @@ def main():
             tflops = conv["work"] / (conv["total_ms"] * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "conv3x3_kernel (implicit-GEMM fwd + dgrad launches)",
                     "achieved": tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": tflops / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                    "frac": tflops / MFMA_F32_PEAK_TFLOPS, "traffic": pmc_traffic(),
                     "avg_launch_ms": conv["avg_ms"], "launches_per_step": conv["calls"] / args.steps}
         families = {k: {"ms_per_step": v["total_ms"] / args.steps,
                         "tflops": (v["work"] / (v["total_ms"] * 1e-3) / 1e12) if v["work"] else None}

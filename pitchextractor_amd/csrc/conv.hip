@@ -83,12 +83,20 @@ int launch_conv(const float* x, const float* wp, float* y, int B, int T, int F, 
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             float* __restrict__ ws, int T, int F, int Cin,
-                                                            int Cout, int P, int k_per_split, int tiles_n) {
+                                                            int Cout, int P, int k_per_split, int tiles_n,
+                                                            int n_tiles, int n_chunks) {
   __shared__ __attribute__((aligned(16))) float As[kBK * BM];
   __shared__ __attribute__((aligned(16))) float Bs[kBK * BN];
-  const int tap = blockIdx.z;
-  const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
-  const int kb = blockIdx.y * k_per_split;
+  // Block order: workgroups b and b+8 share an XCD (its L2).  The 9 taps of one (tile, pixel chunk)
+  // are made consecutive workgroups of ONE XCD, so they stream the same dY / X lines at the same time
+  // and HBM sees them once instead of 9 times (PMC: 17 GB -> per launch before this ordering).
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int tap = q % 9;
+  const int chunk = (q / 9) * 8 + xcd;
+  if (chunk >= n_chunks) return;
+  const int tile = chunk % n_tiles, split = chunk / n_tiles;
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  const int kb = split * k_per_split;
   const int ke = min(P, kb + k_per_split);
   KRowLoader<BM> al{dy, (long)Cout, Cout, 0};
   ShiftedPixelLoader<BN> bl;
@@ -104,7 +112,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restr
       for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
   tn_mainloop<BM, BN>(al, bl, kb, ke, As, Bs, acc);
   // slab layout: [split][tap][Cout][Cin]
-  float* dst = ws + ((long)blockIdx.y * 9 + tap) * Cout * Cin;
+  float* dst = ws + ((long)split * 9 + tap) * Cout * Cin;
   tn_for_each_acc<BM, BN>(acc, [&](int r, int c, float v) {
     const int co = m0 + r, ci = n0 + c;
     if (co < Cout && ci < Cin) dst[(long)co * Cin + ci] = v;
@@ -141,8 +149,10 @@ int launch_wgrad(const float* x, const float* dy, float* dw, float* ws, int B, i
                  int splits, int kps, hipStream_t st) {
   const int P = B * T * F;
   const int tm = pe_cdiv(Cout, BM), tn = pe_cdiv(Cin, BN);
-  hipLaunchKernelGGL((conv3x3_wgrad_kernel<BM, BN>), dim3(tm * tn, splits, 9), dim3(256), 0, st, dy, x, ws, T, F,
-                     Cin, Cout, P, kps, tn);
+  const int n_tiles = tm * tn, n_chunks = n_tiles * splits;
+  const int grid = 8 * 9 * pe_cdiv(n_chunks, 8);
+  hipLaunchKernelGGL((conv3x3_wgrad_kernel<BM, BN>), dim3(grid), dim3(256), 0, st, dy, x, ws, T, F, Cin, Cout, P, kps,
+                     tn, n_tiles, n_chunks);
   PE_LAUNCH_CHECK();
   const int n = 9 * Cout * Cin;
   hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(pe_cdiv(n, 256)), dim3(256), 0, st, ws, dw, splits, Cout,

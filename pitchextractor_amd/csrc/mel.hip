@@ -76,6 +76,16 @@ __device__ __forceinline__ void fft8(float2 (&v)[8]) {
   fft4(d0, d1, d2, d3, v[1], v[3], v[5], v[7]);
 }
 
+// The 4 waves of a workgroup share only read-only LDS (audio chunk, filterbank); the exchange
+// regions A/B/P are private to a wave, and one wave's DS instructions execute in program order, so
+// the passes below need no s_barrier -- only a compiler fence that keeps LDS writes ahead of the
+// dependent LDS reads (waves then drift freely instead of marching in lockstep).
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int FB>
 __global__ __launch_bounds__(256) void mel_fwd_kernel(const MelArgs a) {
   static_assert(FB % 4 == 0, "FB frames are dealt to 4 waves");
@@ -101,11 +111,17 @@ __global__ __launch_bounds__(256) void mel_fwd_kernel(const MelArgs a) {
     const float* wsrc = a.wave + (long)b * a.wave_stride;
     const long base = (long)f0 * hop - kHalf;
     const long N = n_samples;
-    for (int j = tid; j < a.audio_len; j += 256) {
-      long g = base + j;
-      if (g < 0) g = -g;
-      if (g >= N) g = 2 * (N - 1) - g;
-      s_audio[j] = (g >= 0 && g < N) ? wsrc[g] : 0.0f;
+    if (base >= 0 && base + a.audio_len <= N && ((base & 3) == 0) && ((a.wave_stride & 3) == 0)) {
+      // interior block: straight 16-byte copies
+      for (int j = tid * 4; j < a.audio_len; j += 1024)
+        *reinterpret_cast<float4*>(s_audio + j) = *reinterpret_cast<const float4*>(wsrc + base + j);
+    } else {
+      for (int j = tid; j < a.audio_len; j += 256) {
+        long g = base + j;
+        if (g < 0) g = -g;
+        if (g >= N) g = 2 * (N - 1) - g;
+        s_audio[j] = (g >= 0 && g < N) ? wsrc[g] : 0.0f;
+      }
     }
     for (int j = tid; j < a.nnz; j += 256) s_fbw[j] = a.fb_w[j];
     for (int j = tid; j < n_mels; j += 256) {
@@ -148,7 +164,7 @@ __global__ __launch_bounds__(256) void mel_fwd_kernel(const MelArgs a) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) A[r * 72 + lane] = (r == 0) ? v[0] : cmul(v[r], tw1[r]);
       }
-      __syncthreads();
+      wave_lds_sync();
       if (valid) {
         // pass 2: lane = 8*k0 + c, radix-8 over b
         const int k0 = lane >> 3;
@@ -158,7 +174,7 @@ __global__ __launch_bounds__(256) void mel_fwd_kernel(const MelArgs a) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) B[(k0 + 8 * r) * 9 + c_] = (r == 0) ? v[0] : cmul(v[r], tw2[r]);
       }
-      __syncthreads();
+      wave_lds_sync();
       if (valid) {
         // pass 3: lane = k0 + 8*k1, radix-8 over c -> Z[lane + 64*k2]
 #pragma unroll
@@ -167,7 +183,7 @@ __global__ __launch_bounds__(256) void mel_fwd_kernel(const MelArgs a) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) A[lane + 64 * r] = v[r];
       }
-      __syncthreads();
+      wave_lds_sync();
       if (valid) {
         // real-FFT split: X[k] = E + W^k O, X[512-k] = conj(E - W^k O); keep powers
 #pragma unroll
@@ -186,7 +202,7 @@ __global__ __launch_bounds__(256) void mel_fwd_kernel(const MelArgs a) {
           P[256] = z.x * z.x + z.y * z.y;
         }
       }
-      __syncthreads();
+      wave_lds_sync();
       if (valid) {
         for (int m = lane; m < n_mels; m += 64) {
           const int st = s_fbi[m], ln = s_fbi[n_mels + m];

@@ -56,8 +56,10 @@ class GradientAllReduce:
         self.flat_grad = flat_grad
         n = flat_grad.numel()
         per = max(1, bucket_bytes // 4)
+        self.bucket_elems = per
         self.buckets = [(lo, min(n, lo + per)) for lo in range(0, n, per)]
         self._pending = []
+        self._issued = False
         self._stream = torch.cuda.Stream(device=flat_grad.device) if flat_grad.is_cuda else None
         if optimizer is not None:
             optimizer.grad_scale = 1.0 / self.world
@@ -68,26 +70,31 @@ class GradientAllReduce:
                 dist.broadcast(b, src=0, group=group)
 
     def reduce_range(self, lo: int, hi: int):
-        """Start reducing gradient elements [lo, hi) (they must be final)."""
-        if self.world == 1:
+        """Start reducing gradient elements [lo, hi) (they must be final), in bucket-sized messages."""
+        if self.world == 1 or hi <= lo:
             return
-        chunk = self.flat_grad[lo:hi]
+        self._issued = True
         if self._stream is not None:
             self._stream.wait_stream(torch.cuda.current_stream(self.flat_grad.device))
-            with torch.cuda.stream(self._stream):
+        per = max(1, self.bucket_elems)
+        for a in range(lo, hi, per):
+            chunk = self.flat_grad[a:min(hi, a + per)]
+            if self._stream is not None:
+                with torch.cuda.stream(self._stream):
+                    self._pending.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group,
+                                                         async_op=True))
+            else:
                 self._pending.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        else:
-            self._pending.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
         """Reduce whatever has not been issued yet and make the compute stream wait for all of it."""
         if self.world == 1:
             return
-        if not self._pending:
-            for lo, hi in self.buckets:
-                self.reduce_range(lo, hi)
+        if not self._issued:
+            self.reduce_range(0, self.flat_grad.numel())
         for w in self._pending:
             w.wait()
         self._pending = []
+        self._issued = False
         if self._stream is not None:
             torch.cuda.current_stream(self.flat_grad.device).wait_stream(self._stream)

@@ -465,6 +465,7 @@ class JDCNet(nn.Module):
         self.block_dropout = 0.5                                       # model.py:40,56
         self.dropout_cfg = _DropoutCfg()
         self.training_graph_wanted = True
+        self._dp = None
         self.keep_last_context = False      # tests: expose the saved tensors (dropout masks) of the last forward
         self.last_context = None
         self._init_weights()
@@ -519,6 +520,17 @@ class JDCNet(nn.Module):
     def load_state_dict(self, state_dict, strict=True, assign=False):
         res = super().load_state_dict(state_dict, strict=strict, assign=False)
         return res
+
+    def attach_data_parallel(self, dp):
+        """``dp``: pitchextractor_amd.distributed.GradientAllReduce over ``flat_gradients()``.  Backward then
+        hands it gradient ranges as they become final: [sequence models .. heads] (93 % of the bytes)
+        right after the temporal-head backward, so that all-reduce runs on its own stream underneath the
+        whole convolution backward; the convolution stack's range follows at the end."""
+        self._dp = dp
+
+    def _seq_offset(self):
+        first = next(self.sequence_classifier.parameters())
+        return self._param_offsets[id(first)]
 
     @property
     def flat_parameters(self) -> torch.Tensor:
@@ -635,6 +647,9 @@ class JDCNet(nn.Module):
             dseq_d = _tf_backward(models[1], s.tf_d, dyd.view(B, T, D), g)
             dseq_c = _tf_backward(models[0], s.tf_c, dyc.view(B, T, D), g)
 
+        if self._dp is not None:            # temporal heads + output heads are final: start their all-reduce
+            self._dp.reduce_range(self._seq_offset(), self._grad_flat.numel())
+
         # detector branch (model.py:103-112)
         p_blk = self.block_dropout
         d_ddrop = torch.empty((B, T, 2, 256), dtype=torch.float32, device=dev)
@@ -665,6 +680,5 @@ class JDCNet(nn.Module):
         d_a0 = ops.conv3x3_fwd(d_cb, s.wd_cb)
         d_y0 = ops.bn_act_pool_bwd(s.y0, d_a0, s.bn0, g[cbk[1].weight], g[cbk[1].bias], pool=1, slope=slope, dx=d_a0)
         ops.conv3x3_c1_wgrad(s.x_btf, d_y0, g[cbk[0].weight])
-        hook = getattr(self, "_grads_ready_hook", None)
-        if hook is not None:
-            hook()
+        if self._dp is not None:
+            self._dp.reduce_range(0, self._seq_offset())

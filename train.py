@@ -114,6 +114,7 @@ def main(config_path):
         buffers = [b for b in model.buffers() if b.dtype.is_floating_point]
         dp = pdist.GradientAllReduce(model.flat_gradients(), optimizer, flat_param=model.flat_parameters,
                                      buffers=buffers)
+        model.attach_data_parallel(dp)
     trainer = Trainer(model=model, criterion=criterion, optimizer=optimizer, scheduler=scheduler, device=device,
                       train_dataloader=train_dataloader, val_dataloader=val_dataloader,
                       loss_config=config["loss_params"], logger=logger,
