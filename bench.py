@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="utterances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--head", choices=["bilstm", "transformer"], default="bilstm",
+                    help="temporal head (default: the reference's default BiLSTM = BASELINE config[1])")
     args = ap.parse_args()
 
     from pitchextractor_amd import distributed as pdist
@@ -119,7 +121,7 @@ def main():
     torch.cuda.set_device(dev)
 
     torch.manual_seed(1234)                      # same random-init weights on every rank
-    net = JDCNet(num_class=1, sequence_model_config=dict(SEQ_CFG)).to(dev).train()
+    net = JDCNet(num_class=1, sequence_model_config=dict(SEQ_CFG, model_type=args.head)).to(dev).train()
     net.dropout_cfg.seed = 1000 + rank
     opt, sched = build_optimizer({"params": net.parameters(), "optimizer_params": {},
                                   "scheduler_params": {"max_lr": 3e-4, "pct_start": 0.0, "epochs": 100,
@@ -193,13 +195,13 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE config[1]: batch=256/GPU, 24 kHz 2 s synthetic glides "
-                                   "(161 real frames zero-padded to 192), JDCNet+BiLSTM(4x384), fp32, "
+                                   f"(161 real frames zero-padded to 192), JDCNet+{'BiLSTM(4x384)' if args.head == 'bilstm' else 'Transformer(4 layers, 8 heads, ff 1536)'}, fp32, "
                                    "raw audio resident in HBM -> mel -> fwd -> loss -> bwd -> AdamW",
                        "global_batch": args.batch * world, "frames_per_utterance": FRAMES,
                        "real_frames_per_utterance": 161, "parallelism": f"dp{world}"},
             "loss": last["loss"], "roofline": roof, "kernel_families_ms_per_step": families,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.head == "bilstm":
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -119,6 +119,110 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restr
   });
 }
 
+// ---------------------------------------------------------------- weight gradient, all 9 taps per workgroup
+// 64 (Cout) x 64 (Cin) tile, the 4 waves own its 32x32 quadrants and keep one accumulator per tap
+// (9 x 16 registers).  Per 32-pixel k-tile the workgroup stages dY rows once and, for each row
+// offset dt in {-1,0,1}, the 34 consecutive X rows [k0 + dt*F - 1, k0 + dt*F + 32]; the three
+// column shifts df read the same window at row k + df + 1.  That is 134 staged rows for 9 x 32
+// tap-rows of MFMA work (68 FLOP per staged byte instead of 16), and 64-wide tiles fit every layer
+// (64/128/192/256 channels) without padding.  A source row is invalid for a tap when the shift crossed
+// an image border: that only depends on the source pixel's own (t, f) and on (dt, df), so a small
+// mask table Mk[window][row][df] is rebuilt per k-tile and multiplied into the X operand.
+template <int DUMMY>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_kernel(const float* __restrict__ dy,
+                                                                const float* __restrict__ x,
+                                                                float* __restrict__ ws, int T, int F, int Cin,
+                                                                int Cout, int P, int k_per_split, int tiles_n) {
+  __shared__ __attribute__((aligned(16))) float Ys[kBK * 64];
+  __shared__ __attribute__((aligned(16))) float Xs[3 * 34 * 64];
+  __shared__ float Mk[3 * 34 * 4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm = wv >> 1, wn = wv & 1, r = lane & 31, h = lane >> 5;
+  const int m0 = (blockIdx.x / tiles_n) * 64, n0 = (blockIdx.x % tiles_n) * 64;
+  const int kb = blockIdx.y * k_per_split;
+  const int ke = min(P, kb + k_per_split);
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[tp][q] = 0.f;
+
+  // staging assignments: dY 32 rows x 16 float4 (2 per thread); X 102 rows x 16 float4 (up to 7 per thread)
+  const int c4 = (tid & 15) * 4;
+  float4 ry[2], rx[7];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int k = k0 + (tid >> 4) + 16 * i;
+      ry[i] = k < ke ? *reinterpret_cast<const float4*>(dy + (long)k * Cout + m0 + c4)
+                     : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int wr = (tid >> 4) + 16 * i;                 // window-row id 0..101 (w = wr / 34, row = wr % 34)
+      rx[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (wr < 102) {
+        const int w = wr / 34, row = wr - w * 34;
+        const long q = (long)k0 + (long)(w - 1) * F + row - 1;
+        if (q >= 0 && q < P) rx[i] = *reinterpret_cast<const float4*>(x + q * Cin + n0 + c4);
+      }
+    }
+  };
+  fetch(kb);
+  for (int k0 = kb; k0 < ke; k0 += kBK) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(Ys + ((tid >> 4) + 16 * i) * 64 + c4) = ry[i];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int wr = (tid >> 4) + 16 * i;
+      if (wr < 102) *reinterpret_cast<float4*>(Xs + wr * 64 + c4) = rx[i];
+    }
+    if (tid < 102) {                                       // border masks of this k-tile's source rows
+      const int w = tid / 34, row = tid - w * 34;
+      const long q = (long)k0 + (long)(w - 1) * F + row - 1;
+      float m0v = 0.f, m1v = 0.f, m2v = 0.f;
+      if (q >= 0 && q < P) {
+        const int fq = (int)(q % F), tq = (int)((q / F) % T);
+        const bool trow = !((w == 2 && tq == 0) || (w == 0 && tq == T - 1));   // dt = w - 1
+        m0v = (trow && fq != F - 1) ? 1.f : 0.f;          // df = -1: source column F-1 means the shift wrapped
+        m1v = trow ? 1.f : 0.f;                            // df =  0
+        m2v = (trow && fq != 0) ? 1.f : 0.f;              // df = +1
+      }
+      Mk[tid * 4 + 0] = m0v; Mk[tid * 4 + 1] = m1v; Mk[tid * 4 + 2] = m2v;
+    }
+    __syncthreads();
+    if (k0 + kBK < ke) fetch(k0 + kBK);
+    const float* a_rd = Ys + wm * 32 + r;
+    const float* b_rd = Xs + wn * 32 + r;
+#pragma unroll 4
+    for (int s = 0; s < kBK / 2; ++s) {
+      const int k = 2 * s + h;
+      const float a = a_rd[k * 64];
+#pragma unroll
+      for (int w = 0; w < 3; ++w)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const int row = k + d;                           // k + df + 1 with df = d - 1
+          const float b = b_rd[(w * 34 + row) * 64] * Mk[(w * 34 + row) * 4 + d];
+          acc[w * 3 + d] = mfma32(a, b, acc[w * 3 + d]);
+        }
+    }
+  }
+  // slab layout: [split][tap][Cout][Cin]
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp) {
+    float* dst = ws + ((long)blockIdx.y * 9 + tp) * Cout * Cin;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int co = m0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+      const int ci = n0 + wn * 32 + r;
+      dst[(long)co * Cin + ci] = acc[tp][q];
+    }
+  }
+}
+
 // sum slabs in split order and scatter to OIHW: dw[(co*Cin + ci)*9 + tap]
 __global__ void conv3x3_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits,
                                             int Cout, int Cin) {
@@ -131,11 +235,14 @@ __global__ void conv3x3_wgrad_reduce_kernel(const float* __restrict__ ws, float*
   dw[((long)co * Cin + ci) * 9 + tap] = s;
 }
 
+bool wgrad9_ok(int Cout, int Cin) { return (Cout % 64) == 0 && (Cin % 64) == 0; }
+
 void wgrad_plan(int P, int Cout, int Cin, int* bm, int* bn, int* splits, int* kps) {
-  *bm = Cout <= 64 ? 64 : 128;
-  *bn = Cin <= 64 ? 64 : 128;
-  const int tiles = pe_cdiv(Cout, *bm) * pe_cdiv(Cin, *bn) * 9;
-  int s = pe_cdiv(1024, tiles);
+  const bool nine = wgrad9_ok(Cout, Cin);
+  *bm = (nine || Cout <= 64) ? 64 : 128;
+  *bn = (nine || Cin <= 64) ? 64 : 128;
+  const int tiles = pe_cdiv(Cout, *bm) * pe_cdiv(Cin, *bn) * (nine ? 1 : 9);
+  int s = pe_cdiv(nine ? 512 : 1024, tiles);
   const int max_s = P / 1024 > 0 ? P / 1024 : 1;
   if (s > max_s) s = max_s;
   int k = pe_cdiv(P, s);
@@ -284,6 +391,17 @@ extern "C" int pe_conv3x3_wgrad(const float* x, const float* dy, float* dw_oihw,
   int bm, bn, splits, kps;
   wgrad_plan(B * T * F, Cout, Cin, &bm, &bn, &splits, &kps);
   hipStream_t st = pe_stream(stream);
+  if (wgrad9_ok(Cout, Cin)) {
+    const int P = B * T * F, tn = Cin / 64;
+    hipLaunchKernelGGL(conv3x3_wgrad9_kernel<0>, dim3((Cout / 64) * tn, splits), dim3(256), 0, st, dy, x, workspace, T,
+                       F, Cin, Cout, P, kps, tn);
+    PE_LAUNCH_CHECK();
+    const int n = 9 * Cout * Cin;
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(pe_cdiv(n, 256)), dim3(256), 0, st, workspace, dw_oihw,
+                       splits, Cout, Cin);
+    PE_LAUNCH_CHECK();
+    return PE_OK;
+  }
   if (bm == 64 && bn == 64) return launch_wgrad<64, 64>(x, dy, dw_oihw, workspace, B, T, F, Cin, Cout, splits, kps, st);
   if (bm == 64) return launch_wgrad<64, 128>(x, dy, dw_oihw, workspace, B, T, F, Cin, Cout, splits, kps, st);
   if (bn == 64) return launch_wgrad<128, 64>(x, dy, dw_oihw, workspace, B, T, F, Cin, Cout, splits, kps, st);
