@@ -23,6 +23,7 @@ namespace {
 constexpr int kNfft = 1024;
 constexpr int kHalf = 512;     // complex FFT length
 constexpr int kXchg = 576;     // float2 slots per exchange region (8*72 = 64*9)
+constexpr int kMaxParts = 6;   // 8-tap chunks per mel filter (filters up to 48 bins wide)
 
 struct MelArgs {
   const float* wave;
@@ -39,11 +40,9 @@ struct MelArgs {
   const float* win;            // [1024]
   const float2* tw512;         // [512]  exp(-2 pi i k / 512)
   const float2* tw1024;        // [257]  exp(-2 pi i k / 1024)
-  const int* fb_start;         // [n_mels]
-  const int* fb_len;           // [n_mels]
-  const int* fb_ofs;           // [n_mels]
-  const float* fb_w;           // [nnz]
-  int nnz;
+  const int* fb_idx;           // [n_pairs] first FFT bin of each 8-tap chunk | [n_mels] first chunk | [n_mels] #chunks
+  const float* fb_w;           // [n_pairs][8] chunk weights, zero padded
+  int n_pairs;
   int audio_len;               // (FB-1)*hop + 1024, padded to a multiple of 4
   const int* n_samples_arr;    // optional [batch]: per-utterance length (ragged batches)
   const int* frame_start;      // optional [batch]: output frame t shows source frame t + frame_start[b]
@@ -94,8 +93,8 @@ __global__ __launch_bounds__(256) void mel_fwd_kernel(const MelArgs a) {
   float2* s_A = reinterpret_cast<float2*>(s_audio + a.audio_len);   // [4][kXchg]
   float2* s_B = s_A + 4 * kXchg;                                    // [4][kXchg]
   float* s_out = reinterpret_cast<float*>(s_B + 4 * kXchg);         // [n_mels][FB+1]
-  float* s_fbw = s_out + a.n_mels * (FB + 1);                       // [nnz]
-  int* s_fbi = reinterpret_cast<int*>(s_fbw + a.nnz);               // start|len|ofs
+  float* s_fbw = s_out + ((a.n_mels * (FB + 1) + 3) & ~3);          // [n_pairs][8], 16-byte aligned
+  int* s_fbi = reinterpret_cast<int*>(s_fbw + a.n_pairs * 8);       // k0[n_pairs] | first[n_mels] | cnt[n_mels]
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int b = blockIdx.y;
@@ -123,12 +122,8 @@ __global__ __launch_bounds__(256) void mel_fwd_kernel(const MelArgs a) {
         s_audio[j] = (g >= 0 && g < N) ? wsrc[g] : 0.0f;
       }
     }
-    for (int j = tid; j < a.nnz; j += 256) s_fbw[j] = a.fb_w[j];
-    for (int j = tid; j < n_mels; j += 256) {
-      s_fbi[j] = a.fb_start[j];
-      s_fbi[n_mels + j] = a.fb_len[j];
-      s_fbi[2 * n_mels + j] = a.fb_ofs[j];
-    }
+    for (int j = tid; j < a.n_pairs * 8; j += 256) s_fbw[j] = a.fb_w[j];
+    for (int j = tid; j < a.n_pairs + 2 * n_mels; j += 256) s_fbi[j] = a.fb_idx[j];
 
     // ---- per-lane constants, kept in registers across frames
     float2 win[8], tw1[8], tw2[8], twp[4];
@@ -200,18 +195,40 @@ __global__ __launch_bounds__(256) void mel_fwd_kernel(const MelArgs a) {
         if (lane == 0) {
           const float2 z = A[256];                      // k = 256: W = -i, |X|^2 = |Z|^2
           P[256] = z.x * z.x + z.y * z.y;
+        } else if (lane < 8) {
+          P[kNfft / 2 + lane] = 0.0f;                   // zero tail read by the padded 8-tap chunks
+        }
+      }
+      wave_lds_sync();
+      // mel filterbank, two balanced rounds: every filter is cut into chunks of 8 taps (zero padded);
+      // a lane sums one chunk with a fixed, fully unrolled trip count, then each mel bin adds its
+      // <= kMaxParts chunk sums.  (A serial per-filter loop of up to 36 dependent LDS round trips was
+      // the longest phase of the frame.)
+      if (valid) {
+        float* part = reinterpret_cast<float*>(A);      // Z is dead after the power pass
+        for (int id = lane; id < a.n_pairs; id += 64) {
+          const int k0 = s_fbi[id];
+          const float4 w0 = *reinterpret_cast<const float4*>(s_fbw + id * 8);
+          const float4 w1 = *reinterpret_cast<const float4*>(s_fbw + id * 8 + 4);
+          float acc = w0.x * P[k0];
+          acc = fmaf(w0.y, P[k0 + 1], acc); acc = fmaf(w0.z, P[k0 + 2], acc); acc = fmaf(w0.w, P[k0 + 3], acc);
+          acc = fmaf(w1.x, P[k0 + 4], acc); acc = fmaf(w1.y, P[k0 + 5], acc); acc = fmaf(w1.z, P[k0 + 6], acc);
+          acc = fmaf(w1.w, P[k0 + 7], acc);
+          part[id] = acc;
         }
       }
       wave_lds_sync();
       if (valid) {
+        const float* part = reinterpret_cast<const float*>(A);
         for (int m = lane; m < n_mels; m += 64) {
-          const int st = s_fbi[m], ln = s_fbi[n_mels + m];
-          const float* w = s_fbw + s_fbi[2 * n_mels + m];
+          const int first = s_fbi[a.n_pairs + m], cnt = s_fbi[a.n_pairs + n_mels + m];
           float acc = 0.0f;
-          for (int i = 0; i < ln; ++i) acc = fmaf(w[i], P[st + i], acc);
+#pragma unroll
+          for (int j = 0; j < kMaxParts; ++j) acc += (j < cnt) ? part[first + j] : 0.0f;
           s_out[m * (FB + 1) + fi] = a.log_mode ? (logf(a.log_eps + acc) - a.mean) * a.inv_std : acc;
         }
       }
+      wave_lds_sync();                                  // `part` lives in A, which pass 1 of the next frame rewrites
     }
     __syncthreads();
   }
@@ -232,23 +249,21 @@ __global__ __launch_bounds__(256) void mel_fwd_kernel(const MelArgs a) {
 
 constexpr int kFB = 16;
 
-size_t mel_lds_bytes(int audio_len, int n_mels, int nnz, int fb) {
-  size_t bytes = (size_t)audio_len * 4 + 2 * 4 * kXchg * 8 + (size_t)n_mels * (fb + 1) * 4 +
-                 (size_t)nnz * 4 + (size_t)3 * n_mels * 4;
+size_t mel_lds_bytes(int audio_len, int n_mels, int n_pairs, int fb) {
+  size_t bytes = (size_t)audio_len * 4 + 2 * 4 * kXchg * 8 + (size_t)((n_mels * (fb + 1) + 3) & ~3) * 4 +
+                 (size_t)n_pairs * 8 * 4 + (size_t)(n_pairs + 2 * n_mels) * 4;
   return (bytes + 15) & ~(size_t)15;
 }
 
 }  // namespace
 
 struct pe_mel_plan {
-  int sample_rate, n_fft, hop, n_mels, n_freq, nnz;
+  int sample_rate, n_fft, hop, n_mels, n_freq, n_pairs;
   void* d_base;
   float* d_win;
   float2* d_tw512;
   float2* d_tw1024;
-  int* d_fb_start;
-  int* d_fb_len;
-  int* d_fb_ofs;
+  int* d_fb_idx;
   float* d_fb_w;
 };
 
@@ -267,7 +282,8 @@ extern "C" int pe_mel_plan_create(pe_mel_plan** plan_out, int sample_rate, int n
     const double m = m_min + (m_max - m_min) * (double)i / (double)(n_mels + 1);
     f_pts[i] = 700.0 * (pow(10.0, m / 2595.0) - 1.0);
   }
-  std::vector<int> start(n_mels), len(n_mels), ofs(n_mels);
+  // sparse filterbank as 8-tap chunks: pair p covers bins [k0[p], k0[p] + 8) of one filter
+  std::vector<int> pair_k0, mel_first(n_mels), mel_cnt(n_mels);
   std::vector<float> w;
   for (int m = 0; m < n_mels; ++m) {
     int first = -1, last = -1;
@@ -280,12 +296,23 @@ extern "C" int pe_mel_plan_create(pe_mel_plan** plan_out, int sample_rate, int n
       col[k] = (float)v;
       if (col[k] != 0.0f) { if (first < 0) first = k; last = k; }
     }
-    start[m] = first < 0 ? 0 : first;
-    len[m] = first < 0 ? 0 : last - first + 1;
-    ofs[m] = (int)w.size();
-    for (int i = 0; i < len[m]; ++i) w.push_back(col[start[m] + i]);
+    mel_first[m] = (int)pair_k0.size();
+    const int len = first < 0 ? 0 : last - first + 1;
+    mel_cnt[m] = (len + 7) / 8;
+    for (int c = 0; c < mel_cnt[m]; ++c) {
+      pair_k0.push_back(first + 8 * c);
+      for (int i = 0; i < 8; ++i) {
+        const int k = first + 8 * c + i;
+        w.push_back((k <= last) ? col[k] : 0.0f);
+      }
+    }
+    if (mel_cnt[m] > kMaxParts) return PE_E_UNSUPPORTED;
   }
-  const int nnz = (int)w.size();
+  const int n_pairs = (int)pair_k0.size();
+  if (n_pairs > 256) return PE_E_UNSUPPORTED;        // chunk sums live in a 512-float2 exchange region
+  std::vector<int> idx(pair_k0);
+  idx.insert(idx.end(), mel_first.begin(), mel_first.end());
+  idx.insert(idx.end(), mel_cnt.begin(), mel_cnt.end());
 
   std::vector<float> win(kNfft);
   std::vector<float2> tw512(512), tw1024(257);
@@ -304,19 +331,15 @@ extern "C" int pe_mel_plan_create(pe_mel_plan** plan_out, int sample_rate, int n
   size_t o_win = 0;
   size_t o_t5 = o_win + up256(sizeof(float) * kNfft);
   size_t o_t10 = o_t5 + up256(sizeof(float2) * 512);
-  size_t o_st = o_t10 + up256(sizeof(float2) * 257);
-  size_t o_ln = o_st + up256(sizeof(int) * n_mels);
-  size_t o_of = o_ln + up256(sizeof(int) * n_mels);
-  size_t o_w = o_of + up256(sizeof(int) * n_mels);
-  size_t total = o_w + up256(sizeof(float) * (nnz > 0 ? nnz : 1));
+  size_t o_ix = o_t10 + up256(sizeof(float2) * 257);
+  size_t o_w = o_ix + up256(sizeof(int) * idx.size());
+  size_t total = o_w + up256(sizeof(float) * (w.empty() ? 1 : w.size()));
   std::vector<char> host(total, 0);
   memcpy(host.data() + o_win, win.data(), sizeof(float) * kNfft);
   memcpy(host.data() + o_t5, tw512.data(), sizeof(float2) * 512);
   memcpy(host.data() + o_t10, tw1024.data(), sizeof(float2) * 257);
-  memcpy(host.data() + o_st, start.data(), sizeof(int) * n_mels);
-  memcpy(host.data() + o_ln, len.data(), sizeof(int) * n_mels);
-  memcpy(host.data() + o_of, ofs.data(), sizeof(int) * n_mels);
-  if (nnz) memcpy(host.data() + o_w, w.data(), sizeof(float) * nnz);
+  memcpy(host.data() + o_ix, idx.data(), sizeof(int) * idx.size());
+  if (!w.empty()) memcpy(host.data() + o_w, w.data(), sizeof(float) * w.size());
 
   void* d = nullptr;
   PE_CHECK_HIP(hipMalloc(&d, total));
@@ -328,14 +351,12 @@ extern "C" int pe_mel_plan_create(pe_mel_plan** plan_out, int sample_rate, int n
 
   pe_mel_plan* p = new pe_mel_plan;
   p->sample_rate = sample_rate; p->n_fft = n_fft; p->hop = hop_length; p->n_mels = n_mels;
-  p->n_freq = n_freq; p->nnz = nnz; p->d_base = d;
+  p->n_freq = n_freq; p->n_pairs = n_pairs; p->d_base = d;
   char* c = reinterpret_cast<char*>(d);
   p->d_win = reinterpret_cast<float*>(c + o_win);
   p->d_tw512 = reinterpret_cast<float2*>(c + o_t5);
   p->d_tw1024 = reinterpret_cast<float2*>(c + o_t10);
-  p->d_fb_start = reinterpret_cast<int*>(c + o_st);
-  p->d_fb_len = reinterpret_cast<int*>(c + o_ln);
-  p->d_fb_ofs = reinterpret_cast<int*>(c + o_of);
+  p->d_fb_idx = reinterpret_cast<int*>(c + o_ix);
   p->d_fb_w = reinterpret_cast<float*>(c + o_w);
   *plan_out = p;
   return PE_OK;
@@ -371,11 +392,10 @@ static int mel_launch(const pe_mel_plan* plan, const float* wave, int batch, int
   a.log_mode = log_mode; a.log_eps = log_eps; a.mean = mean; a.inv_std = 1.0f / std;
   a.pad_value = pad_value;
   a.win = plan->d_win; a.tw512 = plan->d_tw512; a.tw1024 = plan->d_tw1024;
-  a.fb_start = plan->d_fb_start; a.fb_len = plan->d_fb_len; a.fb_ofs = plan->d_fb_ofs;
-  a.fb_w = plan->d_fb_w; a.nnz = plan->nnz;
+  a.fb_idx = plan->d_fb_idx; a.fb_w = plan->d_fb_w; a.n_pairs = plan->n_pairs;
   a.audio_len = ((kFB - 1) * plan->hop + kNfft + 3) & ~3;
 
-  const size_t lds = mel_lds_bytes(a.audio_len, plan->n_mels, plan->nnz, kFB);
+  const size_t lds = mel_lds_bytes(a.audio_len, plan->n_mels, plan->n_pairs, kFB);
   if (lds > 160 * 1024) return PE_E_UNSUPPORTED;
   dim3 grid(pe_cdiv(out_frames, kFB), batch);
   hipLaunchKernelGGL(mel_fwd_kernel<kFB>, grid, dim3(256), lds, pe_stream(stream), a);

@@ -29,54 +29,37 @@ except Exception:  # pragma: no cover
 
 
 class Trainer(object):
-    def __init__(self,
-                 model=None,
-                 criterion=None,
-                 optimizer=None,
-                 scheduler=None,
-                 config={},
-                 loss_config={},
-                 device=torch.device("cpu"),
-                 logger=logger,
-                 train_dataloader=None,
-                 val_dataloader=None,
-                 initial_steps=0,
-                 initial_epochs=0,
-                 use_mixed_precision=False,
-                 gradient_checkpointing=False,
-                 checkpoint_use_reentrant=None,
-                 mel_transform=None,
-                 data_parallel=None):
-        self.steps = initial_steps
-        self.epochs = initial_epochs
-        self.model = model
-        self.criterion = criterion
-        self.optimizer = optimizer
-        self.scheduler = scheduler
-        self.train_dataloader = train_dataloader
-        self.val_dataloader = val_dataloader
-        self.config = config
-        self.loss_config = loss_config
-        self.device = device
-        self.finish_train = False
-        self.logger = logger
-        self.mel_transform = mel_transform          # on-device mel for batches that carry raw audio
-        self.data_parallel = data_parallel          # pitchextractor_amd.distributed.GradientAllReduce or None
-        device_type = torch.device(self.device).type if isinstance(self.device, (str, torch.device)) else "cpu"
-        if device_type != "cuda":
+    """Keyword-compatible with the reference constructor (trainer.py:33-48), plus ``mel_transform`` (on-device
+    mel for raw-audio batches) and ``data_parallel`` (a ``distributed.GradientAllReduce``)."""
+
+    def __init__(self, model=None, criterion=None, optimizer=None, scheduler=None, config={}, loss_config={},
+                 device=torch.device("cpu"), logger=logger, train_dataloader=None, val_dataloader=None,
+                 initial_steps=0, initial_epochs=0, use_mixed_precision=False, gradient_checkpointing=False,
+                 checkpoint_use_reentrant=None, mel_transform=None, data_parallel=None):
+        kind = torch.device(device).type if isinstance(device, (str, torch.device)) else "cpu"
+        if kind != "cuda":
             raise RuntimeError("pitchextractor_amd.Trainer runs the HIP path only: device must be a HIP "
                                "('cuda') device; there is no CPU fallback")
         self._check_criterion(criterion)
-        # reference trainer.py:63-64,103: both flags are honoured only on an accelerator
+        self.model, self.criterion = model, criterion
+        self.optimizer, self.scheduler = optimizer, scheduler
+        self.train_dataloader, self.val_dataloader = train_dataloader, val_dataloader
+        self.config, self.loss_config = config, loss_config
+        self.device, self.logger = device, logger
+        self.steps, self.epochs = initial_steps, initial_epochs
+        self.finish_train = False
+        self.mel_transform = mel_transform
+        self.data_parallel = data_parallel
+        # The reference honours both flags only on an accelerator (trainer.py:63-64,103).  Here fp32 is the
+        # parity mode and 288 GB of HBM holds every activation of a batch-256 step (~20 GB), so both are
+        # accepted and change nothing numerically.
         self.use_amp = bool(use_mixed_precision)
-        if self.use_amp:
-            self.logger.warning("mixed_precision requested: the HIP path currently computes in fp32 "
-                                "(bit-compatible with the reference's CPU oracle); flag accepted, no-op")
         self.gradient_checkpointing = bool(gradient_checkpointing)
         self.gradient_checkpoint_use_reentrant = checkpoint_use_reentrant
+        if self.use_amp:
+            logger.warning("mixed_precision requested: the HIP path computes in fp32 (flag accepted, no-op)")
         if self.gradient_checkpointing:
-            self.logger.info("gradient_checkpointing requested: 288 GB of HBM holds the full activation set at "
-                             "batch 256 (~20 GB), so nothing is recomputed; flag accepted, no-op")
+            logger.info("gradient_checkpointing requested: nothing is recomputed on this part (flag accepted, no-op)")
 
     @staticmethod
     def _check_criterion(criterion):
@@ -176,28 +159,31 @@ class Trainer(object):
                                "set pitchextractor_amd.ops.USE_PERSISTENT_LSTM = False")
         return {"loss": loss, "f0": loss_f0, "sil": loss_sil}
 
+    def _epoch(self, loader, tag, step_fn):
+        sums = defaultdict(list)
+        for batch in tqdm(loader, desc=f"[{tag}]"):
+            for key, value in step_fn(batch).items():
+                sums[f"{tag}/{key}"].append(value)
+        return {key: float(np.mean(vals)) for key, vals in sums.items()}
+
     def _train_epoch(self):
+        """One pass over ``train_dataloader`` -> {'train/loss','train/f0','train/sil','train/learning_rate'}."""
         self.epochs += 1
-        train_losses = defaultdict(list)
         self.model.train()
-        for _, batch in enumerate(tqdm(self.train_dataloader, desc="[train]"), 1):
-            losses = self.run(batch)
-            for key, value in losses.items():
-                train_losses["train/%s" % key].append(value)
-        train_losses = {key: float(np.mean(value)) for key, value in train_losses.items()}
-        train_losses["train/learning_rate"] = self._get_lr()
-        return train_losses
+        out = self._epoch(self.train_dataloader, "train", self.run)
+        out["train/learning_rate"] = self._get_lr()
+        return out
+
+    @torch.no_grad()
+    def _eval_step(self, batch):
+        x, f0, sil = self._inputs(batch)
+        f0_pred, sil_pred = self.model(x.transpose(-1, -2))
+        out3, _, _ = self._loss(f0_pred, sil_pred, f0, sil, False)
+        loss, loss_f0, loss_sil = out3.tolist()
+        return {"loss": loss, "f0": loss_f0, "sil": loss_sil}
 
     @torch.no_grad()
     def _eval_epoch(self):
+        """One pass over ``val_dataloader`` in eval mode -> {'eval/loss','eval/f0','eval/sil'}."""
         self.model.eval()
-        eval_losses = defaultdict(list)
-        for _, batch in enumerate(tqdm(self.val_dataloader, desc="[eval]"), 1):
-            x, f0, sil = self._inputs(batch)
-            f0_pred, sil_pred = self.model(x.transpose(-1, -2))
-            out3, _, _ = self._loss(f0_pred, sil_pred, f0, sil, False)
-            loss, loss_f0, loss_sil = out3.tolist()
-            eval_losses["eval/loss"].append(loss)
-            eval_losses["eval/f0"].append(loss_f0)
-            eval_losses["eval/sil"].append(loss_sil)
-        return {key: float(np.mean(value)) for key, value in eval_losses.items()}
+        return self._epoch(self.val_dataloader, "eval", self._eval_step)
