@@ -180,3 +180,63 @@ def test_cpu_input_fails_loudly():
     net = JDCNet(num_class=1, sequence_model_config=dict(SEQ_CFG))
     with pytest.raises(RuntimeError):
         net(torch.zeros(1, 1, 192, 80))
+
+
+@pytest.mark.parametrize("B,T", [(1, 192), (3, 48), (2, 208)])
+def test_odd_batch_and_sequence_lengths(hip_device, B, T):
+    """Inference chunks need not be 192 frames (notebook predict_f0 pads the tail) and B may be 1
+    (the reference's ``.squeeze()`` then also drops the batch axis, which the flattened loss ignores)."""
+    state = model_ref.seeded_state(11, hidden_size=64, num_layers=2)
+    cfg = dict(SEQ_CFG, hidden_size=64, num_layers=2)
+    net = JDCNet(num_class=1, sequence_model_config=dict(cfg))
+    net.load_state_dict(state)
+    net = net.to(hip_device).eval()
+    x = golden_input(17, B=B, T=T)
+    with torch.no_grad():
+        cls, det = net(x.to(hip_device))
+        ref_cls, ref_det = model_ref.jdcnet_forward(
+            {k: (v.double() if v.dtype.is_floating_point else v) for k, v in state.items()}, x.double(), cfg)
+    assert cls.shape == (B, T, 1) and det.shape == (B, T)
+    close(cls, ref_cls.numpy(), 1e-4)
+    close(det, ref_det.numpy(), 1e-4)
+
+
+def test_checkpoint_roundtrip_and_partial_load(tmp_path, hip_device):
+    """save_checkpoint / load_checkpoint keep the reference's dict layout (trainer.py:138-195) and the
+    shape-tolerant copy (a num_class=360 checkpoint loads into a num_class=1 model by overlap)."""
+    net = build(model_ref.seeded_state(11, hidden_size=64), 1, 64, hip_device)
+    opt, sched = build_optimizer({"params": net.parameters(), "optimizer_params": {},
+                                  "scheduler_params": {"max_lr": 3e-4, "pct_start": 0.0, "epochs": 2,
+                                                       "steps_per_epoch": 4}})
+    crit = {"l1": torch.nn.SmoothL1Loss(), "ce": torch.nn.BCEWithLogitsLoss()}
+    tr = Trainer(model=net, criterion=crit, optimizer=opt, scheduler=sched, device="cuda:0",
+                 loss_config={"lambda_f0": 0.1}, logger=logging.getLogger("t"))
+    net.train()
+    net.block_dropout = 0.0
+    batch = next(iter(training_batches(1)))
+    tr.run(batch)
+    path = tmp_path / "ckpt" / "epoch_00001.pth"
+    tr.save_checkpoint(str(path))
+    blob = torch.load(path, map_location="cpu", weights_only=True)
+    assert sorted(blob) == ["epochs", "model", "optimizer", "scheduler", "steps"]
+    assert len(blob["model"]) == 125 and len(blob["optimizer"]["state"]) == 98
+    st0 = blob["optimizer"]["state"][0]
+    assert set(st0) >= {"step", "exp_avg", "exp_avg_sq"} and float(st0["step"]) == 1.0
+    # resume into a fresh trainer: identical next step
+    net2 = build(model_ref.seeded_state(12, hidden_size=64), 1, 64, hip_device).train()
+    net2.block_dropout = 0.0
+    opt2, sched2 = build_optimizer({"params": net2.parameters(), "optimizer_params": {},
+                                    "scheduler_params": {"max_lr": 3e-4, "pct_start": 0.0, "epochs": 2,
+                                                         "steps_per_epoch": 4}})
+    tr2 = Trainer(model=net2, criterion=crit, optimizer=opt2, scheduler=sched2, device="cuda:0",
+                  loss_config={"lambda_f0": 0.1}, logger=logging.getLogger("t"))
+    tr2.load_checkpoint(str(path), load_only_params=False)
+    a, b = tr.run(batch), tr2.run(batch)
+    assert abs(a["loss"] - b["loss"]) <= 1e-6 * abs(a["loss"])
+    assert torch.equal(net.flat_parameters, net2.flat_parameters)
+    # shape-tolerant load (classifier 360 x D -> 1 x D keeps row 0)
+    big = model_ref.seeded_state(5, num_class=360, hidden_size=64)
+    torch.save({"model": big, "optimizer": {}, "scheduler": {}, "steps": 0, "epochs": 0}, tmp_path / "big.pth")
+    tr2.load_checkpoint(str(tmp_path / "big.pth"), load_only_params=True)
+    assert torch.equal(net2.classifier.weight.cpu(), big["classifier.weight"][:1])
+    assert torch.equal(net2.conv_block[0].weight.cpu(), big["conv_block.0.weight"])
