@@ -35,3 +35,22 @@ __device__ __forceinline__ double pe_wave_strided_sum(const double* base, long s
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
   return s;
 }
+
+// Split-K planning: choose the number of k-splits so that tiles * splits fills whole "waves" of
+// resident workgroups (wave = CUs x workgroups per CU); a 1.5-wave grid idles a quarter of the chip.
+static inline int pe_pick_splits(int tiles, long K, int min_k_per_split, int resident) {
+  long max_s = K / min_k_per_split;
+  if (max_s < 1) max_s = 1;
+  if (max_s > 1024) max_s = 1024;
+  int best = 1;
+  double best_score = -1.0;
+  for (int sp = 1; sp <= (int)max_s; ++sp) {
+    const long wgs = (long)tiles * sp;
+    const long waves = (wgs + resident - 1) / resident;
+    const double eff = (double)wgs / (double)(waves * resident);
+    // prefer full waves, then fewer splits (less slab traffic) once at least ~2 waves are queued
+    const double score = eff - 0.0001 * sp + (wgs >= 2L * resident ? 0.05 : 0.0);
+    if (score > best_score) { best_score = score; best = sp; }
+  }
+  return best;
+}

@@ -242,9 +242,7 @@ void wgrad_plan(int P, int Cout, int Cin, int* bm, int* bn, int* splits, int* kp
   *bm = (nine || Cout <= 64) ? 64 : 128;
   *bn = (nine || Cin <= 64) ? 64 : 128;
   const int tiles = pe_cdiv(Cout, *bm) * pe_cdiv(Cin, *bn) * (nine ? 1 : 9);
-  int s = pe_cdiv(nine ? 512 : 1024, tiles);
-  const int max_s = P / 1024 > 0 ? P / 1024 : 1;
-  if (s > max_s) s = max_s;
+  const int s = pe_pick_splits(tiles, P, 1024, nine ? 512 : 768);   // resident: 2 (9-tap) or 3 workgroups per CU
   int k = pe_cdiv(P, s);
   k = (k + kBK - 1) / kBK * kBK;
   *kps = k;

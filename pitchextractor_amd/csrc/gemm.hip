@@ -95,10 +95,7 @@ __global__ void splitk_reduce_kernel(const float* ws, long split_stride, int spl
 
 void tn_plan(int M, int N, int K, int bm, int bn, int* splits, int* k_per_split) {
   const int tiles = pe_cdiv(M, bm) * pe_cdiv(N, bn);
-  int s = pe_cdiv(768, tiles);
-  const int max_s = K / 256 > 0 ? K / 256 : 1;
-  if (s > max_s) s = max_s;
-  if (s < 1) s = 1;
+  const int s = pe_pick_splits(tiles, K, 512, 768);      // 256 CUs x 3 resident workgroups
   int kps = pe_cdiv(K, s);
   kps = (kps + kBK - 1) / kBK * kBK;
   *splits = pe_cdiv(K, kps);

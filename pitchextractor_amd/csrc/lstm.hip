@@ -229,9 +229,7 @@ __global__ void slab_reduce_kernel(const float* ws, long n, int splits, float* o
 
 void whh_plan(int M, int N, int K, int* splits, int* kps) {
   const int tiles = pe_cdiv(M, 128) * pe_cdiv(N, 128);
-  int s = pe_cdiv(768, tiles);
-  const int max_s = K / 256 > 0 ? K / 256 : 1;
-  if (s > max_s) s = max_s;
+  const int s = pe_pick_splits(tiles, K, 512, 768);
   int k = pe_cdiv(K, s);
   k = (k + kBK - 1) / kBK * kBK;
   *kps = k;
