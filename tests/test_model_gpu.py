@@ -240,3 +240,31 @@ def test_checkpoint_roundtrip_and_partial_load(tmp_path, hip_device):
     tr2.load_checkpoint(str(tmp_path / "big.pth"), load_only_params=True)
     assert torch.equal(net2.classifier.weight.cpu(), big["classifier.weight"][:1])
     assert torch.equal(net2.conv_block[0].weight.cpu(), big["conv_block.0.weight"])
+
+
+def test_notebook_inference_recipe(tmp_path, hip_device):
+    """load_model + predict_f0 (Utils/dynamic_pitch_behavior.ipynb, cell 5): chunking 192/48, zero-padded
+    tail, un-blended overlaps -- against the oracle run chunk by chunk on the oracle's own mel."""
+    from oracle import mel_ref
+    from pitchextractor_amd import inference, synthetic
+    state = model_ref.seeded_state(31, hidden_size=64, num_layers=2)
+    torch.save({"model": state, "steps": 0, "epochs": 3}, tmp_path / "m.pth")
+    net = inference.load_model(tmp_path / "m.pth", device=hip_device)
+    assert net.sequence_classifier.hidden_size == 64 and net.sequence_classifier.num_layers == 2 and net.num_class == 1
+    wave, _, _ = synthetic.utterance(2, duration=4.2)            # 337 frames -> chunks at 0, 144, 288
+    got = inference.predict_f0(net, wave)
+    mel = mel_ref.log_mel(wave)
+    st64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in state.items()}
+    cfg = dict(SEQ_CFG, hidden_size=64, num_layers=2)
+    parts = []
+    for s in range(0, mel.shape[1], 144):
+        e = min(s + 192, mel.shape[1])
+        chunk = np.zeros((80, 192))
+        chunk[:, :e - s] = mel[:, s:e]
+        x = torch.from_numpy(chunk)[None, None].transpose(-1, -2)
+        with torch.no_grad():
+            f0, _ = model_ref.jdcnet_forward(st64, x, cfg)
+        parts.append(f0[0, :e - s, 0].numpy())
+    ref = np.concatenate(parts)
+    assert got.shape == ref.shape == (192 + 192 + 49,)
+    assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max()   # fp32 mel + fp32 net vs float64 end to end
