@@ -212,6 +212,16 @@ int pe_layernorm_bwd(const float* dy, const float* z, const float* mean, const f
 int pe_gelu_fwd(const float* x, float* y, long n, void* stream);
 int pe_gelu_bwd(const float* x, const float* dy, float* dx, long n, void* stream);
 
+/* ---- resampler (meldataset.py:621-627 -> torchaudio.functional.resample defaults) ----
+ * sinc_interp_hann, lowpass_filter_width 6, rolloff 0.99; y has ceil(new * n_in / orig) samples. */
+typedef struct pe_resample_plan pe_resample_plan;
+int pe_resample_plan_create(pe_resample_plan** plan, int orig_freq, int new_freq, int lowpass_filter_width,
+                            float rolloff);
+int pe_resample_plan_destroy(pe_resample_plan* plan);
+long pe_resample_out_len(const pe_resample_plan* plan, long n_in);
+int pe_resample_forward(const pe_resample_plan* plan, const float* x, int batch, int n_in, long x_stride, float* y,
+                        long y_stride, int n_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

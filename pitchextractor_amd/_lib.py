@@ -82,6 +82,10 @@ PROTOTYPES = {
     "pe_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _l, _i, _p, _z, _p]),
     "pe_gelu_fwd": (_i, [_p, _p, _l, _p]),
     "pe_gelu_bwd": (_i, [_p, _p, _p, _l, _p]),
+    "pe_resample_plan_create": (_i, [C.POINTER(_p), _i, _i, _i, _f]),
+    "pe_resample_plan_destroy": (_i, [_p]),
+    "pe_resample_out_len": (_l, [_p, _l]),
+    "pe_resample_forward": (_i, [_p, _p, _i, _i, _l, _p, _l, _i, _p]),
     "pe_adamw_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _d, _d, _f, _p]),
 }
 

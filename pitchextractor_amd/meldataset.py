@@ -16,8 +16,9 @@ Out of scope here: the F0 tracker backends and the WORLD / pitc
 augmentation need packages that are not installable offline.  F0 labels therefore come from the
 reference's cache files (``<wav>_f0*.npy``; the legacy ``<wav>_f0.npy`` too) or from an
 ``f0_provider`` callable; an item with neither fails loudly, as the reference does when no
-backend is usable (meldataset.py:80-88).  Resampling (meldataset.py:621-627) is not implemented:
-files must already be at the target rate.
+backend is usable (meldataset.py:80-88).  Files at another sample rate are resampled on the GPU
+(meldataset.py:621-627 -> ``pitchextractor_amd.resample.Resampler``) right before the mel launch; one
+batch must come from one source rate.
 """
 from __future__ import annotations
 
@@ -33,6 +34,7 @@ import torch
 from torch.utils.data import DataLoader
 
 from .mel import DEFAULT_MEL_PARAMS, MAX_MEL_LENGTH, MEL_MEAN, MEL_STD, LOG_EPS, MelSpectrogram
+from .resample import Resampler
 
 logger = logging.getLogger(__name__)
 logger.setLevel(logging.DEBUG)
@@ -239,16 +241,15 @@ class MelDataset(torch.utils.data.Dataset):
         if wave.ndim > 1:
             wave = np.mean(wave, axis=-1)
         wave = wave.astype(np.float32)
-        if wave_sr != self.sr:
-            raise NotImplementedError(f"{path}: sample rate {wave_sr} != {self.sr}; resampling is not on the HIP "
-                                      "path yet (SURVEY N1)")
+        # the device resamples; everything below only needs the resampled LENGTH: ceil(new * L / orig)
+        n_target = Resampler(wave_sr, self.sr).out_len(len(wave)) if wave_sr != self.sr else len(wave)
         start_sample = 0 if full else int(round(start / float(md["sample_rate"]) * self.sr))
-        expected = None if full else int(np.ceil(len(wave) / max(hop, 1))) + 2
+        expected = None if full else int(np.ceil(n_target / max(hop, 1))) + 2
         f0 = self._f0_for(path, wave, start_sample, expected)
         if self.data_augmentation:
             wave = (0.5 + 0.5 * np.random.random()) * wave                        # meldataset.py:232-234
             wave = wave.astype(np.float32)
-        mel_len = 1 + len(wave) // hop
+        mel_len = 1 + n_target // hop
         f0 = align_length(f0, mel_len)
         sil = (f0 == 0).astype(np.float32)
         crop = 0
@@ -257,6 +258,7 @@ class MelDataset(torch.utils.data.Dataset):
             f0 = f0[crop:crop + self.max_mel_length]
             sil = sil[crop:crop + self.max_mel_length]
         f0 = np.where(np.isnan(f0), np.float32(self.zero_value), f0).astype(np.float32)
+        self._last_sr = wave_sr
         return wave, f0, sil, crop
 
     def __getitem__(self, idx):
@@ -275,13 +277,16 @@ class MelDataset(torch.utils.data.Dataset):
                 self._invalid_paths.add(path)
                 logger.warning("[MelDataset] Skipping unreadable audio file: %s (%s)", path, exc)
                 continue
-            return torch.from_numpy(wave), torch.from_numpy(f0), torch.from_numpy(sil), crop
+            return torch.from_numpy(wave), torch.from_numpy(f0), torch.from_numpy(sil), crop, int(self._last_sr)
         raise RuntimeError("No valid audio files could be loaded from the dataset")
 
     def path_to_mel_and_label(self, path, device="cuda"):
         """Reference-shaped single item: (mel (80, L<=192) normalised log-mel on the device, f0, is_silence)."""
         wave, f0, sil, crop = self.path_to_wave_and_label(path)
-        mel = self.to_melspec(torch.from_numpy(wave).to(device))
+        wave_dev = torch.from_numpy(wave).to(device)
+        if self._last_sr != self.sr:
+            wave_dev = Resampler(self._last_sr, self.sr)(wave_dev)
+        mel = self.to_melspec(wave_dev)
         mel = (torch.log(LOG_EPS + mel) - self.mean) / self.std
         return mel[:, crop:crop + self.max_mel_length], torch.from_numpy(f0), torch.from_numpy(sil)
 
@@ -290,8 +295,8 @@ class Collater(object):
     """Zero-pads items to 192 frames (meldataset.py:790-826).
 
     Accepts the reference's ``(mel (80,L), f0, is_silence)`` items, or this build's raw-audio items
-    ``(wave (N,), f0, is_silence, crop_start)``; for the latter it returns host tensors
-    ``(waves (B,Nmax), lengths, crop_starts, f0s, is_silences)`` for the device mel stage."""
+    ``(wave (N,), f0, is_silence, crop_start[, source_sr])``; for the latter it returns host tensors
+    ``(waves (B,Nmax), lengths, crop_starts, f0s, is_silences, source_sr)`` for the device mel stage."""
 
     def __init__(self, return_wave=False):
         self.return_wave = return_wave
@@ -316,14 +321,18 @@ class Collater(object):
         waves = torch.zeros((B, n_max), dtype=torch.float32)
         lengths = torch.zeros((B,), dtype=torch.int32)
         crops = torch.zeros((B,), dtype=torch.int32)
-        for i, (wave, f0, sil, crop) in enumerate(batch):
+        rates = {int(item[4]) for item in batch if len(item) > 4}
+        if len(rates) > 1:
+            raise RuntimeError(f"one batch mixes source sample rates {sorted(rates)}: group files by rate")
+        for i, item in enumerate(batch):
+            wave, f0, sil, crop = item[:4]
             n = wave.shape[0]
             waves[i, :n] = wave
             lengths[i] = n
             crops[i] = int(crop)
             f0s[i, :f0.shape[0]] = f0
             sils[i, :sil.shape[0]] = sil
-        return waves, lengths, crops, f0s, sils
+        return waves, lengths, crops, f0s, sils, (rates.pop() if rates else 0)
 
 
 class DeviceMelLoader:
@@ -333,13 +342,18 @@ class DeviceMelLoader:
     def __init__(self, loader: DataLoader, mel: MelSpectrogram, device):
         self.loader, self.mel, self.device = loader, mel, torch.device(device)
         self.dataset = loader.dataset
+        self._resamplers = {}
 
     def __len__(self):
         return len(self.loader)
 
     def __iter__(self):
-        for waves, lengths, crops, f0s, sils in self.loader:
+        for waves, lengths, crops, f0s, sils, src_sr in self.loader:
             waves = waves.to(self.device, non_blocking=True)
+            if src_sr and src_sr != self.mel.sample_rate:
+                rs = self._resamplers.setdefault(src_sr, Resampler(src_sr, self.mel.sample_rate))
+                waves = rs(waves)                             # zero-padded rows resample exactly like each item alone
+                lengths = torch.tensor([rs.out_len(int(n)) for n in lengths], dtype=torch.int32)
             lengths = lengths.to(self.device, non_blocking=True)
             crops = crops.to(self.device, non_blocking=True)
             mels = self.mel.log_mel_ragged(waves, lengths, crops, max_frames=MAX_MEL_LENGTH)

@@ -85,15 +85,17 @@ def test_dataset_item_and_collater(tmp_path):
     ds.data_augmentation = False; ds.max_mel_length = 192; ds.zero_value = 0.0
     ds._audio_metadata_cache = {}; ds._invalid_paths = set()
     items = [ds[i] for i in range(3)]
-    w0, f0_0, s0, c0 = items[0]
+    w0, f0_0, s0, c0, sr0 = items[0]
+    assert sr0 == 24000
     assert w0.shape == (48000,) and f0_0.shape == (161,) and c0 == 0
-    w1, f0_1, s1, c1 = items[1]
+    w1, f0_1, s1, c1, _ = items[1]
     assert w1.shape == (58624,)                                       # pre-cropped segment
     assert f0_1.shape == (192,) and 0 <= c1 < 196 - 192 + 1
     assert torch.equal(s1, (f0_1 == 0).float())
-    w2, f0_2, _, _ = items[2]
+    w2, f0_2, _, _, _ = items[2]
     assert f0_2.shape == (1 + 21600 // 300,)
-    waves, lengths, crops, f0s, sils = md.Collater()(items)
+    waves, lengths, crops, f0s, sils, src_sr = md.Collater()(items)
+    assert src_sr == 24000
     assert waves.shape == (3, 58624) and lengths.tolist() == [48000, 58624, 21600]
     assert f0s.shape == (3, 192) and (f0s[0, 161:] == 0).all() and (sils[0, 161:] == 0).all()
     # reference-shaped items go through the same padding as the oracle's collate
@@ -113,3 +115,18 @@ def test_missing_labels_fail_loudly(tmp_path):
     ds.f0_cache_glob = "_f0*.npy"; ds.f0_provider = None; ds.mel_params = dict(md.DEFAULT_MEL_PARAMS); ds.sr = 24000
     with pytest.raises(RuntimeError):
         ds._f0_for(str(p), wave, 0, None)
+
+
+def test_resampler_oracle_properties():
+    """torchaudio is absent (parity unpinned): pin the float64 restatement by construction."""
+    from oracle import resample_ref as rr
+    k, width, orig, new = rr.sinc_resample_kernel(44100, 24000)
+    assert (k.shape, width, orig, new) == ((80, 171), 12, 147, 80)               # SURVEY N1
+    assert np.abs(k.sum(axis=1) - 1.0).max() < 1e-3                                # unit DC gain per phase
+    t = np.arange(44100) / 44100.0
+    y = rr.resample(np.sin(2 * np.pi * 440 * t), 44100, 24000)
+    assert y.shape == (24000,)
+    ref = np.sin(2 * np.pi * 440 * np.arange(24000) / 24000.0)
+    assert np.abs(y - ref)[200:-200].max() < 1e-3
+    assert rr.resample(np.ones(1000), 24000, 24000).shape == (1000,)
+    assert rr.resample(np.zeros(107722), 44100, 24000).shape == (58624,)            # segment -> 58 624 samples

@@ -67,3 +67,49 @@ def test_dataloader_batches_match_oracle(tmp_path, hip_device):
         assert np.abs(m - rm).max() <= 1e-3
         np.testing.assert_array_equal(f, rf)
         np.testing.assert_array_equal(s, rs)
+
+
+def test_resampler_matches_oracle(hip_device):
+    from oracle import resample_ref as rr
+    from pitchextractor_amd.resample import Resampler
+    rng = np.random.default_rng(0)
+    x = (0.3 * rng.standard_normal((3, 9001))).astype(np.float32)
+    for orig, new in ((44100, 24000), (16000, 24000), (48000, 24000), (22050, 24000)):
+        rs = Resampler(orig, new)
+        y = rs(torch.from_numpy(x).to(hip_device)).cpu().numpy()
+        for i in range(3):
+            ref = rr.resample(x[i], orig, new)
+            assert y[i].shape == ref.shape == (rs.out_len(9001),)
+            assert np.abs(y[i] - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max())
+    assert Resampler(24000, 24000)(torch.ones(5, device=hip_device)).shape == (5,)
+
+
+def test_dataloader_resamples_44k_files(tmp_path, hip_device):
+    """Config 5's data path: 44.1 kHz files -> pre-crop at the source rate -> GPU resample -> mel."""
+    from oracle import resample_ref as rr
+    lines = []
+    for i, dur in enumerate((2.0, 3.1)):
+        n = int(dur * 44100)
+        t = np.arange(n) / 44100.0
+        wave = (0.5 * np.sin(2 * np.pi * (200 + 50 * i) * t)).astype(np.float32)
+        p = tmp_path / f"h{i}.wav"
+        write_wav(p, wave, 44100, "float32")
+        np.save(str(p) + "_f0.npy", np.full(1 + int(dur * 24000) // 300, 200.0 + 50 * i, np.float32))
+        lines.append(f"{p}|0\n")
+    cfg = {"mel_params": {"sample_rate": 24000, "win_len": 1024, "n_fft": 1024, "n_mels": 80, "hop_length": 300},
+           "verbose": False}
+    loader = md.build_dataloader(lines, validation=True, batch_size=2, num_workers=0, device="cuda:0",
+                                 dataset_config=cfg)
+    np.random.seed(7); random.seed(7)
+    (mels, f0s, sils), = list(loader)
+    np.random.seed(7); random.seed(7)
+    ds = loader.dataset
+    for i in range(2):
+        wave, f0, sil, crop = ds.path_to_wave_and_label(ds.data_list[i])
+        assert ds._last_sr == 44100
+        res = rr.resample(wave, 44100, 24000)
+        ref = mel_ref.log_mel(res)[:, crop:crop + 192]
+        L = ref.shape[1]
+        assert np.abs(mels[i, 0, :, :L].cpu().numpy() - ref).max() <= 2e-3
+        np.testing.assert_array_equal(f0s[i, :len(f0)].cpu().numpy(), f0)
+    assert mels.shape == (2, 1, 80, 192)
