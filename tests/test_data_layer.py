@@ -129,4 +129,4 @@ def test_resampler_oracle_properties():
     ref = np.sin(2 * np.pi * 440 * np.arange(24000) / 24000.0)
     assert np.abs(y - ref)[200:-200].max() < 1e-3
     assert rr.resample(np.ones(1000), 24000, 24000).shape == (1000,)
-    assert rr.resample(np.zeros(107722), 44100, 24000).shape == (58624,)            # segment -> 58 624 samples
+    assert rr.resample(np.zeros(107722), 44100, 24000).shape == (58625,)            # ceil(80 * 107722 / 147)
