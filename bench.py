@@ -31,6 +31,7 @@ sys.path.insert(0, str(ROOT))
 FRAMES = 192
 SEQ_CFG = {"model_type": "bilstm", "num_layers": 4, "dropout": 0.1, "nhead": 8, "dim_feedforward": 1536,
            "max_len": 2048}                     # Configs/config.yml:18-24 (hidden_size defaults to 384)
+MFMA_BF16_PEAK_TFLOPS = 2500.0                  # MI355X_MICROARCH.md: dense bf16 MFMA peak
 MFMA_F32_PEAK_TFLOPS = 157.3                    # MI355X_MICROARCH.md: exact-f32 MFMA = vector rate
 HBM_PEAK_GBPS = 8000.0
 
@@ -104,7 +105,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--head", choices=["bilstm", "transformer"], default="bilstm",
                     help="temporal head (default: the reference's default BiLSTM = BASELINE config[1])")
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
+                    help="fp32 = BASELINE config[1] (headline); bf16 = training.mixed_precision "
+                         "(bf16 MFMA operands, fp32 accumulate/state) = BASELINE configs[2]/[3]")
     args = ap.parse_args()
+    bf16 = args.precision == "bf16"
 
     from pitchextractor_amd import distributed as pdist
     from pitchextractor_amd import ops, synthetic
@@ -135,7 +140,7 @@ def main():
     log = logging.getLogger("bench")
     tr = Trainer(model=net, criterion=crit, optimizer=opt, scheduler=sched, device=str(dev),
                  loss_config={"lambda_f0": 0.1}, logger=log, mel_transform=MelSpectrogram(**DEFAULT_MEL_PARAMS),
-                 data_parallel=dp)
+                 data_parallel=dp, use_mixed_precision=bf16)
 
     # this rank's shard of the global minibatch: 32 distinct synthetic utterances tiled to the batch
     lo, _ = pdist.shard_range(args.batch * world, rank, world)
@@ -178,13 +183,14 @@ def main():
         ms = elapsed / args.steps * 1e3
         frames = args.batch * world * FRAMES * args.steps
         summ = timer.summary()
-        conv = summ.get("pe_conv3x3_fwd")
+        conv = summ.get("pe_conv3x3_fwd_bf16" if bf16 else "pe_conv3x3_fwd")
         roof = None
         if conv:
             tflops = conv["work"] / (conv["total_ms"] * 1e-3) / 1e12
+            peak = MFMA_BF16_PEAK_TFLOPS if bf16 else MFMA_F32_PEAK_TFLOPS
             roof = {"bound": "mfma", "kernel": "conv3x3_kernel (implicit-GEMM fwd + dgrad launches)",
-                    "achieved": tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": tflops / MFMA_F32_PEAK_TFLOPS, "traffic": pmc_traffic(),
+                    "achieved": tflops, "peak": peak, "unit": "TFLOP/s",
+                    "frac": tflops / peak, "traffic": None if bf16 else pmc_traffic(),
                     "avg_launch_ms": conv["avg_ms"], "launches_per_step": conv["calls"] / args.steps}
         families = {k: {"ms_per_step": v["total_ms"] / args.steps,
                         "tflops": (v["work"] / (v["total_ms"] * 1e-3) / 1e12) if v["work"] else None}
@@ -193,15 +199,15 @@ def main():
             "metric": "mel-frames/sec training throughput (JDCNet, 24 kHz, batch=256)",
             "value": frames / elapsed, "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE config[1]: batch=256/GPU, 24 kHz 2 s synthetic glides "
-                                   f"(161 real frames zero-padded to 192), JDCNet+{'BiLSTM(4x384)' if args.head == 'bilstm' else 'Transformer(4 layers, 8 heads, ff 1536)'}, fp32, "
+            "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
+            "config": {"workload": (("BASELINE config[2]: batch" if args.head == "transformer" else "BASELINE config[3] per-GPU shape: batch") if bf16 else "BASELINE config[1]: batch") + "=256/GPU, 24 kHz 2 s synthetic glides "
+                                   f"(161 real frames zero-padded to 192), JDCNet+{'BiLSTM(4x384)' if args.head == 'bilstm' else 'Transformer(4 layers, 8 heads, ff 1536)'}, " + ("mixed precision (bf16 conv/linear operands, fp32 accumulate), " if bf16 else "fp32, ") +
                                    "raw audio resident in HBM -> mel -> fwd -> loss -> bwd -> AdamW",
                        "global_batch": args.batch * world, "frames_per_utterance": FRAMES,
                        "real_frames_per_utterance": 161, "parallelism": f"dp{world}"},
             "loss": last["loss"], "roofline": roof, "kernel_families_ms_per_step": families,
         }
-        if world == 1 and not args.no_cpu_baseline and args.head == "bilstm":
+        if world == 1 and not args.no_cpu_baseline and args.head == "bilstm" and not bf16:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:

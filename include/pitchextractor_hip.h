@@ -78,6 +78,10 @@ int pe_mel_forward_ragged(const pe_mel_plan* plan, const float* wave, int batch,
  *   workgroups into workspace slabs that are reduced in a fixed order (deterministic). */
 int pe_gemm_nt(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
                int K, const float* bias0, const float* bias1, int accumulate, void* stream);
+/* Opt-in mixed-precision variant (reference trainer.py:103 autocast): same contract, operands rounded to
+ * bf16 on the way into LDS (v_mfma_f32_32x32x16_bf16), fp32 accumulate, fp32 tensors in HBM. */
+int pe_gemm_nt_bf16(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
+                    int K, const float* bias0, const float* bias1, int accumulate, void* stream);
 size_t pe_gemm_tn_workspace_bytes(int M, int N, int K);
 int pe_gemm_tn(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
                int K, int accumulate, float* workspace, size_t workspace_bytes, void* stream);
@@ -93,6 +97,8 @@ int pe_transpose2d(const float* in, float* out, int rows, int cols, void* stream
 int pe_conv3x3_repack(const float* w_oihw, float* w_fwd, float* w_dgrad, int Cout, int Cin, void* stream);
 int pe_conv3x3_fwd(const float* x, const float* w_packed, float* y, int B, int T, int F, int C, int N,
                    int accumulate, void* stream);
+int pe_conv3x3_fwd_bf16(const float* x, const float* w_packed, float* y, int B, int T, int F, int C, int N,
+                        int accumulate, void* stream);   /* bf16 operands, fp32 accumulate (see pe_gemm_nt_bf16) */
 size_t pe_conv3x3_wgrad_workspace_bytes(int B, int T, int F, int Cin, int Cout);
 int pe_conv3x3_wgrad(const float* x, const float* dy, float* dw_oihw, int B, int T, int F, int Cin,
                      int Cout, float* workspace, size_t workspace_bytes, void* stream);

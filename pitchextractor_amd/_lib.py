@@ -40,11 +40,13 @@ PROTOTYPES = {
     "pe_mel_forward": (_i, [_p, _p, _i, _i, _l, _p, _l, _l, _l, _i, _i, _f, _f, _f, _f, _p]),
     "pe_mel_forward_ragged": (_i, [_p, _p, _i, _i, _l, _p, _p, _p, _l, _l, _l, _i, _i, _f, _f, _f, _f, _p]),
     "pe_gemm_nt": (_i, [_p, _l, _p, _l, _p, _l, _i, _i, _i, _p, _p, _i, _p]),
+    "pe_gemm_nt_bf16": (_i, [_p, _l, _p, _l, _p, _l, _i, _i, _i, _p, _p, _i, _p]),
     "pe_gemm_tn_workspace_bytes": (_z, [_i, _i, _i]),
     "pe_gemm_tn": (_i, [_p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _p, _z, _p]),
     "pe_transpose2d": (_i, [_p, _p, _i, _i, _p]),
     "pe_conv3x3_repack": (_i, [_p, _p, _p, _i, _i, _p]),
     "pe_conv3x3_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "pe_conv3x3_fwd_bf16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "pe_conv3x3_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
     "pe_conv3x3_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
     "pe_conv3x3_c1_fwd": (_i, [_p, _l, _l, _l, _p, _p, _i, _i, _i, _p]),

@@ -50,7 +50,7 @@ struct ConvEpi {
   }
 };
 
-template <class TL>
+template <class TL, bool BF16>
 __global__ __launch_bounds__(256) void conv3x3_kernel(ConvLoader<TL::A_LOADS> al, RowLoader bl, ConvEpi ep,
                                                       int K, int tiles_m, int tiles_n) {
   __shared__ __attribute__((aligned(16))) float As[TL::BM * kLdsStride];
@@ -61,11 +61,12 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvLoader<TL::A_LOADS> al
   bl.init(n0);
   f32x16 acc[TL::TM][TL::TN];
   zero_acc<TL>(acc);
-  nt_mainloop<TL>(al, bl, K, As, Bs, acc);
+  if constexpr (BF16) nt_mainloop_bf16<TL>(al, bl, K, As, Bs, acc);
+  else nt_mainloop<TL>(al, bl, K, As, Bs, acc);
   for_each_acc<TL>(acc, [&](int r, int c, float v) { ep(m0 + r, n0 + c, v); });
 }
 
-template <class TL>
+template <class TL, bool BF16>
 int launch_conv(const float* x, const float* wp, float* y, int B, int T, int F, int C, int N, int accumulate,
                 hipStream_t st) {
   const int rows = B * T * F, K = 9 * C;
@@ -74,7 +75,7 @@ int launch_conv(const float* x, const float* wp, float* y, int B, int T, int F, 
   RowLoader bl{wp, (long)K, N, K, 0};
   ConvEpi ep{y, rows, N, accumulate};
   const int tm = pe_cdiv(rows, TL::BM), tn = pe_cdiv(N, TL::BN);
-  hipLaunchKernelGGL(conv3x3_kernel<TL>, dim3(tm * tn), dim3(256), 0, st, al, bl, ep, K, tm, tn);
+  hipLaunchKernelGGL((conv3x3_kernel<TL, BF16>), dim3(tm * tn), dim3(256), 0, st, al, bl, ep, K, tm, tn);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }
@@ -364,14 +365,26 @@ extern "C" int pe_transpose2d(const float* in, float* out, int rows, int cols, v
   return PE_OK;
 }
 
-extern "C" int pe_conv3x3_fwd(const float* x, const float* w_packed, float* y, int B, int T, int F, int C, int N,
-                              int accumulate, void* stream) {
+template <bool BF16>
+static int conv3x3_fwd_impl(const float* x, const float* w_packed, float* y, int B, int T, int F, int C, int N,
+                            int accumulate, void* stream) {
   if (!x || !w_packed || !y || B <= 0 || T <= 0 || F <= 0 || C <= 0 || N <= 0) return PE_E_ARG;
   if ((C % 32) != 0 || (long)B * T * F * (C > N ? C : N) >= (1L << 31)) return PE_E_UNSUPPORTED;
   hipStream_t st = pe_stream(stream);
-  if (N <= 64) return launch_conv<Tile<256, 64, 4, 1>>(x, w_packed, y, B, T, F, C, N, accumulate, st);
-  if (N % 192 == 0 && N % 128 != 0) return launch_conv<Tile<128, 192, 2, 2>>(x, w_packed, y, B, T, F, C, N, accumulate, st);
-  return launch_conv<Tile<128, 128, 2, 2>>(x, w_packed, y, B, T, F, C, N, accumulate, st);
+  if (N <= 64) return launch_conv<Tile<256, 64, 4, 1>, BF16>(x, w_packed, y, B, T, F, C, N, accumulate, st);
+  if (N % 192 == 0 && N % 128 != 0)
+    return launch_conv<Tile<128, 192, 2, 2>, BF16>(x, w_packed, y, B, T, F, C, N, accumulate, st);
+  return launch_conv<Tile<128, 128, 2, 2>, BF16>(x, w_packed, y, B, T, F, C, N, accumulate, st);
+}
+
+extern "C" int pe_conv3x3_fwd(const float* x, const float* w_packed, float* y, int B, int T, int F, int C, int N,
+                              int accumulate, void* stream) {
+  return conv3x3_fwd_impl<false>(x, w_packed, y, B, T, F, C, N, accumulate, stream);
+}
+
+extern "C" int pe_conv3x3_fwd_bf16(const float* x, const float* w_packed, float* y, int B, int T, int F, int C,
+                                   int N, int accumulate, void* stream) {
+  return conv3x3_fwd_impl<true>(x, w_packed, y, B, T, F, C, N, accumulate, stream);
 }
 
 extern "C" size_t pe_conv3x3_wgrad_workspace_bytes(int B, int T, int F, int Cin, int Cout) {

@@ -27,7 +27,7 @@ struct StoreEpi {
   }
 };
 
-template <class TL>
+template <class TL, bool BF16>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(RowLoader al, RowLoader bl, StoreEpi ep, int K,
                                                       int tiles_m, int tiles_n) {
   __shared__ __attribute__((aligned(16))) float As[TL::BM * kLdsStride];
@@ -38,15 +38,16 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(RowLoader al, RowLoader bl
   bl.init(n0);
   f32x16 acc[TL::TM][TL::TN];
   zero_acc<TL>(acc);
-  nt_mainloop<TL>(al, bl, K, As, Bs, acc);
+  if constexpr (BF16) nt_mainloop_bf16<TL>(al, bl, K, As, Bs, acc);
+  else nt_mainloop<TL>(al, bl, K, As, Bs, acc);
   for_each_acc<TL>(acc, [&](int r, int c, float v) { ep(m0 + r, n0 + c, v); });
 }
 
-template <class TL>
+template <class TL, bool BF16>
 int launch_nt(const RowLoader& al, const RowLoader& bl, const StoreEpi& ep, int M, int N, int K,
               hipStream_t st) {
   const int tm = pe_cdiv(M, TL::BM), tn = pe_cdiv(N, TL::BN);
-  hipLaunchKernelGGL(gemm_nt_kernel<TL>, dim3(tm * tn), dim3(256), 0, st, al, bl, ep, K, tm, tn);
+  hipLaunchKernelGGL((gemm_nt_kernel<TL, BF16>), dim3(tm * tn), dim3(256), 0, st, al, bl, ep, K, tm, tn);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }
@@ -132,8 +133,9 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 }  // namespace
 
-extern "C" int pe_gemm_nt(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
-                          int K, const float* bias0, const float* bias1, int accumulate, void* stream) {
+template <bool BF16>
+static int gemm_nt_impl(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
+                        int K, const float* bias0, const float* bias1, int accumulate, void* stream) {
   if (!A || !B || !C || M < 0 || N < 0 || K <= 0) return PE_E_ARG;
   if (M == 0 || N == 0) return PE_OK;
   if ((K & 3) || (lda & 3) || (ldb & 3) || !aligned16(A) || !aligned16(B)) return PE_E_UNSUPPORTED;
@@ -141,10 +143,21 @@ extern "C" int pe_gemm_nt(const float* A, long lda, const float* B, long ldb, fl
   RowLoader bl{B, ldb, N, K, 0};
   StoreEpi ep{C, ldc, bias0, bias1, M, N, accumulate};
   hipStream_t st = pe_stream(stream);
-  if (N <= 32) return launch_nt<Tile<128, 32, 4, 1>>(al, bl, ep, M, N, K, st);
-  if (N <= 64) return launch_nt<Tile<256, 64, 4, 1>>(al, bl, ep, M, N, K, st);
-  if (N % 192 == 0 && N % 128 != 0) return launch_nt<Tile<128, 192, 2, 2>>(al, bl, ep, M, N, K, st);
-  return launch_nt<Tile<128, 128, 2, 2>>(al, bl, ep, M, N, K, st);
+  if (N <= 32) return launch_nt<Tile<128, 32, 4, 1>, BF16>(al, bl, ep, M, N, K, st);
+  if (N <= 64) return launch_nt<Tile<256, 64, 4, 1>, BF16>(al, bl, ep, M, N, K, st);
+  if (N % 192 == 0 && N % 128 != 0) return launch_nt<Tile<128, 192, 2, 2>, BF16>(al, bl, ep, M, N, K, st);
+  return launch_nt<Tile<128, 128, 2, 2>, BF16>(al, bl, ep, M, N, K, st);
+}
+
+extern "C" int pe_gemm_nt(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
+                          int K, const float* bias0, const float* bias1, int accumulate, void* stream) {
+  return gemm_nt_impl<false>(A, lda, B, ldb, C, ldc, M, N, K, bias0, bias1, accumulate, stream);
+}
+
+extern "C" int pe_gemm_nt_bf16(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M,
+                               int N, int K, const float* bias0, const float* bias1, int accumulate,
+                               void* stream) {
+  return gemm_nt_impl<true>(A, lda, B, ldb, C, ldc, M, N, K, bias0, bias1, accumulate, stream);
 }
 
 extern "C" size_t pe_gemm_tn_workspace_bytes(int M, int N, int K) {

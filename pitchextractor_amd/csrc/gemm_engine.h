@@ -150,6 +150,74 @@ __device__ __forceinline__ void nt_mainloop(AL& al, BL& bl, int K, float* As, fl
   }
 }
 
+// ------------------------------------------------------------------ NT main loop, bf16 operands
+// Opt-in "mixed precision" variant (reference trainer.py:103 autocast): the fp32 operands are rounded
+// to bf16 (RNE, v_cvt_pk_bf16_f32) on their way into LDS and multiplied with
+// v_mfma_f32_32x32x16_bf16; accumulation, epilogue and every tensor in HBM stay fp32.
+// LDS images are [row][40] bf16 (32 + one 16-byte pad): lane (r, h) reads k = 16*kk + 8*h .. +7 of
+// row r with one ds_read_b128, which is exactly the 32x32x16 A/B operand layout.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int kLdsStrideH = kBK + 8;   // in bf16 elements
+
+__device__ __forceinline__ bf16x4 to_bf16x4(const float4& v) {
+  bf16x4 o;
+  o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+  return o;
+}
+
+template <class TL, class AL, class BL>
+__device__ __forceinline__ void nt_mainloop_bf16(AL& al, BL& bl, int K, float* As_f, float* Bs_f,
+                                                 f32x16 (&acc)[TL::TM][TL::TN]) {
+  __bf16* As = reinterpret_cast<__bf16*>(As_f);
+  __bf16* Bs = reinterpret_cast<__bf16*>(Bs_f);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm = wv / TL::WAVES_N, wn = wv % TL::WAVES_N;
+  const int r = lane & 31, h = lane >> 5;
+  const int nk = (K + kBK - 1) / kBK;
+  float4 ra[TL::A_LOADS], rb[TL::B_LOADS];
+#pragma unroll
+  for (int i = 0; i < TL::A_LOADS; ++i) ra[i] = al.load(i, 0);
+#pragma unroll
+  for (int i = 0; i < TL::B_LOADS; ++i) rb[i] = bl.load(i, 0);
+
+  const int st_off = (tid >> 3) * kLdsStrideH + (tid & 7) * 4;
+  const __bf16* a_rd = As + (wm * TL::WM + r) * kLdsStrideH + h * 8;
+  const __bf16* b_rd = Bs + (wn * TL::WN + r) * kLdsStrideH + h * 8;
+
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TL::A_LOADS; ++i)
+      *reinterpret_cast<bf16x4*>(As + st_off + i * 32 * kLdsStrideH) = to_bf16x4(ra[i]);
+#pragma unroll
+    for (int i = 0; i < TL::B_LOADS; ++i)
+      *reinterpret_cast<bf16x4*>(Bs + st_off + i * 32 * kLdsStrideH) = to_bf16x4(rb[i]);
+    __syncthreads();
+    if (kt + 1 < nk) {
+#pragma unroll
+      for (int i = 0; i < TL::A_LOADS; ++i) ra[i] = al.load(i, kt + 1);
+#pragma unroll
+      for (int i = 0; i < TL::B_LOADS; ++i) rb[i] = bl.load(i, kt + 1);
+    }
+#pragma unroll
+    for (int kk = 0; kk < kBK / 16; ++kk) {
+      bf16x8 fa[TL::TM], fb[TL::TN];
+#pragma unroll
+      for (int i = 0; i < TL::TM; ++i)
+        fa[i] = *reinterpret_cast<const bf16x8*>(a_rd + i * 32 * kLdsStrideH + kk * 16);
+#pragma unroll
+      for (int j = 0; j < TL::TN; ++j)
+        fb[j] = *reinterpret_cast<const bf16x8*>(b_rd + j * 32 * kLdsStrideH + kk * 16);
+#pragma unroll
+      for (int i = 0; i < TL::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TL::TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+  }
+}
+
 // Visit every accumulator element of this lane: fn(row_in_tile, col_in_tile, value).
 template <class TL, class FN>
 __device__ __forceinline__ void for_each_acc(const f32x16 (&acc)[TL::TM][TL::TN], FN&& fn) {

@@ -91,6 +91,29 @@ def _s():
     return _lib.stream_ptr()
 
 
+# Opt-in mixed precision (reference trainer.py:103 autocast; config training.mixed_precision): when True the
+# k-contiguous MFMA products (conv forward / data gradient, every gemm_nt) round their operands to bf16
+# on the way into LDS and accumulate in fp32.  Everything in HBM stays fp32; False is the parity mode.
+MATMUL_BF16 = False
+
+
+class matmul_bf16:
+    """``with ops.matmul_bf16(True): ...`` -- the autocast-like scope Trainer.run opens for a mixed-precision step."""
+
+    def __init__(self, enabled=True):
+        self.enabled = bool(enabled)
+
+    def __enter__(self):
+        global MATMUL_BF16
+        self._prev, MATMUL_BF16 = MATMUL_BF16, self.enabled
+        return self
+
+    def __exit__(self, *exc):
+        global MATMUL_BF16
+        MATMUL_BF16 = self._prev
+        return False
+
+
 # ------------------------------------------------------------------ GEMM
 def gemm_nt(A, B, bias0=None, bias1=None, out=None, accumulate=False):
     """out[M,N] = A[M,K] @ B[N,K]^T + bias0 + bias1 (+ out)."""
@@ -105,7 +128,7 @@ def gemm_nt(A, B, bias0=None, bias1=None, out=None, accumulate=False):
     for b in (bias0, bias1):
         if b is not None:
             _chk(_dense(b, "bias").numel() == N, "bias size")
-    _call("pe_gemm_nt", A.data_ptr(), lda, B.data_ptr(), ldb, out.data_ptr(), ldc, M, N, K,
+    _call("pe_gemm_nt_bf16" if MATMUL_BF16 else "pe_gemm_nt", A.data_ptr(), lda, B.data_ptr(), ldb, out.data_ptr(), ldc, M, N, K,
           _lib.ptr(bias0), _lib.ptr(bias1), int(bool(accumulate)), _s(), work=2.0 * M * N * K)
     return out
 
@@ -162,7 +185,7 @@ def conv3x3_fwd(x, w_packed, out=None, accumulate=False):
         _chk(not accumulate, "accumulate needs out")
         out = torch.empty((B, T, F, N), dtype=torch.float32, device=x.device)
     _chk(_dense(out, "out").shape == (B, T, F, N), "conv3x3_fwd: out shape")
-    _call("pe_conv3x3_fwd", x.data_ptr(), w_packed.data_ptr(), out.data_ptr(), B, T, F, Cc, N,
+    _call("pe_conv3x3_fwd_bf16" if MATMUL_BF16 else "pe_conv3x3_fwd", x.data_ptr(), w_packed.data_ptr(), out.data_ptr(), B, T, F, Cc, N,
           int(bool(accumulate)), _s(), work=2.0 * B * T * F * N * 9 * Cc)
     return out
 

@@ -50,14 +50,17 @@ class Trainer(object):
         self.finish_train = False
         self.mel_transform = mel_transform
         self.data_parallel = data_parallel
-        # The reference honours both flags only on an accelerator (trainer.py:63-64,103).  Here fp32 is the
-        # parity mode and 288 GB of HBM holds every activation of a batch-256 step (~20 GB), so both are
-        # accepted and change nothing numerically.
+        # The reference honours both flags only on an accelerator (trainer.py:63-64,103).  mixed_precision
+        # switches the k-contiguous MFMA products (conv forward / data gradient, Linear / LSTM input
+        # projections) to bf16 operands with fp32 accumulation -- the autocast op set minus the weight
+        # gradients and the recurrence, which stay fp32; no GradScaler is needed (bf16 keeps the fp32
+        # exponent).  288 GB of HBM holds every activation of a batch-256 step (~20 GB), so
+        # gradient_checkpointing is accepted and recomputes nothing.
         self.use_amp = bool(use_mixed_precision)
         self.gradient_checkpointing = bool(gradient_checkpointing)
         self.gradient_checkpoint_use_reentrant = checkpoint_use_reentrant
         if self.use_amp:
-            logger.warning("mixed_precision requested: the HIP path computes in fp32 (flag accepted, no-op)")
+            logger.info("mixed_precision: bf16 MFMA operands for conv / linear products, fp32 accumulate and state")
         if self.gradient_checkpointing:
             logger.info("gradient_checkpointing requested: nothing is recomputed on this part (flag accepted, no-op)")
 
@@ -146,9 +149,10 @@ class Trainer(object):
     def run(self, batch):
         self.optimizer.zero_grad(set_to_none=True)
         x, f0, sil = self._inputs(batch)
-        f0_pred, sil_pred = self.model(x.transpose(-1, -2))
-        out3, d_f0, d_sil = self._loss(f0_pred, sil_pred, f0, sil, True)
-        torch.autograd.backward([f0_pred, sil_pred], [d_f0.view_as(f0_pred), d_sil.view_as(sil_pred)])
+        with ops.matmul_bf16(self.use_amp):
+            f0_pred, sil_pred = self.model(x.transpose(-1, -2))
+            out3, d_f0, d_sil = self._loss(f0_pred, sil_pred, f0, sil, True)
+            torch.autograd.backward([f0_pred, sil_pred], [d_f0.view_as(f0_pred), d_sil.view_as(sil_pred)])
         if self.data_parallel is not None:
             self.data_parallel.finish()
         self.optimizer.step()
@@ -177,7 +181,8 @@ class Trainer(object):
     @torch.no_grad()
     def _eval_step(self, batch):
         x, f0, sil = self._inputs(batch)
-        f0_pred, sil_pred = self.model(x.transpose(-1, -2))
+        with ops.matmul_bf16(self.use_amp):
+            f0_pred, sil_pred = self.model(x.transpose(-1, -2))
         out3, _, _ = self._loss(f0_pred, sil_pred, f0, sil, False)
         loss, loss_f0, loss_sil = out3.tolist()
         return {"loss": loss, "f0": loss_f0, "sil": loss_sil}

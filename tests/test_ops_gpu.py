@@ -50,6 +50,32 @@ def test_gemm_nt(hip_device, M, N, K):
     close(ops.gemm_nt(A.to(hip_device), B.to(hip_device), out=out, accumulate=True), ref2)
 
 
+def bf16r(t):      # what the bf16 kernels see: operands rounded to bf16 (RNE), products exact in fp32
+    return t.to(torch.bfloat16).to(torch.float64)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 1536, 384), (1000, 64, 576), (257, 192, 96), (130, 20, 64), (33, 1, 4)])
+def test_gemm_nt_bf16_operands(hip_device, M, N, K):
+    """Mixed-precision variant: equals the fp64 product of the bf16-rounded operands to fp32 accumulation
+    accuracy (1e-5 of scale), and is within bf16 rounding (2^-8 relative per operand) of the fp32 product."""
+    A, B = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    b0 = rnd(N, seed=3)
+    with ops.matmul_bf16(True):
+        got = ops.gemm_nt(A.to(hip_device), B.to(hip_device), bias0=b0.to(hip_device))
+    assert ops.MATMUL_BF16 is False
+    close(got, bf16r(A) @ bf16r(B).T + b0.double())
+    close(got, A.double() @ B.double().T + b0.double(), tol=2e-2)
+
+
+def test_conv3x3_bf16_operands(hip_device):
+    B, T, Fq, Ci, Co = 2, 12, 10, 64, 128
+    x, w = rnd(B, Ci, T, Fq, seed=1), rnd(Co, Ci, 3, 3, seed=2, scale=0.1)
+    wf, _ = ops.conv3x3_repack(w.to(hip_device))
+    with ops.matmul_bf16(True):
+        got = ops.conv3x3_fwd(nhwc(x).to(hip_device), wf)
+    close(nchw(got), F.conv2d(bf16r(x), bf16r(w), padding=1))
+
+
 def test_gemm_nt_strided_rows(hip_device):
     big = rnd(40, 7, 96, seed=6).to(hip_device)              # rows taken at a fixed time step: ld = 7*96
     A = big[:, 3, 32:96]
