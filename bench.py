@@ -108,6 +108,9 @@ def main():
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
                     help="fp32 = BASELINE config[1] (headline); bf16 = training.mixed_precision "
                          "(bf16 MFMA operands, fp32 accumulate/state) = BASELINE configs[2]/[3]")
+    ap.add_argument("--fp32-matmul", choices=["native", "x3"], default=None,
+                    help="fp32 products on v_mfma_f32_32x32x2_f32 (native) or as an exact three-term bf16 split "
+                         "on the bf16 MFMA pipe (x3, fp32-accurate); default: PE_FP32_MATMUL or the library default")
     args = ap.parse_args()
     bf16 = args.precision == "bf16"
 
@@ -119,6 +122,8 @@ def main():
     from pitchextractor_amd.trainer import Trainer
     import torch.distributed as dist
 
+    if args.fp32_matmul:
+        ops.FP32_MATMUL = args.fp32_matmul
     rank, world, local = pdist.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")

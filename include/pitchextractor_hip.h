@@ -82,9 +82,16 @@ int pe_gemm_nt(const float* A, long lda, const float* B, long ldb, float* C, lon
  * bf16 on the way into LDS (v_mfma_f32_32x32x16_bf16), fp32 accumulate, fp32 tensors in HBM. */
 int pe_gemm_nt_bf16(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
                     int K, const float* bias0, const float* bias1, int accumulate, void* stream);
+/* fp32-accurate variant on the bf16 MFMA pipe: each fp32 operand is split exactly into three bf16 terms
+ * (x = hi + mid + lo) and six of the nine cross products are accumulated in fp32; the dropped terms are
+ * below 2^-23 of each product, i.e. under the rounding of an fp32 product.  Same contract as pe_gemm_nt. */
+int pe_gemm_nt_x3(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
+                  int K, const float* bias0, const float* bias1, int accumulate, void* stream);
 size_t pe_gemm_tn_workspace_bytes(int M, int N, int K);
 int pe_gemm_tn(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
                int K, int accumulate, float* workspace, size_t workspace_bytes, void* stream);
+int pe_gemm_tn_x3(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
+                  int K, int accumulate, float* workspace, size_t workspace_bytes, void* stream);
 int pe_transpose2d(const float* in, float* out, int rows, int cols, void* stream);
 
 /* ---- 3x3 / pad 1 convolutions (model.py:23-28,157-161), channels-last -------
@@ -99,9 +106,13 @@ int pe_conv3x3_fwd(const float* x, const float* w_packed, float* y, int B, int T
                    int accumulate, void* stream);
 int pe_conv3x3_fwd_bf16(const float* x, const float* w_packed, float* y, int B, int T, int F, int C, int N,
                         int accumulate, void* stream);   /* bf16 operands, fp32 accumulate (see pe_gemm_nt_bf16) */
+int pe_conv3x3_fwd_x3(const float* x, const float* w_packed, float* y, int B, int T, int F, int C, int N,
+                      int accumulate, void* stream);     /* fp32-accurate, three-term bf16 split (see pe_gemm_nt_x3) */
 size_t pe_conv3x3_wgrad_workspace_bytes(int B, int T, int F, int Cin, int Cout);
 int pe_conv3x3_wgrad(const float* x, const float* dy, float* dw_oihw, int B, int T, int F, int Cin,
                      int Cout, float* workspace, size_t workspace_bytes, void* stream);
+int pe_conv3x3_wgrad_x3(const float* x, const float* dy, float* dw_oihw, int B, int T, int F, int Cin,
+                        int Cout, float* workspace, size_t workspace_bytes, void* stream);
 int pe_conv3x3_c1_fwd(const float* x, long sb, long st, long sf, const float* w_oihw, float* y, int B,
                       int T, int F, void* stream);
 int pe_conv3x3_c1_wgrad(const float* x, long sb, long st, long sf, const float* dy, float* dw_oihw,
@@ -170,6 +181,8 @@ int pe_lstm_bwd_persistent(int ncells, const float* const* whh_t, float* const* 
 size_t pe_lstm_whh_grad_workspace_bytes(int B, int T, int H);
 int pe_lstm_whh_grad(const float* dgates, const float* y, long ldy, float* dwhh, int B, int T, int H,
                      int reverse, float* workspace, size_t workspace_bytes, void* stream);
+int pe_lstm_whh_grad_x3(const float* dgates, const float* y, long ldy, float* dwhh, int B, int T, int H,
+                     int reverse, float* workspace, size_t workspace_bytes, void* stream);   /* three-term bf16 split */
 size_t pe_colsum_workspace_bytes(int cols);
 int pe_colsum(const float* x, long rows, int cols, long ld, float* out0, float* out1, void* workspace,
               size_t workspace_bytes, void* stream);

@@ -50,23 +50,22 @@ struct ConvEpi {
   }
 };
 
-template <class TL, bool BF16>
+template <class TL, int MODE>
 __global__ __launch_bounds__(256) void conv3x3_kernel(ConvLoader<TL::A_LOADS> al, RowLoader bl, ConvEpi ep,
                                                       int K, int tiles_m, int tiles_n) {
-  __shared__ __attribute__((aligned(16))) float As[TL::BM * kLdsStride];
-  __shared__ __attribute__((aligned(16))) float Bs[TL::BN * kLdsStride];
+  __shared__ __attribute__((aligned(16))) float As[TL::BM * nt_row_floats<MODE>()];
+  __shared__ __attribute__((aligned(16))) float Bs[TL::BN * nt_row_floats<MODE>()];
   const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   const int m0 = (tile / tiles_n) * TL::BM, n0 = (tile % tiles_n) * TL::BN;
   al.init(m0);
   bl.init(n0);
   f32x16 acc[TL::TM][TL::TN];
   zero_acc<TL>(acc);
-  if constexpr (BF16) nt_mainloop_bf16<TL>(al, bl, K, As, Bs, acc);
-  else nt_mainloop<TL>(al, bl, K, As, Bs, acc);
+  nt_mainloop_mode<TL, MODE>(al, bl, K, As, Bs, acc);
   for_each_acc<TL>(acc, [&](int r, int c, float v) { ep(m0 + r, n0 + c, v); });
 }
 
-template <class TL, bool BF16>
+template <class TL, int MODE>
 int launch_conv(const float* x, const float* wp, float* y, int B, int T, int F, int C, int N, int accumulate,
                 hipStream_t st) {
   const int rows = B * T * F, K = 9 * C;
@@ -75,7 +74,7 @@ int launch_conv(const float* x, const float* wp, float* y, int B, int T, int F, 
   RowLoader bl{wp, (long)K, N, K, 0};
   ConvEpi ep{y, rows, N, accumulate};
   const int tm = pe_cdiv(rows, TL::BM), tn = pe_cdiv(N, TL::BN);
-  hipLaunchKernelGGL((conv3x3_kernel<TL, BF16>), dim3(tm * tn), dim3(256), 0, st, al, bl, ep, K, tm, tn);
+  hipLaunchKernelGGL((conv3x3_kernel<TL, MODE>), dim3(tm * tn), dim3(256), 0, st, al, bl, ep, K, tm, tn);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }
@@ -212,6 +211,123 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_kernel(const float* __r
     }
   }
   // slab layout: [split][tap][Cout][Cin]
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp) {
+    float* dst = ws + ((long)blockIdx.y * 9 + tp) * Cout * Cin;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int co = m0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+      const int ci = n0 + wn * 32 + r;
+      dst[(long)co * Cin + ci] = acc[tp][q];
+    }
+  }
+}
+
+// The same 9-tap tile on the bf16 MFMA pipe with the exact three-term split (gemm_engine.h): dY and the
+// X windows are staged as three [row][64 + 32 pad] bf16 images each, MFMA fragments (8 consecutive pixels
+// of one channel) come from ds_read_b64_tr_b16, and the border mask becomes a 16-bit AND mask per pixel:
+// Mk16[d][w][k] covers source row k + d of window w for column shift df = d - 1, so the 8 masks of a
+// fragment are one aligned 16-byte read.
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(const float* __restrict__ dy,
+                                                                   const float* __restrict__ x,
+                                                                   float* __restrict__ ws, int T, int F, int Cin,
+                                                                   int Cout, int P, int k_per_split, int tiles_n) {
+  constexpr int ST = 96;                                   // bf16 elements per staged row
+  constexpr int YIMG = kBK * ST, XIMG = 102 * ST;
+  __shared__ __attribute__((aligned(16))) __bf16 Ys[3 * YIMG];
+  __shared__ __attribute__((aligned(16))) __bf16 Xs[3 * XIMG];
+  __shared__ __attribute__((aligned(16))) unsigned short Mk16[9 * kBK];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm = wv >> 1, wn = wv & 1, r = lane & 31, h = lane >> 5;
+  const int g1 = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = (lane & 3) * 4;
+  const int m0 = (blockIdx.x / tiles_n) * 64, n0 = (blockIdx.x % tiles_n) * 64;
+  const int kb = blockIdx.y * k_per_split;
+  const int ke = min(P, kb + k_per_split);
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[tp][q] = 0.f;
+
+  const int c4 = (tid & 15) * 4;
+  float4 ry[2], rx[7];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int k = k0 + (tid >> 4) + 16 * i;
+      ry[i] = k < ke ? *reinterpret_cast<const float4*>(dy + (long)k * Cout + m0 + c4)
+                     : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int wr = (tid >> 4) + 16 * i;
+      rx[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (wr < 102) {
+        const int w = wr / 34, row = wr - w * 34;
+        const long q = (long)k0 + (long)(w - 1) * F + row - 1;
+        if (q >= 0 && q < P) rx[i] = *reinterpret_cast<const float4*>(x + q * Cin + n0 + c4);
+      }
+    }
+  };
+  auto store3 = [&](__bf16* img, int img_elems, int off, const float4& v) {
+    const Split3 sp = split3(v);
+    *reinterpret_cast<uint2*>(img + off) = sp.hi;
+    *reinterpret_cast<uint2*>(img + off + img_elems) = sp.mid;
+    *reinterpret_cast<uint2*>(img + off + 2 * img_elems) = sp.lo;
+  };
+  fetch(kb);
+  const __bf16* a_rd = Ys + (8 * h + q4) * ST + wm * 32 + 16 * g1 + p4;
+  const __bf16* b_rd = Xs + (8 * h + q4) * ST + wn * 32 + 16 * g1 + p4;
+  for (int k0 = kb; k0 < ke; k0 += kBK) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) store3(Ys, YIMG, ((tid >> 4) + 16 * i) * ST + c4, ry[i]);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int wr = (tid >> 4) + 16 * i;
+      if (wr < 102) store3(Xs, XIMG, wr * ST + c4, rx[i]);
+    }
+    if (tid < 102) {                                       // border masks of this k-tile's source rows
+      const int w = tid / 34, row = tid - w * 34;
+      const long q = (long)k0 + (long)(w - 1) * F + row - 1;
+      bool mv[3] = {false, false, false};
+      if (q >= 0 && q < P) {
+        const int fq = (int)(q % F), tq = (int)((q / F) % T);
+        const bool trow = !((w == 2 && tq == 0) || (w == 0 && tq == T - 1));   // dt = w - 1
+        mv[0] = trow && fq != F - 1;                       // df = -1: source column F-1 means the shift wrapped
+        mv[1] = trow;
+        mv[2] = trow && fq != 0;                           // df = +1
+      }
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const int k = row - d;
+        if (k >= 0 && k < kBK) Mk16[(d * 3 + w) * kBK + k] = mv[d] ? 0xffffu : 0u;
+      }
+    }
+    __syncthreads();
+    if (k0 + kBK < ke) fetch(k0 + kBK);
+#pragma unroll
+    for (int kk = 0; kk < kBK / 16; ++kk) {
+      bf16x8 fa[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) fa[c] = tr_fragment(a_rd + c * YIMG + kk * 16 * ST, ST);
+#pragma unroll
+      for (int w = 0; w < 3; ++w)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const uint4 mk = *reinterpret_cast<const uint4*>(Mk16 + (d * 3 + w) * kBK + kk * 16 + 8 * h);
+          bf16x8 fb[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            uint4 v = __builtin_bit_cast(uint4, tr_fragment(b_rd + c * XIMG + (w * 34 + kk * 16 + d) * ST, ST));
+            v.x &= mk.x; v.y &= mk.y; v.z &= mk.z; v.w &= mk.w;
+            fb[c] = __builtin_bit_cast(bf16x8, v);
+          }
+          acc[w * 3 + d] = mfma_split(fa, fb, acc[w * 3 + d]);
+        }
+    }
+  }
 #pragma unroll
   for (int tp = 0; tp < 9; ++tp) {
     float* dst = ws + ((long)blockIdx.y * 9 + tp) * Cout * Cin;
@@ -365,26 +481,31 @@ extern "C" int pe_transpose2d(const float* in, float* out, int rows, int cols, v
   return PE_OK;
 }
 
-template <bool BF16>
+template <int MODE>
 static int conv3x3_fwd_impl(const float* x, const float* w_packed, float* y, int B, int T, int F, int C, int N,
                             int accumulate, void* stream) {
   if (!x || !w_packed || !y || B <= 0 || T <= 0 || F <= 0 || C <= 0 || N <= 0) return PE_E_ARG;
   if ((C % 32) != 0 || (long)B * T * F * (C > N ? C : N) >= (1L << 31)) return PE_E_UNSUPPORTED;
   hipStream_t st = pe_stream(stream);
-  if (N <= 64) return launch_conv<Tile<256, 64, 4, 1>, BF16>(x, w_packed, y, B, T, F, C, N, accumulate, st);
+  if (N <= 64) return launch_conv<Tile<256, 64, 4, 1>, MODE>(x, w_packed, y, B, T, F, C, N, accumulate, st);
   if (N % 192 == 0 && N % 128 != 0)
-    return launch_conv<Tile<128, 192, 2, 2>, BF16>(x, w_packed, y, B, T, F, C, N, accumulate, st);
-  return launch_conv<Tile<128, 128, 2, 2>, BF16>(x, w_packed, y, B, T, F, C, N, accumulate, st);
+    return launch_conv<Tile<128, 192, 2, 2>, MODE>(x, w_packed, y, B, T, F, C, N, accumulate, st);
+  return launch_conv<Tile<128, 128, 2, 2>, MODE>(x, w_packed, y, B, T, F, C, N, accumulate, st);
 }
 
 extern "C" int pe_conv3x3_fwd(const float* x, const float* w_packed, float* y, int B, int T, int F, int C, int N,
                               int accumulate, void* stream) {
-  return conv3x3_fwd_impl<false>(x, w_packed, y, B, T, F, C, N, accumulate, stream);
+  return conv3x3_fwd_impl<kNative>(x, w_packed, y, B, T, F, C, N, accumulate, stream);
 }
 
 extern "C" int pe_conv3x3_fwd_bf16(const float* x, const float* w_packed, float* y, int B, int T, int F, int C,
                                    int N, int accumulate, void* stream) {
-  return conv3x3_fwd_impl<true>(x, w_packed, y, B, T, F, C, N, accumulate, stream);
+  return conv3x3_fwd_impl<kBf16>(x, w_packed, y, B, T, F, C, N, accumulate, stream);
+}
+
+extern "C" int pe_conv3x3_fwd_x3(const float* x, const float* w_packed, float* y, int B, int T, int F, int C,
+                                 int N, int accumulate, void* stream) {
+  return conv3x3_fwd_impl<kSplit>(x, w_packed, y, B, T, F, C, N, accumulate, stream);
 }
 
 extern "C" size_t pe_conv3x3_wgrad_workspace_bytes(int B, int T, int F, int Cin, int Cout) {
@@ -394,8 +515,9 @@ extern "C" size_t pe_conv3x3_wgrad_workspace_bytes(int B, int T, int F, int Cin,
   return (size_t)splits * 9 * Cout * Cin * sizeof(float);
 }
 
-extern "C" int pe_conv3x3_wgrad(const float* x, const float* dy, float* dw_oihw, int B, int T, int F, int Cin,
-                                int Cout, float* workspace, size_t workspace_bytes, void* stream) {
+template <int MODE>
+static int conv3x3_wgrad_impl(const float* x, const float* dy, float* dw_oihw, int B, int T, int F, int Cin,
+                              int Cout, float* workspace, size_t workspace_bytes, void* stream) {
   if (!x || !dy || !dw_oihw || B <= 0 || T <= 0 || F <= 0 || Cin <= 0 || Cout <= 0) return PE_E_ARG;
   if ((Cin & 3) || (Cout & 3)) return PE_E_UNSUPPORTED;
   if (!workspace || workspace_bytes < pe_conv3x3_wgrad_workspace_bytes(B, T, F, Cin, Cout)) return PE_E_WORKSPACE;
@@ -404,8 +526,12 @@ extern "C" int pe_conv3x3_wgrad(const float* x, const float* dy, float* dw_oihw,
   hipStream_t st = pe_stream(stream);
   if (wgrad9_ok(Cout, Cin)) {
     const int P = B * T * F, tn = Cin / 64;
-    hipLaunchKernelGGL(conv3x3_wgrad9_kernel<0>, dim3((Cout / 64) * tn, splits), dim3(256), 0, st, dy, x, workspace, T,
-                       F, Cin, Cout, P, kps, tn);
+    if (MODE == kSplit)
+      hipLaunchKernelGGL(conv3x3_wgrad9_x3_kernel, dim3((Cout / 64) * tn, splits), dim3(256), 0, st, dy, x,
+                         workspace, T, F, Cin, Cout, P, kps, tn);
+    else
+      hipLaunchKernelGGL(conv3x3_wgrad9_kernel<0>, dim3((Cout / 64) * tn, splits), dim3(256), 0, st, dy, x,
+                         workspace, T, F, Cin, Cout, P, kps, tn);
     PE_LAUNCH_CHECK();
     const int n = 9 * Cout * Cin;
     hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(pe_cdiv(n, 256)), dim3(256), 0, st, workspace, dw_oihw,
@@ -413,10 +539,21 @@ extern "C" int pe_conv3x3_wgrad(const float* x, const float* dy, float* dw_oihw,
     PE_LAUNCH_CHECK();
     return PE_OK;
   }
+  // channel counts that are not multiples of 64: per-tap kernels on the native fp32 MFMA in every mode
   if (bm == 64 && bn == 64) return launch_wgrad<64, 64>(x, dy, dw_oihw, workspace, B, T, F, Cin, Cout, splits, kps, st);
   if (bm == 64) return launch_wgrad<64, 128>(x, dy, dw_oihw, workspace, B, T, F, Cin, Cout, splits, kps, st);
   if (bn == 64) return launch_wgrad<128, 64>(x, dy, dw_oihw, workspace, B, T, F, Cin, Cout, splits, kps, st);
   return launch_wgrad<128, 128>(x, dy, dw_oihw, workspace, B, T, F, Cin, Cout, splits, kps, st);
+}
+
+extern "C" int pe_conv3x3_wgrad(const float* x, const float* dy, float* dw_oihw, int B, int T, int F, int Cin,
+                                int Cout, float* workspace, size_t workspace_bytes, void* stream) {
+  return conv3x3_wgrad_impl<kNative>(x, dy, dw_oihw, B, T, F, Cin, Cout, workspace, workspace_bytes, stream);
+}
+
+extern "C" int pe_conv3x3_wgrad_x3(const float* x, const float* dy, float* dw_oihw, int B, int T, int F, int Cin,
+                                   int Cout, float* workspace, size_t workspace_bytes, void* stream) {
+  return conv3x3_wgrad_impl<kSplit>(x, dy, dw_oihw, B, T, F, Cin, Cout, workspace, workspace_bytes, stream);
 }
 
 extern "C" int pe_conv3x3_c1_fwd(const float* x, long sb, long st, long sf, const float* w_oihw, float* y, int B,

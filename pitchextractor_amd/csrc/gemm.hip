@@ -27,38 +27,37 @@ struct StoreEpi {
   }
 };
 
-template <class TL, bool BF16>
+template <class TL, int MODE>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(RowLoader al, RowLoader bl, StoreEpi ep, int K,
                                                       int tiles_m, int tiles_n) {
-  __shared__ __attribute__((aligned(16))) float As[TL::BM * kLdsStride];
-  __shared__ __attribute__((aligned(16))) float Bs[TL::BN * kLdsStride];
+  __shared__ __attribute__((aligned(16))) float As[TL::BM * nt_row_floats<MODE>()];
+  __shared__ __attribute__((aligned(16))) float Bs[TL::BN * nt_row_floats<MODE>()];
   const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   const int m0 = (tile / tiles_n) * TL::BM, n0 = (tile % tiles_n) * TL::BN;
   al.init(m0);
   bl.init(n0);
   f32x16 acc[TL::TM][TL::TN];
   zero_acc<TL>(acc);
-  if constexpr (BF16) nt_mainloop_bf16<TL>(al, bl, K, As, Bs, acc);
-  else nt_mainloop<TL>(al, bl, K, As, Bs, acc);
+  nt_mainloop_mode<TL, MODE>(al, bl, K, As, Bs, acc);
   for_each_acc<TL>(acc, [&](int r, int c, float v) { ep(m0 + r, n0 + c, v); });
 }
 
-template <class TL, bool BF16>
+template <class TL, int MODE>
 int launch_nt(const RowLoader& al, const RowLoader& bl, const StoreEpi& ep, int M, int N, int K,
               hipStream_t st) {
   const int tm = pe_cdiv(M, TL::BM), tn = pe_cdiv(N, TL::BN);
-  hipLaunchKernelGGL((gemm_nt_kernel<TL, BF16>), dim3(tm * tn), dim3(256), 0, st, al, bl, ep, K, tm, tn);
+  hipLaunchKernelGGL((gemm_nt_kernel<TL, MODE>), dim3(tm * tn), dim3(256), 0, st, al, bl, ep, K, tm, tn);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }
 
 // ---- TN with split-K
-template <int BM, int BN>
+template <int BM, int BN, int MODE>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(KRowLoader<BM> al, KRowLoader<BN> bl, float* out,
                                                       long ldo, long split_stride, int M, int N, int K,
                                                       int k_per_split, int tiles_n, int accumulate) {
-  __shared__ __attribute__((aligned(16))) float As[kBK * BM];
-  __shared__ __attribute__((aligned(16))) float Bs[kBK * BN];
+  __shared__ __attribute__((aligned(16))) float As[tn_lds_floats<MODE, BM>()];
+  __shared__ __attribute__((aligned(16))) float Bs[tn_lds_floats<MODE, BN>()];
   const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
   const int kb = blockIdx.y * k_per_split;
   const int ke = min(K, kb + k_per_split);
@@ -71,7 +70,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(KRowLoader<BM> al, KRowLoa
     for (int j = 0; j < BN / 64; ++j)
 #pragma unroll
       for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
-  tn_mainloop<BM, BN>(al, bl, kb, ke, As, Bs, acc);
+  tn_mainloop_mode<MODE, BM, BN>(al, bl, kb, ke, As, Bs, acc);
   float* dst = out + (long)blockIdx.y * split_stride;
   tn_for_each_acc<BM, BN>(acc, [&](int r, int c, float v) {
     const int row = m0 + r, col = n0 + c;
@@ -94,32 +93,33 @@ __global__ void splitk_reduce_kernel(const float* ws, long split_stride, int spl
   *d = accumulate ? *d + s : s;
 }
 
-void tn_plan(int M, int N, int K, int bm, int bn, int* splits, int* k_per_split) {
+void tn_plan(int M, int N, int K, int bm, int bn, int mode, int* splits, int* k_per_split) {
   const int tiles = pe_cdiv(M, bm) * pe_cdiv(N, bn);
-  const int s = pe_pick_splits(tiles, K, 512, 768);      // 256 CUs x 3 resident workgroups
+  // resident workgroups: 3 per CU (native), 2 per CU when the three-term images fill the LDS
+  const int s = pe_pick_splits(tiles, K, 512, mode == kSplit ? 512 : 768);
   int kps = pe_cdiv(K, s);
   kps = (kps + kBK - 1) / kBK * kBK;
   *splits = pe_cdiv(K, kps);
   *k_per_split = kps;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int MODE>
 int launch_tn(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, int K,
               int accumulate, float* ws, size_t ws_bytes, hipStream_t st) {
   int splits, kps;
-  tn_plan(M, N, K, BM, BN, &splits, &kps);
+  tn_plan(M, N, K, BM, BN, MODE, &splits, &kps);
   KRowLoader<BM> al{A, lda, M, 0};
   KRowLoader<BN> bl{B, ldb, N, 0};
   const int tm = pe_cdiv(M, BM), tn = pe_cdiv(N, BN);
   if (splits == 1) {
-    hipLaunchKernelGGL((gemm_tn_kernel<BM, BN>), dim3(tm * tn, 1), dim3(256), 0, st, al, bl, C, ldc, 0L, M, N,
+    hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, MODE>), dim3(tm * tn, 1), dim3(256), 0, st, al, bl, C, ldc, 0L, M, N,
                        K, kps, tn, accumulate);
     PE_LAUNCH_CHECK();
     return PE_OK;
   }
   const size_t need = (size_t)splits * M * N * sizeof(float);
   if (!ws || ws_bytes < need) return PE_E_WORKSPACE;
-  hipLaunchKernelGGL((gemm_tn_kernel<BM, BN>), dim3(tm * tn, splits), dim3(256), 0, st, al, bl, ws, (long)N,
+  hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, MODE>), dim3(tm * tn, splits), dim3(256), 0, st, al, bl, ws, (long)N,
                      (long)M * N, M, N, K, kps, tn, 0);
   PE_LAUNCH_CHECK();
   const long total = (long)M * N;
@@ -133,7 +133,7 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 }  // namespace
 
-template <bool BF16>
+template <int MODE>
 static int gemm_nt_impl(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
                         int K, const float* bias0, const float* bias1, int accumulate, void* stream) {
   if (!A || !B || !C || M < 0 || N < 0 || K <= 0) return PE_E_ARG;
@@ -143,41 +143,62 @@ static int gemm_nt_impl(const float* A, long lda, const float* B, long ldb, floa
   RowLoader bl{B, ldb, N, K, 0};
   StoreEpi ep{C, ldc, bias0, bias1, M, N, accumulate};
   hipStream_t st = pe_stream(stream);
-  if (N <= 32) return launch_nt<Tile<128, 32, 4, 1>, BF16>(al, bl, ep, M, N, K, st);
-  if (N <= 64) return launch_nt<Tile<256, 64, 4, 1>, BF16>(al, bl, ep, M, N, K, st);
-  if (N % 192 == 0 && N % 128 != 0) return launch_nt<Tile<128, 192, 2, 2>, BF16>(al, bl, ep, M, N, K, st);
-  return launch_nt<Tile<128, 128, 2, 2>, BF16>(al, bl, ep, M, N, K, st);
+  if (N <= 32) return launch_nt<Tile<128, 32, 4, 1>, MODE>(al, bl, ep, M, N, K, st);
+  if (N <= 64) return launch_nt<Tile<256, 64, 4, 1>, MODE>(al, bl, ep, M, N, K, st);
+  if (N % 192 == 0 && N % 128 != 0) return launch_nt<Tile<128, 192, 2, 2>, MODE>(al, bl, ep, M, N, K, st);
+  return launch_nt<Tile<128, 128, 2, 2>, MODE>(al, bl, ep, M, N, K, st);
 }
 
 extern "C" int pe_gemm_nt(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
                           int K, const float* bias0, const float* bias1, int accumulate, void* stream) {
-  return gemm_nt_impl<false>(A, lda, B, ldb, C, ldc, M, N, K, bias0, bias1, accumulate, stream);
+  return gemm_nt_impl<kNative>(A, lda, B, ldb, C, ldc, M, N, K, bias0, bias1, accumulate, stream);
 }
 
 extern "C" int pe_gemm_nt_bf16(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M,
                                int N, int K, const float* bias0, const float* bias1, int accumulate,
                                void* stream) {
-  return gemm_nt_impl<true>(A, lda, B, ldb, C, ldc, M, N, K, bias0, bias1, accumulate, stream);
+  return gemm_nt_impl<kBf16>(A, lda, B, ldb, C, ldc, M, N, K, bias0, bias1, accumulate, stream);
+}
+
+extern "C" int pe_gemm_nt_x3(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
+                             int K, const float* bias0, const float* bias1, int accumulate, void* stream) {
+  return gemm_nt_impl<kSplit>(A, lda, B, ldb, C, ldc, M, N, K, bias0, bias1, accumulate, stream);
 }
 
 extern "C" size_t pe_gemm_tn_workspace_bytes(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  int splits, kps;
-  tn_plan(M, N, K, M <= 64 ? 64 : 128, N <= 64 ? 64 : 128, &splits, &kps);
-  return splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
+  size_t need = 0;
+  for (int mode : {kNative, kSplit}) {                   // one size serves pe_gemm_tn and pe_gemm_tn_x3
+    int splits, kps;
+    tn_plan(M, N, K, M <= 64 ? 64 : 128, N <= 64 ? 64 : 128, mode, &splits, &kps);
+    const size_t b = splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
+    need = b > need ? b : need;
+  }
+  return need;
 }
 
-extern "C" int pe_gemm_tn(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
-                          int K, int accumulate, float* workspace, size_t workspace_bytes, void* stream) {
+template <int MODE>
+static int gemm_tn_impl(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
+                        int K, int accumulate, float* workspace, size_t workspace_bytes, void* stream) {
   if (!A || !B || !C || M < 0 || N < 0 || K <= 0) return PE_E_ARG;
   if (M == 0 || N == 0) return PE_OK;
   if ((M & 3) || (N & 3) || (lda & 3) || (ldb & 3) || !aligned16(A) || !aligned16(B)) return PE_E_UNSUPPORTED;
   hipStream_t st = pe_stream(stream);
   if (M <= 64 && N <= 64)
-    return launch_tn<64, 64>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, st);
+    return launch_tn<64, 64, MODE>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, st);
   if (M <= 64)
-    return launch_tn<64, 128>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, st);
+    return launch_tn<64, 128, MODE>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, st);
   if (N <= 64)
-    return launch_tn<128, 64>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, st);
-  return launch_tn<128, 128>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, st);
+    return launch_tn<128, 64, MODE>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, st);
+  return launch_tn<128, 128, MODE>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, st);
+}
+
+extern "C" int pe_gemm_tn(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
+                          int K, int accumulate, float* workspace, size_t workspace_bytes, void* stream) {
+  return gemm_tn_impl<kNative>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, stream);
+}
+
+extern "C" int pe_gemm_tn_x3(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
+                             int K, int accumulate, float* workspace, size_t workspace_bytes, void* stream) {
+  return gemm_tn_impl<kSplit>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, stream);
 }

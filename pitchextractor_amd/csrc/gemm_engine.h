@@ -21,6 +21,10 @@
 namespace pe {
 
 constexpr int kBK = 32;
+// precision modes of the tile engines
+constexpr int kNative = 0;    // v_mfma_f32_32x32x2_f32
+constexpr int kBf16 = 1;      // operands rounded to bf16 (mixed precision; NT engines only)
+constexpr int kSplit = 2;     // fp32 as three bf16 terms, six bf16 MFMAs per product block (fp32-accurate)
 constexpr int kLdsStride = kBK + 4;
 
 template <int BM_, int BN_, int WAVES_M_, int WAVES_N_>
@@ -218,6 +222,127 @@ __device__ __forceinline__ void nt_mainloop_bf16(AL& al, BL& bl, int K, float* A
   }
 }
 
+// ------------------------------------------------------------------ NT main loop, fp32 as three bf16 terms
+// fp32-accurate products on the bf16 MFMA pipe (16x the fp32 MFMA rate on gfx950).  Every fp32 operand
+// is split EXACTLY into three bf16 terms by truncation, x = hi + mid + lo (8 + 8 + 8 significand bits;
+// both subtractions are exact), on its way into LDS.  a*b = sum of 9 exact cross products; the three
+// smallest (mid*lo, lo*mid, lo*lo <= 2^-23 |a*b|, below the rounding of an fp32 product) are dropped and
+// the other six are accumulated in fp32 by v_mfma_f32_32x32x16_bf16, small terms first.
+// LDS: three [row][40] bf16 images per operand.
+constexpr int kSplitRowFloats = 3 * kLdsStrideH / 2;     // floats of LDS per tile row (240 B)
+
+struct Split3 { uint2 hi, mid, lo; };                    // 4 consecutive k of one row, packed bf16 pairs
+
+__device__ __forceinline__ unsigned pack_hi16(float a, float b) {   // {bf16 bits of a, bf16 bits of b} by truncation
+  return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+}
+__device__ __forceinline__ float trunc_bf16(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
+
+__device__ __forceinline__ Split3 split3(const float4& v) {
+  Split3 o;
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  float r1[4], r2[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r1[i] = x[i] - trunc_bf16(x[i]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r2[i] = r1[i] - trunc_bf16(r1[i]);
+  o.hi = make_uint2(pack_hi16(x[0], x[1]), pack_hi16(x[2], x[3]));
+  o.mid = make_uint2(pack_hi16(r1[0], r1[1]), pack_hi16(r1[2], r1[3]));
+  o.lo = make_uint2(pack_hi16(r2[0], r2[1]), pack_hi16(r2[2], r2[3]));
+  return o;
+}
+
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// acc += a * b to fp32 accuracy, a and b given as their three bf16 terms
+__device__ __forceinline__ f32x16 mfma_split(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 c) {
+  c = mfma_bf16(a[2], b[0], c);
+  c = mfma_bf16(a[0], b[2], c);
+  c = mfma_bf16(a[1], b[1], c);
+  c = mfma_bf16(a[1], b[0], c);
+  c = mfma_bf16(a[0], b[1], c);
+  c = mfma_bf16(a[0], b[0], c);
+  return c;
+}
+
+template <class TL, class AL, class BL>
+__device__ __forceinline__ void nt_mainloop_split(AL& al, BL& bl, int K, float* As_f, float* Bs_f,
+                                                  f32x16 (&acc)[TL::TM][TL::TN]) {
+  constexpr int A_IMG = TL::BM * kLdsStrideH, B_IMG = TL::BN * kLdsStrideH;   // bf16 elements per image
+  __bf16* As = reinterpret_cast<__bf16*>(As_f);
+  __bf16* Bs = reinterpret_cast<__bf16*>(Bs_f);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm = wv / TL::WAVES_N, wn = wv % TL::WAVES_N;
+  const int r = lane & 31, h = lane >> 5;
+  const int nk = (K + kBK - 1) / kBK;
+  float4 ra[TL::A_LOADS], rb[TL::B_LOADS];
+#pragma unroll
+  for (int i = 0; i < TL::A_LOADS; ++i) ra[i] = al.load(i, 0);
+#pragma unroll
+  for (int i = 0; i < TL::B_LOADS; ++i) rb[i] = bl.load(i, 0);
+
+  const int st_off = (tid >> 3) * kLdsStrideH + (tid & 7) * 4;
+  const __bf16* a_rd = As + (wm * TL::WM + r) * kLdsStrideH + h * 8;
+  const __bf16* b_rd = Bs + (wn * TL::WN + r) * kLdsStrideH + h * 8;
+
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TL::A_LOADS; ++i) {
+      const Split3 sp = split3(ra[i]);
+      __bf16* d = As + st_off + i * 32 * kLdsStrideH;
+      *reinterpret_cast<uint2*>(d) = sp.hi;
+      *reinterpret_cast<uint2*>(d + A_IMG) = sp.mid;
+      *reinterpret_cast<uint2*>(d + 2 * A_IMG) = sp.lo;
+    }
+#pragma unroll
+    for (int i = 0; i < TL::B_LOADS; ++i) {
+      const Split3 sp = split3(rb[i]);
+      __bf16* d = Bs + st_off + i * 32 * kLdsStrideH;
+      *reinterpret_cast<uint2*>(d) = sp.hi;
+      *reinterpret_cast<uint2*>(d + B_IMG) = sp.mid;
+      *reinterpret_cast<uint2*>(d + 2 * B_IMG) = sp.lo;
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {
+#pragma unroll
+      for (int i = 0; i < TL::A_LOADS; ++i) ra[i] = al.load(i, kt + 1);
+#pragma unroll
+      for (int i = 0; i < TL::B_LOADS; ++i) rb[i] = bl.load(i, kt + 1);
+    }
+#pragma unroll
+    for (int kk = 0; kk < kBK / 16; ++kk) {
+      bf16x8 fa[TL::TM][3], fb[TL::TN][3];
+#pragma unroll
+      for (int i = 0; i < TL::TM; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          fa[i][c] = *reinterpret_cast<const bf16x8*>(a_rd + c * A_IMG + i * 32 * kLdsStrideH + kk * 16);
+#pragma unroll
+      for (int j = 0; j < TL::TN; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          fb[j][c] = *reinterpret_cast<const bf16x8*>(b_rd + c * B_IMG + j * 32 * kLdsStrideH + kk * 16);
+#pragma unroll
+      for (int i = 0; i < TL::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TL::TN; ++j) acc[i][j] = mfma_split(fa[i], fb[j], acc[i][j]);
+    }
+  }
+}
+
+template <int MODE> constexpr int nt_row_floats() { return MODE == kSplit ? kSplitRowFloats : kLdsStride; }
+
+template <class TL, int MODE, class AL, class BL>
+__device__ __forceinline__ void nt_mainloop_mode(AL& al, BL& bl, int K, float* As, float* Bs,
+                                                 f32x16 (&acc)[TL::TM][TL::TN]) {
+  if constexpr (MODE == kBf16) nt_mainloop_bf16<TL>(al, bl, K, As, Bs, acc);
+  else if constexpr (MODE == kSplit) nt_mainloop_split<TL>(al, bl, K, As, Bs, acc);
+  else nt_mainloop<TL>(al, bl, K, As, Bs, acc);
+}
+
 // Visit every accumulator element of this lane: fn(row_in_tile, col_in_tile, value).
 template <class TL, class FN>
 __device__ __forceinline__ void for_each_acc(const f32x16 (&acc)[TL::TM][TL::TN], FN&& fn) {
@@ -375,6 +500,103 @@ __device__ __forceinline__ void tn_mainloop(AL& al, BL& bl, int k_begin, int k_e
         for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(fa[i], fb[j], acc[i][j]);
     }
   }
+}
+
+// ------------------------------------------------------------------ TN main loop, fp32 as three bf16 terms
+// Same exact three-term split as nt_mainloop_split.  The operands are k-major, so the LDS images stay
+// [k][cols (+32 pad)] bf16 and the MFMA fragments (8 consecutive k of one column) come from the gfx950
+// transposed read ds_read_b64_tr_b16: per 16-lane group, lane 4q+p supplies the address of row q,
+// columns 4p..4p+3 of a 4 x 16 block and lane i receives column i of the 4 rows.  With a row stride of
+// cols/2 + 16 dwords the four rows of a half-wave's two blocks fall on disjoint banks.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+template <int COLS> constexpr int tn_split_stride() { return COLS + 32; }                 // bf16 elements per k-row
+template <int COLS> constexpr int tn_split_floats() { return 3 * kBK * tn_split_stride<COLS>() / 2; }
+
+__device__ __forceinline__ s16x4 lds_read_tr(const __bf16* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)(reinterpret_cast<const short*>(p)));
+}
+
+// fragment of 16 k-rows starting at `p` (this lane's block-row address for rows +0..3; rows +4..7 one
+// 4-row block further): elements j = 0..7 <-> k = 8h + j
+__device__ __forceinline__ bf16x8 tr_fragment(const __bf16* p, int stride) {
+  const s16x4 lo = lds_read_tr(p), hi = lds_read_tr(p + 4 * stride);
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int COLS>
+__device__ __forceinline__ void tn_split_store(__bf16* img, int off, const float4& v) {
+  constexpr int IMG = kBK * tn_split_stride<COLS>();
+  const Split3 sp = split3(v);
+  *reinterpret_cast<uint2*>(img + off) = sp.hi;
+  *reinterpret_cast<uint2*>(img + off + IMG) = sp.mid;
+  *reinterpret_cast<uint2*>(img + off + 2 * IMG) = sp.lo;
+}
+
+template <int BM, int BN, class AL, class BL>
+__device__ __forceinline__ void tn_mainloop_split(AL& al, BL& bl, int k_begin, int k_end, float* As_f, float* Bs_f,
+                                                  f32x16 (&acc)[BM / 64][BN / 64]) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int SA = TnGeom<BM>::SLOTS, SB = TnGeom<BN>::SLOTS;
+  constexpr int STA = tn_split_stride<BM>(), STB = tn_split_stride<BN>();
+  constexpr int IMGA = kBK * STA, IMGB = kBK * STB;
+  __bf16* As = reinterpret_cast<__bf16*>(As_f);
+  __bf16* Bs = reinterpret_cast<__bf16*>(Bs_f);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm = wv >> 1, wn = wv & 1;
+  const int h = lane >> 5, g1 = (lane >> 4) & 1, q = (lane & 15) >> 2, p4 = (lane & 3) * 4;
+  float4 ra[SA], rb[SB];
+#pragma unroll
+  for (int i = 0; i < SA; ++i) ra[i] = al.load(i, k_begin, k_end);
+#pragma unroll
+  for (int i = 0; i < SB; ++i) rb[i] = bl.load(i, k_begin, k_end);
+  const int sta = (tid / TnGeom<BM>::TPR) * STA + TnGeom<BM>::col4();
+  const int stb = (tid / TnGeom<BN>::TPR) * STB + TnGeom<BN>::col4();
+  const __bf16* a_rd = As + (8 * h + q) * STA + wm * (BM / 2) + 16 * g1 + p4;
+  const __bf16* b_rd = Bs + (8 * h + q) * STB + wn * (BN / 2) + 16 * g1 + p4;
+  for (int k0 = k_begin; k0 < k_end; k0 += kBK) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < SA; ++i) tn_split_store<BM>(As, sta + i * TnGeom<BM>::ROWS * STA, ra[i]);
+#pragma unroll
+    for (int i = 0; i < SB; ++i) tn_split_store<BN>(Bs, stb + i * TnGeom<BN>::ROWS * STB, rb[i]);
+    __syncthreads();
+    if (k0 + kBK < k_end) {
+#pragma unroll
+      for (int i = 0; i < SA; ++i) ra[i] = al.load(i, k0 + kBK, k_end);
+#pragma unroll
+      for (int i = 0; i < SB; ++i) rb[i] = bl.load(i, k0 + kBK, k_end);
+    }
+#pragma unroll
+    for (int kk = 0; kk < kBK / 16; ++kk) {
+      bf16x8 fa[TM][3], fb[TN][3];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) fa[i][c] = tr_fragment(a_rd + c * IMGA + kk * 16 * STA + i * 32, STA);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) fb[j][c] = tr_fragment(b_rd + c * IMGB + kk * 16 * STB + j * 32, STB);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_split(fa[i], fb[j], acc[i][j]);
+    }
+  }
+}
+
+template <int MODE, int COLS> constexpr int tn_lds_floats() {
+  return MODE == kSplit ? tn_split_floats<COLS>() : kBK * COLS;
+}
+
+template <int MODE, int BM, int BN, class AL, class BL>
+__device__ __forceinline__ void tn_mainloop_mode(AL& al, BL& bl, int k_begin, int k_end, float* As, float* Bs,
+                                                 f32x16 (&acc)[BM / 64][BN / 64]) {
+  if constexpr (MODE == kSplit) tn_mainloop_split<BM, BN>(al, bl, k_begin, k_end, As, Bs, acc);
+  else tn_mainloop<BM, BN>(al, bl, k_begin, k_end, As, Bs, acc);
 }
 
 // ------------------------------------------------------------------ NN main loop (64 x 64 tile)

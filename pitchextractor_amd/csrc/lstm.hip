@@ -193,12 +193,12 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(const BwdCells cells
 }
 
 // ------------------------------------------------------------------ dW_hh = sum_t dgates_t^T h_{t-1}
-template <int BM, int BN>
+template <int BM, int BN, int MODE>
 __global__ __launch_bounds__(256) void lstm_whh_grad_kernel(KRowLoader<BM> al, ShiftedTimeLoader<BN> bl, float* out,
                                                             long ldo, long split_stride, int M, int N, int K,
                                                             int k_per_split, int tiles_n) {
-  __shared__ __attribute__((aligned(16))) float As[kBK * BM];
-  __shared__ __attribute__((aligned(16))) float Bs[kBK * BN];
+  __shared__ __attribute__((aligned(16))) float As[tn_lds_floats<MODE, BM>()];
+  __shared__ __attribute__((aligned(16))) float Bs[tn_lds_floats<MODE, BN>()];
   const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
   const int kb = blockIdx.y * k_per_split;
   const int ke = min(K, kb + k_per_split);
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void lstm_whh_grad_kernel(KRowLoader<BM> al, S
     for (int j = 0; j < BN / 64; ++j)
 #pragma unroll
       for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
-  tn_mainloop<BM, BN>(al, bl, kb, ke, As, Bs, acc);
+  tn_mainloop_mode<MODE, BM, BN>(al, bl, kb, ke, As, Bs, acc);
   float* dst = out + (long)blockIdx.y * split_stride;
   tn_for_each_acc<BM, BN>(acc, [&](int r, int c, float v) {
     const int row = m0 + r, col = n0 + c;
@@ -227,9 +227,9 @@ __global__ void slab_reduce_kernel(const float* ws, long n, int splits, float* o
   out[idx] = s;
 }
 
-void whh_plan(int M, int N, int K, int* splits, int* kps) {
+void whh_plan(int M, int N, int K, int mode, int* splits, int* kps) {
   const int tiles = pe_cdiv(M, 128) * pe_cdiv(N, 128);
-  const int s = pe_pick_splits(tiles, K, 512, 768);
+  const int s = pe_pick_splits(tiles, K, 512, mode == kSplit ? 512 : 768);
   int k = pe_cdiv(K, s);
   k = (k + kBK - 1) / kBK * kBK;
   *kps = k;
@@ -306,19 +306,25 @@ extern "C" int pe_lstm_bwd(int ncells, const float* const* whh_t, float* const* 
 }
 
 extern "C" size_t pe_lstm_whh_grad_workspace_bytes(int B, int T, int H) {
-  int splits, kps;
-  whh_plan(4 * H, H, B * T, &splits, &kps);
-  return (size_t)splits * 4 * H * H * sizeof(float);
+  size_t need = 0;
+  for (int mode : {kNative, kSplit}) {
+    int splits, kps;
+    whh_plan(4 * H, H, B * T, mode, &splits, &kps);
+    const size_t b = (size_t)splits * 4 * H * H * sizeof(float);
+    need = b > need ? b : need;
+  }
+  return need;
 }
 
 // dW_hh[4H][H] = sum_{b,t} dgates[b][t][:]^T . y[b][t -/+ 1][:]   (y = this direction's output slice)
-extern "C" int pe_lstm_whh_grad(const float* dgates, const float* y, long ldy, float* dwhh, int B, int T, int H,
-                                int reverse, float* workspace, size_t workspace_bytes, void* stream) {
+template <int MODE>
+static int whh_grad_impl(const float* dgates, const float* y, long ldy, float* dwhh, int B, int T, int H,
+                         int reverse, float* workspace, size_t workspace_bytes, void* stream) {
   if (!dgates || !y || !dwhh || B <= 0 || T <= 0 || H <= 0) return PE_E_ARG;
   if ((H & 3) || (ldy & 3)) return PE_E_UNSUPPORTED;
   const int M = 4 * H, N = H, K = B * T;
   int splits, kps;
-  whh_plan(M, N, K, &splits, &kps);
+  whh_plan(M, N, K, MODE, &splits, &kps);
   const size_t need = (size_t)splits * M * N * sizeof(float);
   if (!workspace || workspace_bytes < need) return PE_E_WORKSPACE;
   KRowLoader<128> al{dgates, (long)M, M, 0};
@@ -326,13 +332,23 @@ extern "C" int pe_lstm_whh_grad(const float* dgates, const float* y, long ldy, f
   bl.p = y; bl.ld = ldy; bl.T = T; bl.dt = reverse ? 1 : -1; bl.cols = N; bl.col0 = 0;
   const int tm = pe_cdiv(M, 128), tn = pe_cdiv(N, 128);
   hipStream_t st = pe_stream(stream);
-  hipLaunchKernelGGL((lstm_whh_grad_kernel<128, 128>), dim3(tm * tn, splits), dim3(256), 0, st, al, bl, workspace,
-                     (long)N, (long)M * N, M, N, K, kps, tn);
+  hipLaunchKernelGGL((lstm_whh_grad_kernel<128, 128, MODE>), dim3(tm * tn, splits), dim3(256), 0, st, al, bl,
+                     workspace, (long)N, (long)M * N, M, N, K, kps, tn);
   PE_LAUNCH_CHECK();
   const long n = (long)M * N;
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(pe_cdiv(n, 256)), dim3(256), 0, st, workspace, n, splits, dwhh);
   PE_LAUNCH_CHECK();
   return PE_OK;
+}
+
+extern "C" int pe_lstm_whh_grad(const float* dgates, const float* y, long ldy, float* dwhh, int B, int T, int H,
+                                int reverse, float* workspace, size_t workspace_bytes, void* stream) {
+  return whh_grad_impl<kNative>(dgates, y, ldy, dwhh, B, T, H, reverse, workspace, workspace_bytes, stream);
+}
+
+extern "C" int pe_lstm_whh_grad_x3(const float* dgates, const float* y, long ldy, float* dwhh, int B, int T, int H,
+                                   int reverse, float* workspace, size_t workspace_bytes, void* stream) {
+  return whh_grad_impl<kSplit>(dgates, y, ldy, dwhh, B, T, H, reverse, workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t pe_colsum_workspace_bytes(int cols) { return (size_t)kColsumParts * cols * sizeof(double); }

@@ -9,6 +9,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib
@@ -95,6 +97,24 @@ def _s():
 # k-contiguous MFMA products (conv forward / data gradient, every gemm_nt) round their operands to bf16
 # on the way into LDS and accumulate in fp32.  Everything in HBM stays fp32; False is the parity mode.
 MATMUL_BF16 = False
+# How fp32 products run when MATMUL_BF16 is off: "native" = v_mfma_f32_32x32x2_f32, "x3" = exact
+# three-term bf16 split on the bf16 MFMA pipe (fp32-accurate, see include/pitchextractor_hip.h).
+FP32_MATMUL = os.environ.get("PE_FP32_MATMUL", "native")
+
+
+def _tn_suffix():
+    """Weight-gradient / k-major products: fp32-accurate in every mode (native or three-term split)."""
+    _chk(FP32_MATMUL in ("native", "x3"), "ops.FP32_MATMUL must be 'native' or 'x3'")
+    return "_x3" if FP32_MATMUL == "x3" else ""
+
+
+def _nt_suffix():
+    if MATMUL_BF16:
+        return "_bf16"
+    if FP32_MATMUL == "x3":
+        return "_x3"
+    _chk(FP32_MATMUL == "native", "ops.FP32_MATMUL must be 'native' or 'x3'")
+    return ""
 
 
 class matmul_bf16:
@@ -128,7 +148,7 @@ def gemm_nt(A, B, bias0=None, bias1=None, out=None, accumulate=False):
     for b in (bias0, bias1):
         if b is not None:
             _chk(_dense(b, "bias").numel() == N, "bias size")
-    _call("pe_gemm_nt_bf16" if MATMUL_BF16 else "pe_gemm_nt", A.data_ptr(), lda, B.data_ptr(), ldb, out.data_ptr(), ldc, M, N, K,
+    _call("pe_gemm_nt" + _nt_suffix(), A.data_ptr(), lda, B.data_ptr(), ldb, out.data_ptr(), ldc, M, N, K,
           _lib.ptr(bias0), _lib.ptr(bias1), int(bool(accumulate)), _s(), work=2.0 * M * N * K)
     return out
 
@@ -146,7 +166,7 @@ def gemm_tn(A, B, out=None, accumulate=False):
     lib = _lib.load()
     need = lib.pe_gemm_tn_workspace_bytes(M, N, K)
     ws = workspace(need, A.device)
-    _call("pe_gemm_tn", A.data_ptr(), lda, B.data_ptr(), ldb, out.data_ptr(), ldc, M, N, K,
+    _call("pe_gemm_tn" + _tn_suffix(), A.data_ptr(), lda, B.data_ptr(), ldb, out.data_ptr(), ldc, M, N, K,
           int(bool(accumulate)), ws.data_ptr(), ws.numel(), _s(), work=2.0 * M * N * K)
     return out
 
@@ -185,7 +205,7 @@ def conv3x3_fwd(x, w_packed, out=None, accumulate=False):
         _chk(not accumulate, "accumulate needs out")
         out = torch.empty((B, T, F, N), dtype=torch.float32, device=x.device)
     _chk(_dense(out, "out").shape == (B, T, F, N), "conv3x3_fwd: out shape")
-    _call("pe_conv3x3_fwd_bf16" if MATMUL_BF16 else "pe_conv3x3_fwd", x.data_ptr(), w_packed.data_ptr(), out.data_ptr(), B, T, F, Cc, N,
+    _call("pe_conv3x3_fwd" + _nt_suffix(), x.data_ptr(), w_packed.data_ptr(), out.data_ptr(), B, T, F, Cc, N,
           int(bool(accumulate)), _s(), work=2.0 * B * T * F * N * 9 * Cc)
     return out
 
@@ -201,7 +221,7 @@ def conv3x3_wgrad(x, dy, dw):
     _chk(dw.shape == (Co, Ci, 3, 3), "conv3x3_wgrad: dw shape")
     lib = _lib.load()
     ws = workspace(lib.pe_conv3x3_wgrad_workspace_bytes(B, T, F, Ci, Co), x.device)
-    _call("pe_conv3x3_wgrad", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, T, F, Ci, Co,
+    _call("pe_conv3x3_wgrad" + _tn_suffix(), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, T, F, Ci, Co,
           ws.data_ptr(), ws.numel(), _s(), work=2.0 * B * T * F * Co * 9 * Ci)
     return dw
 
@@ -475,7 +495,7 @@ def lstm_whh_grad(dgates, y_slice, dwhh, reverse, B, T, H):
     _chk(_dense(dwhh, "dwhh").shape == (4 * H, H), "dwhh shape")
     lib = _lib.load()
     ws = workspace(lib.pe_lstm_whh_grad_workspace_bytes(B, T, H), dgates.device)
-    _call("pe_lstm_whh_grad", dgates.data_ptr(), ys.data_ptr(), ys.stride(1), dwhh.data_ptr(), B, T, H,
+    _call("pe_lstm_whh_grad" + _tn_suffix(), dgates.data_ptr(), ys.data_ptr(), ys.stride(1), dwhh.data_ptr(), B, T, H,
           int(bool(reverse)), ws.data_ptr(), ws.numel(), _s(), work=2.0 * B * T * 4 * H * H)
     return dwhh
 

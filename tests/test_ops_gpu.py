@@ -38,7 +38,9 @@ def nchw(x):
 # ------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("M,N,K", [(300, 1536, 384), (1000, 64, 576), (257, 192, 96), (130, 20, 64),
                                    (64, 128, 32), (5, 360, 768), (1024, 256, 640), (33, 1, 4)])
-def test_gemm_nt(hip_device, M, N, K):
+@pytest.mark.parametrize("fp32_mode", ["native", "x3"])
+def test_gemm_nt(hip_device, M, N, K, fp32_mode, monkeypatch):
+    monkeypatch.setattr(ops, "FP32_MATMUL", fp32_mode)
     A, B = rnd(M, K, seed=1), rnd(N, K, seed=2)
     b0, b1 = rnd(N, seed=3), rnd(N, seed=4)
     ref = A.double() @ B.double().T
@@ -76,6 +78,26 @@ def test_conv3x3_bf16_operands(hip_device):
     close(nchw(got), F.conv2d(bf16r(x), bf16r(w), padding=1))
 
 
+def test_x3_split_is_as_accurate_as_native_fp32(hip_device):
+    """The three-term bf16 split must not be a precision downgrade: against the fp64 product its error is
+    held to the same bound as the native fp32 MFMA path (and to 2x the native path's own error + 1 ulp-ish
+    slack), on a long-K product with a wide dynamic range."""
+    g = torch.Generator().manual_seed(11)
+    A = torch.randn(512, 4608, generator=g) * torch.exp(torch.randn(512, 4608, generator=g) * 2)
+    B = torch.randn(256, 4608, generator=g) * torch.exp(torch.randn(256, 4608, generator=g) * 2)
+    ref = A.double() @ B.double().T
+    mag = A.double().abs() @ B.double().abs().T                      # condition-free error scale
+    errs = {}
+    for mode in ("native", "x3"):
+        ops.FP32_MATMUL = mode
+        try:
+            got = ops.gemm_nt(A.to(hip_device), B.to(hip_device)).cpu().double()
+        finally:
+            ops.FP32_MATMUL = "native"
+        errs[mode] = ((got - ref).abs() / mag).max().item()
+    assert errs["native"] < 2e-5 and errs["x3"] <= 2 * errs["native"], errs
+
+
 def test_gemm_nt_strided_rows(hip_device):
     big = rnd(40, 7, 96, seed=6).to(hip_device)              # rows taken at a fixed time step: ld = 7*96
     A = big[:, 3, 32:96]
@@ -87,7 +109,9 @@ def test_gemm_nt_strided_rows(hip_device):
 
 
 @pytest.mark.parametrize("K,M,N", [(5000, 64, 64), (3001, 192, 128), (777, 1536, 96), (20000, 128, 64), (64, 4, 8)])
-def test_gemm_tn(hip_device, K, M, N):
+@pytest.mark.parametrize("fp32_mode", ["native", "x3"])
+def test_gemm_tn(hip_device, K, M, N, fp32_mode, monkeypatch):
+    monkeypatch.setattr(ops, "FP32_MATMUL", fp32_mode)
     A, B = rnd(K, M, seed=1), rnd(K, N, seed=2)
     ref = A.double().T @ B.double()
     close(ops.gemm_tn(A.to(hip_device), B.to(hip_device)), ref)
@@ -109,7 +133,9 @@ def test_transpose2d(hip_device):
 # ------------------------------------------------------------------ conv
 @pytest.mark.parametrize("B,T,Fq,Ci,Co", [(2, 12, 10, 64, 64), (1, 9, 7, 64, 128), (2, 5, 20, 128, 192),
                                           (1, 6, 10, 192, 256), (1, 4, 5, 256, 256), (3, 16, 40, 128, 128)])
-def test_conv3x3_fwd_dgrad_wgrad(hip_device, B, T, Fq, Ci, Co):
+@pytest.mark.parametrize("fp32_mode", ["native", "x3"])
+def test_conv3x3_fwd_dgrad_wgrad(hip_device, B, T, Fq, Ci, Co, fp32_mode, monkeypatch):
+    monkeypatch.setattr(ops, "FP32_MATMUL", fp32_mode)
     x = rnd(B, Ci, T, Fq, seed=1).double().requires_grad_(True)
     w = rnd(Co, Ci, 3, 3, seed=2, scale=0.1).double().requires_grad_(True)
     y = F.conv2d(x, w, padding=1)
