@@ -52,12 +52,13 @@ def host_cores():
     return max(1, min(n, 32))
 
 
-def pmc_traffic():
+def pmc_traffic(conv_key="pe_conv3x3_fwd"):
     """HBM bytes per conv3x3_kernel launch from the committed rocprofv3 --pmc passes (separate runs of
-    this same command; FETCH_SIZE doubled per the gfx950 correction) -- None when absent."""
+    this same command; FETCH_SIZE doubled per the gfx950 correction) -- None when absent for this mode."""
+    entry = {"pe_conv3x3_fwd": "conv3x3_kernel_all_tiles", "pe_conv3x3_fwd_x3": "conv3x3_kernel_x3"}.get(conv_key)
     try:
         d = json.loads((ROOT / "profiles" / "pmc_r01_traffic.json").read_text())
-        return d["conv3x3_kernel_all_tiles"]["hbm_bytes_per_launch"]
+        return d[entry]["hbm_bytes_per_launch"]
     except Exception:
         return None
 
@@ -188,14 +189,23 @@ def main():
         ms = elapsed / args.steps * 1e3
         frames = args.batch * world * FRAMES * args.steps
         summ = timer.summary()
-        conv = summ.get("pe_conv3x3_fwd_bf16" if bf16 else "pe_conv3x3_fwd")
+        x3 = ops.FP32_MATMUL == "x3"
+        conv_key = "pe_conv3x3_fwd" + ("_bf16" if bf16 else "_x3" if x3 else "")
+        conv = summ.get(conv_key)
         roof = None
         if conv:
-            tflops = conv["work"] / (conv["total_ms"] * 1e-3) / 1e12
-            peak = MFMA_BF16_PEAK_TFLOPS if bf16 else MFMA_F32_PEAK_TFLOPS
+            tflops = conv["work"] / (conv["total_ms"] * 1e-3) / 1e12        # algorithmic 2*M*N*K per launch
+            if bf16:
+                peak, note = MFMA_BF16_PEAK_TFLOPS, "bf16 dense MFMA peak"
+            elif x3:
+                peak, note = MFMA_BF16_PEAK_TFLOPS / 6.0, ("fp32 product = 6 bf16 MFMAs (exact 3-term split): "
+                                                           "bf16 dense MFMA peak / 6; the native fp32 MFMA peak "
+                                                           f"is {MFMA_F32_PEAK_TFLOPS} TFLOP/s")
+            else:
+                peak, note = MFMA_F32_PEAK_TFLOPS, "fp32 MFMA (32x32x2) peak"
             roof = {"bound": "mfma", "kernel": "conv3x3_kernel (implicit-GEMM fwd + dgrad launches)",
-                    "achieved": tflops, "peak": peak, "unit": "TFLOP/s",
-                    "frac": tflops / peak, "traffic": None if bf16 else pmc_traffic(),
+                    "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak,
+                    "peak_note": note, "traffic": pmc_traffic(conv_key),
                     "avg_launch_ms": conv["avg_ms"], "launches_per_step": conv["calls"] / args.steps}
         families = {k: {"ms_per_step": v["total_ms"] / args.steps,
                         "tflops": (v["work"] / (v["total_ms"] * 1e-3) / 1e12) if v["work"] else None}
@@ -206,7 +216,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
             "config": {"workload": (("BASELINE config[2]: batch" if args.head == "transformer" else "BASELINE config[3] per-GPU shape: batch") if bf16 else "BASELINE config[1]: batch") + "=256/GPU, 24 kHz 2 s synthetic glides "
-                                   f"(161 real frames zero-padded to 192), JDCNet+{'BiLSTM(4x384)' if args.head == 'bilstm' else 'Transformer(4 layers, 8 heads, ff 1536)'}, " + ("mixed precision (bf16 conv/linear operands, fp32 accumulate), " if bf16 else "fp32, ") +
+                                   f"(161 real frames zero-padded to 192), JDCNet+{'BiLSTM(4x384)' if args.head == 'bilstm' else 'Transformer(4 layers, 8 heads, ff 1536)'}, " + ("mixed precision (bf16 conv/linear operands, fp32 accumulate), " if bf16 else f"fp32 (products: {ops.FP32_MATMUL}), ") +
                                    "raw audio resident in HBM -> mel -> fwd -> loss -> bwd -> AdamW",
                        "global_batch": args.batch * world, "frames_per_utterance": FRAMES,
                        "real_frames_per_utterance": 161, "parallelism": f"dp{world}"},

@@ -234,6 +234,102 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a, co
   }
 }
 
+// Window form of the two backward passes for POOL in {1, 2, 4}: one thread owns a whole pool window of a
+// channel quad, so x is read exactly once per pass (float4, coalesced along C), the arg-max is found once
+// and only one 64-bit division is paid per window.  Item w of a row is window w for w < Fout, plus one
+// trailing item for the floor-mode remainder pixels (dz = 0, but they count in the means and get a dx).
+template <int POOL>
+struct BnWindow {
+  float4 v[POOL], dz[POOL];
+  long p0;       // first input pixel of the item
+  int n;         // pixels in it
+};
+
+template <int POOL>
+__device__ __forceinline__ void bn_window(const BnBwdArgs& a, long item, int nwin, int c, BnWindow<POOL>& w) {
+  const int Fout = a.Fin / POOL;
+  const long row = item / nwin;
+  const int wi = (int)(item - row * nwin);
+  const bool real = wi < Fout;
+  w.n = real ? POOL : a.Fin - Fout * POOL;
+  w.p0 = row * a.Fin + (long)wi * POOL;
+  const float* xp = a.x + w.p0 * a.C + c;
+#pragma unroll
+  for (int j = 0; j < POOL; ++j) {
+    w.v[j] = j < w.n ? *reinterpret_cast<const float4*>(xp + (long)j * a.C) : make_float4(0.f, 0.f, 0.f, 0.f);
+    w.dz[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (!real) return;
+  const float4 dyv = *reinterpret_cast<const float4*>(a.dy + (row * Fout + wi) * a.lddy + a.coff + c);
+  const float4 sc = *reinterpret_cast<const float4*>(a.scale + c);
+  const float4 sh = *reinterpret_cast<const float4*>(a.shift + c);
+  const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+  const float dys[4] = {dyv.x, dyv.y, dyv.z, dyv.w};
+#pragma unroll
+  for (int ch = 0; ch < 4; ++ch) {
+    float best = lrelu(fmaf(reinterpret_cast<const float*>(&w.v[0])[ch], scv[ch], shv[ch]), a.slope);
+    int arg = 0;
+#pragma unroll
+    for (int j = 1; j < POOL; ++j) {
+      const float act = lrelu(fmaf(reinterpret_cast<const float*>(&w.v[j])[ch], scv[ch], shv[ch]), a.slope);
+      if (act > best) { best = act; arg = j; }               // first maximum wins (torch max_pool2d backward)
+    }
+    const float g = best > 0.f ? dys[ch] : dys[ch] * a.slope;  // sign(lrelu(z)) == sign(z)
+#pragma unroll
+    for (int j = 0; j < POOL; ++j) reinterpret_cast<float*>(&w.dz[j])[ch] = j == arg ? g : 0.f;
+  }
+}
+
+template <int POOL>
+__global__ __launch_bounds__(256) void bn_bwd_partial_win_kernel(const BnBwdArgs a, long n_items, int nwin,
+                                                                 double* __restrict__ partial) {
+  column_reduce2(
+      [&](long item, int c, float4& s, float4& t) {
+        BnWindow<POOL> w;
+        bn_window<POOL>(a, item, nwin, c, w);
+        const float4 mu = *reinterpret_cast<const float4*>(a.mean + c);
+        const float4 is = *reinterpret_cast<const float4*>(a.invstd + c);
+        s = make_float4(0.f, 0.f, 0.f, 0.f);
+        t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < POOL; ++j) {                      // one dz per channel is non-zero: plain fp32 sums are exact
+          s.x += w.dz[j].x; s.y += w.dz[j].y; s.z += w.dz[j].z; s.w += w.dz[j].w;
+          t.x += w.dz[j].x * ((w.v[j].x - mu.x) * is.x); t.y += w.dz[j].y * ((w.v[j].y - mu.y) * is.y);
+          t.z += w.dz[j].z * ((w.v[j].z - mu.z) * is.z); t.w += w.dz[j].w * ((w.v[j].w - mu.w) * is.w);
+        }
+      },
+      n_items, a.C, partial);
+}
+
+template <int POOL>
+__global__ __launch_bounds__(256) void bn_bwd_apply_win_kernel(const BnBwdArgs a, long n_items, int nwin,
+                                                               const float* __restrict__ c1,
+                                                               const float* __restrict__ c2, float* __restrict__ dx) {
+  const int quads = a.C >> 2;
+  const long total = n_items * quads;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long item = i / quads;
+    const int c = (int)(i - item * quads) * 4;
+    BnWindow<POOL> w;
+    bn_window<POOL>(a, item, nwin, c, w);
+    const float4 mu = *reinterpret_cast<const float4*>(a.mean + c);
+    const float4 is = *reinterpret_cast<const float4*>(a.invstd + c);
+    const float4 sc = *reinterpret_cast<const float4*>(a.scale + c);
+    const float4 k1 = *reinterpret_cast<const float4*>(c1 + c);
+    const float4 k2 = *reinterpret_cast<const float4*>(c2 + c);
+#pragma unroll
+    for (int j = 0; j < POOL; ++j) {
+      if (j >= w.n) break;
+      float4 o;
+      o.x = sc.x * (w.dz[j].x - k1.x - (w.v[j].x - mu.x) * is.x * k2.x);
+      o.y = sc.y * (w.dz[j].y - k1.y - (w.v[j].y - mu.y) * is.y * k2.y);
+      o.z = sc.z * (w.dz[j].z - k1.z - (w.v[j].z - mu.z) * is.z * k2.z);
+      o.w = sc.w * (w.dz[j].w - k1.w - (w.v[j].w - mu.w) * is.w * k2.w);
+      *reinterpret_cast<float4*>(dx + (w.p0 + j) * a.C + c) = o;
+    }
+  }
+}
+
 // ---------------------------------------------------------------- plain MaxPool(1,k) (detector taps)
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                           long n_out_pix, int Fin, int C, int pool, long ldy,
@@ -447,13 +543,31 @@ extern "C" int pe_bn_act_pool_bwd(const float* x, const float* dy, const float* 
   double* partial = reinterpret_cast<double*>(workspace);
   float* c1 = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + pe_bn_workspace_bytes(C));
   float* c2 = c1 + C;
-  const int grid = reduce_grid(a.n_in_pix, C);
-  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(grid), dim3(256), reduce_lds(C), st, a, partial);
+  const int nwin = Fin / pool + (Fin % pool ? 1 : 0);
+  const long n_items = rows * nwin;
+  const bool win = pool == 1 || pool == 2 || pool == 4;
+  const int grid = reduce_grid(win ? n_items : a.n_in_pix, C);
+  if (pool == 1)
+    hipLaunchKernelGGL(bn_bwd_partial_win_kernel<1>, dim3(grid), dim3(256), reduce_lds(C), st, a, n_items, nwin, partial);
+  else if (pool == 2)
+    hipLaunchKernelGGL(bn_bwd_partial_win_kernel<2>, dim3(grid), dim3(256), reduce_lds(C), st, a, n_items, nwin, partial);
+  else if (pool == 4)
+    hipLaunchKernelGGL(bn_bwd_partial_win_kernel<4>, dim3(grid), dim3(256), reduce_lds(C), st, a, n_items, nwin, partial);
+  else
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(grid), dim3(256), reduce_lds(C), st, a, partial);
   PE_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pe_cdiv(C, 4)), dim3(256), 0, st, partial, grid, a.n_in_pix, C,
                      dgamma, dbeta, c1, c2);
   PE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(a.n_in_pix * (C / 4))), dim3(256), 0, st, a, c1, c2, dx);
+  const int agrid = ew_grid((win ? n_items : a.n_in_pix) * (C / 4));
+  if (pool == 1)
+    hipLaunchKernelGGL(bn_bwd_apply_win_kernel<1>, dim3(agrid), dim3(256), 0, st, a, n_items, nwin, c1, c2, dx);
+  else if (pool == 2)
+    hipLaunchKernelGGL(bn_bwd_apply_win_kernel<2>, dim3(agrid), dim3(256), 0, st, a, n_items, nwin, c1, c2, dx);
+  else if (pool == 4)
+    hipLaunchKernelGGL(bn_bwd_apply_win_kernel<4>, dim3(agrid), dim3(256), 0, st, a, n_items, nwin, c1, c2, dx);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(agrid), dim3(256), 0, st, a, c1, c2, dx);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }

@@ -97,9 +97,12 @@ def _s():
 # k-contiguous MFMA products (conv forward / data gradient, every gemm_nt) round their operands to bf16
 # on the way into LDS and accumulate in fp32.  Everything in HBM stays fp32; False is the parity mode.
 MATMUL_BF16 = False
-# How fp32 products run when MATMUL_BF16 is off: "native" = v_mfma_f32_32x32x2_f32, "x3" = exact
-# three-term bf16 split on the bf16 MFMA pipe (fp32-accurate, see include/pitchextractor_hip.h).
-FP32_MATMUL = os.environ.get("PE_FP32_MATMUL", "native")
+# How fp32 products run (always, for the weight-gradient products; when MATMUL_BF16 is off for the rest):
+#   "x3"     every fp32 operand is split exactly into three bf16 terms and six cross products are
+#            accumulated in fp32 on the bf16 MFMA pipe (16x the fp32 MFMA rate on gfx950); measured
+#            error against fp64 is the same as the native path's (tests/test_ops_gpu.py).  Default.
+#   "native" v_mfma_f32_32x32x2_f32.
+FP32_MATMUL = os.environ.get("PE_FP32_MATMUL", "x3")
 
 
 def _tn_suffix():

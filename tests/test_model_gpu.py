@@ -1,9 +1,10 @@
 """JDCNet on the HIP path vs the functional CPU oracle / the reference's golden vectors.
 
 Tolerances: the oracle side is float64 (exact to ~1e-9 against the reference, see
-tests/test_oracle_golden.py), the HIP side is fp32 MFMA (exact-f32 fmaf chains).  Outputs are held
-to 1e-4 of their scale (north_star), per-parameter gradient norms to 2e-3 and the 100-step loss
-curve to 1e-3 relative.
+tests/test_oracle_golden.py), the HIP side is fp32.  Outputs are held to 1e-4 of their scale
+(north_star), per-parameter gradient norms to 2e-3 and the 100-step loss curve to 1e-3 relative.
+The golden comparisons run in both fp32 product modes -- "x3" (default: exact three-term bf16 split on
+the bf16 MFMA pipe) and "native" (v_mfma_f32_32x32x2_f32) -- at the same tolerances.
 """
 import logging
 
@@ -12,6 +13,7 @@ import pytest
 import torch
 
 from oracle import model_ref
+from pitchextractor_amd import ops
 from pitchextractor_amd.model import JDCNet
 from pitchextractor_amd.optimizers import build_optimizer
 from pitchextractor_amd.trainer import Trainer
@@ -50,8 +52,10 @@ def test_state_dict_layout_matches_reference(G, hip_device):
     assert all(p.data_ptr() >= net.flat_parameters.data_ptr() for p in net.parameters())
 
 
+@pytest.mark.parametrize("fp32_mode", ["x3", "native"])
 @pytest.mark.parametrize("tag,nc,hidden", [("nc1", 1, 384), ("nc360", 360, 64)])
-def test_eval_forward_matches_reference_golden(G, hip_device, tag, nc, hidden):
+def test_eval_forward_matches_reference_golden(G, hip_device, tag, nc, hidden, fp32_mode, monkeypatch):
+    monkeypatch.setattr(ops, "FP32_MATMUL", fp32_mode)
     net = build(model_ref.seeded_state(11, num_class=nc, hidden_size=hidden), nc, hidden, hip_device).eval()
     with torch.no_grad():
         cls, det = net(golden_input(3).to(hip_device))
@@ -60,18 +64,21 @@ def test_eval_forward_matches_reference_golden(G, hip_device, tag, nc, hidden):
     close(det, G[f"{tag}_eval_det"], 1e-4)
 
 
-@pytest.fixture(scope="module")
-def train_pass(hip_device):
-    net = build(model_ref.seeded_state(11), 1, 384, hip_device).train()
-    net.block_dropout = 0.0
-    net.keep_last_context = True
-    x = golden_input(3).to(hip_device)
-    f0, sil = (t.to(hip_device) for t in golden_targets(3))
-    cls, det = net(x)
-    from pitchextractor_amd import ops
-    out3, d_f0, d_sil = ops.f0_sil_loss(cls.detach().reshape(-1), f0.reshape(-1), det.detach().reshape(-1),
-                                        sil.reshape(-1), 0.1)
-    torch.autograd.backward([cls, det], [d_f0.view_as(cls), d_sil.view_as(det)])
+@pytest.fixture(scope="module", params=["x3", "native"])
+def train_pass(hip_device, request):
+    prev, ops.FP32_MATMUL = ops.FP32_MATMUL, request.param
+    try:
+        net = build(model_ref.seeded_state(11), 1, 384, hip_device).train()
+        net.block_dropout = 0.0
+        net.keep_last_context = True
+        x = golden_input(3).to(hip_device)
+        f0, sil = (t.to(hip_device) for t in golden_targets(3))
+        cls, det = net(x)
+        out3, d_f0, d_sil = ops.f0_sil_loss(cls.detach().reshape(-1), f0.reshape(-1), det.detach().reshape(-1),
+                                            sil.reshape(-1), 0.1)
+        torch.autograd.backward([cls, det], [d_f0.view_as(cls), d_sil.view_as(det)])
+    finally:
+        ops.FP32_MATMUL = prev
     return net, cls, det, out3
 
 
