@@ -79,6 +79,183 @@ int launch_conv(const float* x, const float* wp, float* y, int B, int T, int F, 
   return PE_OK;
 }
 
+// ---------------------------------------------------------------- forward / dgrad without im2col re-reads
+// The implicit-GEMM kernel above fetches every input pixel nine times (once per tap); with ~100 KB of
+// distinct rows in flight per tile the XCD's 4 MB L2 does not absorb that (PMC: 2.5-4x the algorithmic
+// bytes reach the fabric).  This kernel stages, per 32-channel chunk, the whole input window of its 128
+// output pixels once -- the 128 + 2F + 2 consecutive pixels [p0 - F - 1, p0 + 128 + F] -- and lets the nine
+// taps read it at nine row offsets; only the weights change per tap.  A neighbour that the flat offset
+// takes across an image border (other time row / other utterance) is masked per output pixel and tap.
+//
+// bf16-term images in LDS are [row][32 k] with NO padding: the 16-byte chunk c of a row sits at chunk
+// c ^ ((row >> 2) & 3), which keeps ds_read_b128 fragment reads (32 consecutive rows at any offset) and the
+// ds_write_b64 staging stores conflict-free (MI355X_MICROARCH.md, LDS lane groups).  NT = 3 images per
+// operand for the exact three-term split, 1 for mixed precision.
+// PASSES = staged window rows / 32: 7 (F <= 47) for the wide tiles, 10 (F <= 95) for the 64-channel layers.
+
+__device__ __forceinline__ int swz_off(int row, int chunk) {        // in bf16 elements
+  return row * 32 + ((chunk ^ ((row >> 2) & 3)) << 3);
+}
+
+template <int NT>
+__device__ __forceinline__ void halo_store(__bf16* img, int img_elems, int row, int piece, const float4& v) {
+  const int off = swz_off(row, piece >> 1) + (piece & 1) * 4;
+  if constexpr (NT == 3) {
+    const Split3 sp = split3(v);
+    *reinterpret_cast<uint2*>(img + off) = sp.hi;
+    *reinterpret_cast<uint2*>(img + off + img_elems) = sp.mid;
+    *reinterpret_cast<uint2*>(img + off + 2 * img_elems) = sp.lo;
+  } else {
+    *reinterpret_cast<bf16x4*>(img + off) = to_bf16x4(v);
+  }
+}
+
+template <int BN, int MODE, int PASSES>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ wp, ConvEpi ep, int T, int F,
+                                                              int C, int N, int P, int tiles_m, int tiles_n) {
+  constexpr int NT = MODE == kSplit ? 3 : 1;
+  constexpr int TM = 2, TN = BN / 64, WN = BN / 2;
+  constexpr int AIMG = PASSES * 32 * 32, BIMG = BN * 32;           // bf16 elements per image
+  constexpr int BL = BN / 32;                                      // weight float4 per thread per stage
+  __shared__ __attribute__((aligned(16))) __bf16 As[NT * AIMG];
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[NT * BIMG];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm = wv >> 1, wn = wv & 1, r = lane & 31, h = lane >> 5;
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int p0 = (tile / tiles_n) * 128, n0 = (tile % tiles_n) * BN;
+  const int WR = 128 + 2 * F + 2;                                  // window rows actually used
+  const int srow = tid >> 3, piece = tid & 7;                      // staging assignment: 8 threads per row
+  const int K = 9 * C, nchunks = C / 32;
+
+  // tap validity of this lane's two output pixels: bit tap of vbits[i]
+  unsigned vbits[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int p = p0 + wm * 64 + i * 32 + r;
+    unsigned b = 0;
+    if (p < P) {
+      const int f = p % F, t = (p / F) % T;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int tt = t + tap / 3 - 1, ff = f + tap % 3 - 1;
+        if (tt >= 0 && tt < T && ff >= 0 && ff < F) b |= 1u << tap;
+      }
+    }
+    vbits[i] = b;
+  }
+
+  float4 ra[PASSES], rb[BL];
+  auto fetch_a = [&](int cc) {
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int wr = ps * 32 + srow;
+      const long q = (long)p0 - F - 1 + wr;
+      ra[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (wr < WR && q >= 0 && q < P) ra[ps] = *reinterpret_cast<const float4*>(x + q * C + cc * 32 + piece * 4);
+    }
+  };
+  auto fetch_b = [&](int stage) {                                  // stage = cc * 9 + tap
+    const int cc = stage / 9, tap = stage - cc * 9;
+    const int k0 = tap * C + cc * 32 + piece * 4;
+#pragma unroll
+    for (int i = 0; i < BL; ++i) {
+      const int n = n0 + i * 32 + srow;
+      rb[i] = n < N ? *reinterpret_cast<const float4*>(wp + (long)n * K + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
+
+  fetch_a(0);
+  fetch_b(0);
+  const int nstages = nchunks * 9;
+  for (int cc = 0; cc < nchunks; ++cc) {
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+      const int stage = cc * 9 + tap;
+      __syncthreads();
+      if (tap == 0) {
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) halo_store<NT>(As, AIMG, ps * 32 + srow, piece, ra[ps]);
+      }
+#pragma unroll
+      for (int i = 0; i < BL; ++i) halo_store<NT>(Bs, BIMG, i * 32 + srow, piece, rb[i]);
+      __syncthreads();
+      if (stage + 1 < nstages) fetch_b(stage + 1);
+      if (tap == 0 && cc + 1 < nchunks) fetch_a(cc + 1);
+      const int shift = (tap / 3) * F + tap % 3;                   // (F + 1) + (dt * F + df)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 fa[TM][NT], fb[TN][NT];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int row = wm * 64 + i * 32 + r + shift;
+          const unsigned m = (vbits[i] >> tap) & 1u ? 0xffffffffu : 0u;
+#pragma unroll
+          for (int c = 0; c < NT; ++c) {
+            uint4 v = *reinterpret_cast<const uint4*>(As + c * AIMG + swz_off(row, kk * 2 + h));
+            v.x &= m; v.y &= m; v.z &= m; v.w &= m;
+            fa[i][c] = __builtin_bit_cast(bf16x8, v);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int row = wn * WN + j * 32 + r;
+#pragma unroll
+          for (int c = 0; c < NT; ++c)
+            fb[j][c] = *reinterpret_cast<const bf16x8*>(Bs + c * BIMG + swz_off(row, kk * 2 + h));
+        }
+        if constexpr (NT == 3) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = mfma_split(fa[i], fb[j], acc[i][j]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(fa[i][0], fb[j][0], acc[i][j]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int g = 0; g < 16; ++g)
+        ep(p0 + wm * 64 + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * h, n0 + wn * WN + j * 32 + r, acc[i][j][g]);
+}
+
+template <int BN, int MODE, int PASSES>
+int launch_conv_halo(const float* x, const float* wp, float* y, int B, int T, int F, int C, int N, int accumulate,
+                     hipStream_t st) {
+  const int P = B * T * F;
+  ConvEpi ep{y, P, N, accumulate};
+  const int tm = pe_cdiv(P, 128), tn = pe_cdiv(N, BN);
+  hipLaunchKernelGGL((conv3x3_halo_kernel<BN, MODE, PASSES>), dim3(tm * tn), dim3(256), 0, st, x, wp, ep, T, F, C, N, P, tm,
+                     tn);
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+
+// which staged-window variant serves (F, N): 7 passes + a 128/192-wide tile, 10 passes + a 64-wide tile
+// (two workgroups per CU must fit the LDS), or 0 = use the implicit-GEMM kernel
+int conv_halo_passes(int F, int N) {
+  const int wr = 128 + 2 * F + 2;
+  if (wr <= 7 * 32 && N >= 96) return 7;
+  if (wr <= 10 * 32 && N <= 64) return 10;
+  return 0;
+}
+
 // ---------------------------------------------------------------- weight gradient
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
@@ -487,6 +664,15 @@ static int conv3x3_fwd_impl(const float* x, const float* w_packed, float* y, int
   if (!x || !w_packed || !y || B <= 0 || T <= 0 || F <= 0 || C <= 0 || N <= 0) return PE_E_ARG;
   if ((C % 32) != 0 || (long)B * T * F * (C > N ? C : N) >= (1L << 31)) return PE_E_UNSUPPORTED;
   hipStream_t st = pe_stream(stream);
+  if constexpr (MODE != kNative) {
+    const int passes = conv_halo_passes(F, N);
+    if (passes == 10) return launch_conv_halo<64, MODE, 10>(x, w_packed, y, B, T, F, C, N, accumulate, st);
+    if (passes == 7) {
+      if (N % 192 == 0 && N % 128 != 0)
+        return launch_conv_halo<192, MODE, 7>(x, w_packed, y, B, T, F, C, N, accumulate, st);
+      return launch_conv_halo<128, MODE, 7>(x, w_packed, y, B, T, F, C, N, accumulate, st);
+    }
+  }
   if (N <= 64) return launch_conv<Tile<256, 64, 4, 1>, MODE>(x, w_packed, y, B, T, F, C, N, accumulate, st);
   if (N % 192 == 0 && N % 128 != 0)
     return launch_conv<Tile<128, 192, 2, 2>, MODE>(x, w_packed, y, B, T, F, C, N, accumulate, st);
