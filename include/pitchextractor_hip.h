@@ -203,6 +203,14 @@ int pe_head_bwd(const float* x, long ldx, const float* w, const float* dy, int n
 int pe_f0_sil_loss(const float* f0_pred, const float* f0, const float* sil_pred, const float* sil,
                    float lambda_f0, long R, float grad_scale, float* out3, float* d_f0_pred,
                    float* d_sil_pred, void* stream);
+/* 360-bin F0 classification loss (build-defined, the reference has none): CREPE bins
+ * bin = clamp(rint((1200 log2(f0/10) - 1997.3794084376191) / 20), 0, C-1) on voiced frames (f0 > 0), CE averaged
+ * over voiced frames, total = lambda * CE + BCEWithLogits(sil).  out4 = {total, lambda*CE, BCE, voiced count}. */
+size_t pe_f0_bins_ce_workspace_bytes(long R);
+int pe_f0_bins_ce_loss(const float* logits, long ldl, int C, const float* f0, const float* sil_pred,
+                       const float* sil, float lambda_f0, long R, float grad_scale, float* out4,
+                       float* d_logits, long ldd, float* d_sil_pred, float* workspace, size_t workspace_bytes,
+                       void* stream);
 int pe_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr,
                   float beta1, float beta2, float eps, float weight_decay, double bias_correction1,
                   double bias_correction2, float grad_scale, void* stream);

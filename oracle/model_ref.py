@@ -233,6 +233,38 @@ def jdc_loss(f0_pred, sil_pred, f0, sil, lambda_f0=0.1):
     return loss_f0 + bce, loss_f0, bce
 
 
+CREPE_CENTS0 = 1997.3794084376191
+
+
+def f0_to_bins(f0_hz, n_bins: int = 360):
+    """Build-defined 360-bin target (the reference has no classification loss): CREPE bins,
+    ``cents = 1200 log2(f0/10)``, ``bin = clip(rint((cents - 1997.3794084376191)/20), 0, n_bins-1)`` for voiced
+    frames (f0 > 0) and -1 (ignored) for unvoiced ones.  float64 / int64 numpy."""
+    import numpy as np
+    f = np.asarray(f0_hz, dtype=np.float64)
+    bins = np.full(f.shape, -1, dtype=np.int64)
+    v = f > 0
+    cents = 1200.0 * np.log2(f[v] / 10.0)
+    bins[v] = np.clip(np.rint((cents - CREPE_CENTS0) / 20.0), 0, n_bins - 1).astype(np.int64)
+    return bins
+
+
+def jdc_bins_loss(logits, sil_pred, f0, sil, lambda_f0=0.1):
+    """lambda * CE(logits, f0_to_bins(f0)) averaged over voiced frames (0 if none) + BCEWithLogits(sil)."""
+    bins = torch.from_numpy(f0_to_bins(f0.detach().cpu().numpy(), logits.shape[-1])).to(logits.device)
+    flat, tgt = logits.reshape(-1, logits.shape[-1]), bins.reshape(-1)
+    voiced = tgt >= 0
+    if bool(voiced.any()):
+        lse = torch.logsumexp(flat[voiced], dim=-1)
+        ce = (lse - flat[voiced].gather(1, tgt[voiced, None]).squeeze(1)).mean()
+    else:
+        ce = flat.sum() * 0.0
+    z = sil_pred
+    bce = (z.clamp(min=0) - z * sil + torch.log1p(torch.exp(-z.abs()))).mean()
+    loss_f0 = lambda_f0 * ce
+    return loss_f0 + bce, loss_f0, bce
+
+
 # --------------------------------------------------------------------------- deterministic weights
 def seeded_state(seed: int, num_class: int = 1, hidden_size: int = 384, num_layers: int = 4,
                  bidirectional: bool = True, dtype=torch.float32, model_type: str = "bilstm", nhead: int = 8,

@@ -122,7 +122,10 @@ class CpuTrainer:
         new_stats = {}
         cls, det = model_ref.jdcnet_forward(live, x.transpose(-1, -2), self.seq_cfg, train=True,
                                             new_stats=new_stats, fused_lstm=self.fused_lstm)
-        loss, lf0, lsil = model_ref.jdc_loss(cls, det, f0, sil, self.lam)
+        if cls.shape[-1] == 1:
+            loss, lf0, lsil = model_ref.jdc_loss(cls, det, f0, sil, self.lam)
+        else:                                    # build-defined 360-bin classification target
+            loss, lf0, lsil = model_ref.jdc_bins_loss(cls, det, f0, sil, self.lam)
         loss.backward()
         lr, beta1 = one_cycle(self.k, self.total, self.max_lr)
         for k in self.names:

@@ -93,6 +93,8 @@ PROTOTYPES = {
     "pe_resample_plan_destroy": (_i, [_p]),
     "pe_resample_out_len": (_l, [_p, _l]),
     "pe_resample_forward": (_i, [_p, _p, _i, _i, _l, _p, _l, _i, _p]),
+    "pe_f0_bins_ce_workspace_bytes": (_z, [_l]),
+    "pe_f0_bins_ce_loss": (_i, [_p, _l, _i, _p, _p, _p, _f, _l, _f, _p, _p, _l, _p, _p, _z, _p]),
     "pe_adamw_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _d, _d, _f, _p]),
 }
 

@@ -84,6 +84,112 @@ __global__ void head_bwd_dw_final_kernel(const double* __restrict__ partial, int
   }
 }
 
+// ------------------------------------------------------------------ 360-bin F0 classification loss
+// Build-defined (the reference has no classification loss): CREPE-style targets
+//   cents = 1200 log2(f0 / 10 Hz),  bin = clamp(rint((cents - 1997.3794084376191) / 20), 0, C - 1)
+// for voiced frames (f0 > 0); unvoiced frames are ignored by the cross-entropy, which is averaged over
+// the voiced frames (0 when there are none).  total = lambda * CE + BCEWithLogits(sil), as the
+// regression loss above.  One wave per row; index arithmetic in double so it matches the float64 oracle.
+constexpr double kCrepeCents0 = 1997.3794084376191;
+
+__device__ __forceinline__ int f0_bin(float f0, int C) {
+  const double cents = 1200.0 * log2((double)f0 / 10.0);
+  double b = rint((cents - kCrepeCents0) / 20.0);
+  b = b < 0.0 ? 0.0 : b;
+  b = b > (double)(C - 1) ? (double)(C - 1) : b;
+  return (int)b;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_sum_all(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// row_ce[r] = -log softmax(logits[r])[bin] (0 for unvoiced), row_lse[r] = log-sum-exp of the row
+__global__ __launch_bounds__(256) void bins_ce_rows_kernel(const float* __restrict__ logits, long ldl, int C,
+                                                           const float* __restrict__ f0, long R,
+                                                           float* __restrict__ row_ce, float* __restrict__ row_lse) {
+  const int lane = threadIdx.x & 63;
+  const long wave = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * 256) >> 6;
+  for (long r = wave; r < R; r += nwaves) {
+    const float* lr = logits + r * ldl;
+    float m = -INFINITY;
+    for (int c = lane; c < C; c += 64) m = fmaxf(m, lr[c]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += expf(lr[c] - m);
+    s = wave_sum_all(s);
+    const float lse = m + logf(s);
+    if (lane == 0) {
+      const float f = f0[r];
+      row_lse[r] = lse;
+      row_ce[r] = f > 0.f ? lse - lr[f0_bin(f, C)] : 0.f;
+    }
+  }
+}
+
+// out[0] = total, out[1] = lambda * ce, out[2] = bce, out[3] = voiced frame count; d_sil as in f0_sil_loss
+__global__ __launch_bounds__(1024) void bins_ce_reduce_kernel(const float* __restrict__ row_ce,
+                                                              const float* __restrict__ f0,
+                                                              const float* __restrict__ sil_pred,
+                                                              const float* __restrict__ sil, float lambda_f0, long R,
+                                                              float grad_scale, float* __restrict__ out,
+                                                              float* __restrict__ d_sil) {
+  __shared__ double red[3][1024];
+  double s1 = 0, s2 = 0, cnt = 0;
+  const float inv_n = 1.0f / (float)R;
+  for (long r = threadIdx.x; r < R; r += 1024) {
+    s1 += row_ce[r];
+    cnt += f0[r] > 0.f ? 1.0 : 0.0;
+    const float z = sil_pred[r], y = sil[r];
+    s2 += fmaxf(z, 0.f) - z * y + log1pf(expf(-fabsf(z)));
+    if (d_sil) d_sil[r] = grad_scale * inv_n * (1.0f / (1.0f + expf(-z)) - y);
+  }
+  red[0][threadIdx.x] = s1; red[1][threadIdx.x] = s2; red[2][threadIdx.x] = cnt;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s)
+      for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double n_voiced = red[2][0];
+    const float ce = n_voiced > 0 ? (float)(red[0][0] / n_voiced) : 0.f;
+    const float bce = (float)(red[1][0] / (double)R);
+    out[1] = lambda_f0 * ce;
+    out[2] = bce;
+    out[0] = lambda_f0 * ce + bce;
+    out[3] = (float)n_voiced;
+  }
+}
+
+// d_logits[r][c] = grad_scale * lambda / n_voiced * (softmax - onehot) on voiced rows, 0 elsewhere
+__global__ __launch_bounds__(256) void bins_ce_grad_kernel(const float* __restrict__ logits, long ldl, int C,
+                                                           const float* __restrict__ f0,
+                                                           const float* __restrict__ row_lse,
+                                                           const float* __restrict__ out, float lambda_f0,
+                                                           float grad_scale, long R, float* __restrict__ d_logits,
+                                                           long ldd) {
+  const float nv = out[3];
+  const float k = nv > 0.f ? grad_scale * lambda_f0 / nv : 0.f;
+  const long total = R * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / C;
+    const int c = (int)(i - r * C);
+    const float f = f0[r];
+    float g = 0.f;
+    if (f > 0.f) g = k * (expf(logits[r * ldl + c] - row_lse[r]) - (c == f0_bin(f, C) ? 1.f : 0.f));
+    d_logits[r * ldd + c] = g;
+  }
+}
+
 constexpr int kHeadParts = 256;
 
 // ------------------------------------------------------------------ losses
@@ -207,6 +313,35 @@ extern "C" int pe_f0_sil_loss(const float* f0_pred, const float* f0, const float
   hipLaunchKernelGGL(f0_sil_loss_kernel, dim3(1), dim3(1024), 0, pe_stream(stream), f0_pred, f0, sil_pred, sil,
                      lambda_f0, R, grad_scale, out3, d_f0_pred, d_sil_pred);
   PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+
+extern "C" size_t pe_f0_bins_ce_workspace_bytes(long R) { return (size_t)(2 * R) * sizeof(float); }
+
+extern "C" int pe_f0_bins_ce_loss(const float* logits, long ldl, int C, const float* f0, const float* sil_pred,
+                                  const float* sil, float lambda_f0, long R, float grad_scale, float* out4,
+                                  float* d_logits, long ldd, float* d_sil_pred, float* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  if (!logits || !f0 || !sil_pred || !sil || !out4 || R <= 0 || C < 2 || ldl < C) return PE_E_ARG;
+  if (d_logits && ldd < C) return PE_E_ARG;
+  if (!workspace || workspace_bytes < pe_f0_bins_ce_workspace_bytes(R)) return PE_E_WORKSPACE;
+  hipStream_t st = pe_stream(stream);
+  float* row_ce = workspace;
+  float* row_lse = workspace + R;
+  long g = (R + 3) / 4;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(bins_ce_rows_kernel, dim3((int)g), dim3(256), 0, st, logits, ldl, C, f0, R, row_ce, row_lse);
+  PE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bins_ce_reduce_kernel, dim3(1), dim3(1024), 0, st, row_ce, f0, sil_pred, sil, lambda_f0, R,
+                     grad_scale, out4, d_sil_pred);
+  PE_LAUNCH_CHECK();
+  if (d_logits) {
+    long gg = (R * C + 255) / 256;
+    if (gg > 8192) gg = 8192;
+    hipLaunchKernelGGL(bins_ce_grad_kernel, dim3((int)gg), dim3(256), 0, st, logits, ldl, C, f0, row_lse, out4,
+                       lambda_f0, grad_scale, R, d_logits, ldd);
+    PE_LAUNCH_CHECK();
+  }
   return PE_OK;
 }
 

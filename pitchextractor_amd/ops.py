@@ -557,6 +557,26 @@ def f0_sil_loss(f0_pred, f0, sil_pred, sil, lambda_f0, grad_scale=1.0, want_grad
     return out3, d_f0, d_sil
 
 
+def f0_bins_ce_loss(logits, f0, sil_pred, sil, lambda_f0, grad_scale=1.0, want_grads=True):
+    """360-bin (CREPE-style) F0 classification loss + silence BCE (build-defined).
+    logits (R, C), f0 / sil_pred / sil (R,).  Returns (out4 = [total, lambda*CE, BCE, n_voiced], d_logits, d_sil)."""
+    logits = _dense(logits, "logits")
+    _chk(logits.dim() == 2, "logits: expected (R, C)")
+    R, C = logits.shape
+    for t, n in ((f0, "f0"), (sil_pred, "sil_pred"), (sil, "sil")):
+        _chk(_dense(t, n).numel() == R, f"{n}: size")
+    lib = _lib.load()
+    out4 = torch.empty((4,), dtype=torch.float32, device=f0.device)
+    d_logits = torch.empty((R, C), dtype=torch.float32, device=f0.device) if want_grads else None
+    d_sil = torch.empty((R,), dtype=torch.float32, device=f0.device) if want_grads else None
+    nbytes = lib.pe_f0_bins_ce_workspace_bytes(R)
+    ws = workspace(nbytes, f0.device)
+    _call("pe_f0_bins_ce_loss", logits.data_ptr(), C, C, f0.data_ptr(), sil_pred.data_ptr(), sil.data_ptr(),
+          float(lambda_f0), R, float(grad_scale), out4.data_ptr(), _lib.ptr(d_logits), C, _lib.ptr(d_sil),
+          ws.data_ptr(), ws.numel(), _s())
+    return out4, d_logits, d_sil
+
+
 def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
     n = param.numel()
     for t, nme in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):

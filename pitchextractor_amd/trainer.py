@@ -141,10 +141,18 @@ class Trainer(object):
         return x, f0.contiguous().float(), sil.contiguous().float()
 
     def _loss(self, f0_pred, sil_pred, f0, sil, want_grads):
+        """num_class == 1: the reference's regression loss (train.py:104-106).  num_class > 1 has no loss in the
+        reference; this build defines the CREPE-style bin classification of SURVEY 8f N4 for it
+        (ops.f0_bins_ce_loss: voiced frames only, lambda_f0 * CE + BCE)."""
+        lam = self.loss_config["lambda_f0"]
         if f0_pred.shape[-1] != 1:
-            raise NotImplementedError("the reference loss is defined for num_class == 1 (F0 regression)")
+            C = f0_pred.shape[-1]
+            out4, d_logits, d_sil = ops.f0_bins_ce_loss(f0_pred.detach().reshape(-1, C), f0.reshape(-1),
+                                                        sil_pred.detach().reshape(-1), sil.reshape(-1), lam, 1.0,
+                                                        want_grads)
+            return out4[:3], d_logits, d_sil
         return ops.f0_sil_loss(f0_pred.detach().reshape(-1), f0.reshape(-1), sil_pred.detach().reshape(-1),
-                               sil.reshape(-1), self.loss_config["lambda_f0"], 1.0, want_grads)
+                               sil.reshape(-1), lam, 1.0, want_grads)
 
     def run(self, batch):
         self.optimizer.zero_grad(set_to_none=True)

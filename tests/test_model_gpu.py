@@ -168,6 +168,28 @@ def test_hundred_step_loss_curve_matches_reference_trainer(golden_dir, hip_devic
     assert np.abs(got[:, 2] - curve[:, 2]).max() <= 1e-3 * max(curve[:, 2].max(), 1e-2) + 2e-4
 
 
+def test_classification_head_training_steps_match_oracle(hip_device):
+    """N4 (build-defined, no reference semantics): num_class = 360 with the CREPE-bin cross-entropy.  Five
+    optimiser steps of the HIP trainer vs the fp32 CPU oracle trainer on identical batches (dropout off)."""
+    from oracle import train_ref
+    cfg = dict(SEQ_CFG, hidden_size=64, dropout=0.0)
+    state = model_ref.seeded_state(31, num_class=360, hidden_size=64)
+    net = build(state, 360, 64, hip_device).train()
+    net.block_dropout = 0.0
+    opt, sched = build_optimizer({"params": net.parameters(), "optimizer_params": {},
+                                  "scheduler_params": {"max_lr": 3e-4, "pct_start": 0.0, "epochs": 100,
+                                                       "steps_per_epoch": 8}})
+    tr = Trainer(model=net, criterion={"l1": torch.nn.SmoothL1Loss(), "ce": torch.nn.BCEWithLogitsLoss()},
+                 optimizer=opt, scheduler=sched, device="cuda:0", loss_config={"lambda_f0": 0.1},
+                 logger=logging.getLogger("t"))
+    cpu = train_ref.CpuTrainer(state, cfg, max_lr=3e-4, total_steps=800, lambda_f0=0.1)
+    for batch in training_batches(5):
+        got, ref = tr.run(batch), cpu.run(batch)
+        for key in ("loss", "f0", "sil"):
+            assert abs(got[key] - ref[key]) <= 1e-3 * abs(ref[key]) + 1e-5, (key, got, ref)
+    assert ref["f0"] > 0.1                       # the CE term is live (ln 360 * 0.1 ~ 0.59 at init)
+
+
 def test_full_batch_is_sample_independent_and_deterministic(hip_device):
     """BASELINE size B=256 in eval mode: every sample's logits equal the same sample run in a batch of 8,
     bit for bit (tile position must not change a row's summation order), and reruns are identical."""

@@ -356,6 +356,38 @@ def test_loss_matches_torch_criteria(hip_device):
     close(d_sil, silp.grad, 1e-5)
 
 
+def test_bins_ce_loss_matches_float64_oracle(hip_device):
+    """N4: 360-bin classification loss + gradients vs the float64 restatement (oracle/model_ref.py)."""
+    from oracle import model_ref
+    g = torch.Generator().manual_seed(5)
+    R, C = 517, 360
+    logits = torch.randn(R, C, generator=g) * 3
+    f0 = torch.rand(R, generator=g) * 600 + 40
+    f0[torch.rand(R, generator=g) < 0.3] = 0.0
+    f0[:4] = torch.tensor([0.0, 5.0, 31.7, 3000.0])                      # unvoiced, below / on / above the grid
+    silp, sil = torch.randn(R, generator=g), (f0 == 0).float()
+    lg = logits.double().requires_grad_(True)
+    sp = silp.double().requires_grad_(True)
+    tot, lf0, bce = model_ref.jdc_bins_loss(lg, sp, f0.double(), sil.double(), 0.1)
+    tot.backward()
+    out4, d_logits, d_sil = ops.f0_bins_ce_loss(logits.to(hip_device), f0.to(hip_device), silp.to(hip_device),
+                                                sil.to(hip_device), 0.1)
+    np.testing.assert_allclose(out4[:3].cpu().numpy(), [tot.item(), lf0.item(), bce.item()], rtol=2e-6)
+    assert int(out4[3].item()) == int((f0 > 0).sum())
+    close(d_logits, lg.grad, tol=2e-6)
+    close(d_sil, sp.grad, tol=2e-6)
+    # bins are index work: bit-exact against the float64 mapping
+    onehot_rows = (d_logits.cpu() < 0).float().argmax(dim=1)
+    ref_bins = torch.from_numpy(model_ref.f0_to_bins(f0.numpy()))
+    voiced = ref_bins >= 0
+    assert torch.equal(onehot_rows[voiced], ref_bins[voiced])
+    assert (d_logits.cpu()[~voiced] == 0).all()
+    # no voiced frame at all: CE term is 0 and its gradient vanishes
+    out4, d_logits, _ = ops.f0_bins_ce_loss(logits.to(hip_device), torch.zeros(R, device=hip_device),
+                                            silp.to(hip_device), torch.ones(R, device=hip_device), 0.1)
+    assert out4[1].item() == 0.0 and (d_logits == 0).all()
+
+
 def test_adamw_matches_torch(hip_device):
     n = 1003
     p0, grads = rnd(n, seed=1), [rnd(n, seed=10 + i) for i in range(6)]

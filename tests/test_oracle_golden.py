@@ -193,3 +193,17 @@ def test_transformer_eval_forward_matches_reference(G):
         cls, det = model_ref.jdcnet_forward(state, golden_input(3), dict(TF_CFG))
     np.testing.assert_allclose(cls.numpy(), G["tf_eval_cls"], rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(det.numpy(), G["tf_eval_det"], rtol=2e-4, atol=2e-5)
+
+
+def test_crepe_bin_mapping_known_values():
+    """N4 (build-defined): known anchors of the CREPE 360-bin grid -- bin b is centred on
+    10 * 2^((20 b + 1997.379...)/1200) Hz, so bin 0 = 31.70 Hz (C1 - ~0.2 semitones) and bin 359 = 2005.5 Hz."""
+    import numpy as np
+    from oracle import model_ref
+    centres = 10.0 * 2.0 ** ((20.0 * np.arange(360) + model_ref.CREPE_CENTS0) / 1200.0)
+    assert abs(centres[0] - 31.70) < 0.01 and abs(centres[359] - 2005.5) < 0.5
+    bins = model_ref.f0_to_bins(centres)
+    assert (bins == np.arange(360)).all()
+    assert list(model_ref.f0_to_bins([0.0, 5.0, 440.0, 1e5])) == [-1, 0, 228, 359]
+    edge = 10.0 * 2.0 ** ((20.0 * 100.5 + model_ref.CREPE_CENTS0) / 1200.0)        # exactly between bins 100 and 101
+    assert model_ref.f0_to_bins([edge * (1 - 1e-9), edge * (1 + 1e-9)]).tolist() == [100, 101]
