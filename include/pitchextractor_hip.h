@@ -92,6 +92,8 @@ int pe_gemm_tn(const float* A, long lda, const float* B, long ldb, float* C, lon
                int K, int accumulate, float* workspace, size_t workspace_bytes, void* stream);
 int pe_gemm_tn_x3(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
                   int K, int accumulate, float* workspace, size_t workspace_bytes, void* stream);
+int pe_gemm_tn_bf16(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
+                    int K, int accumulate, float* workspace, size_t workspace_bytes, void* stream);  /* mixed precision */
 int pe_transpose2d(const float* in, float* out, int rows, int cols, void* stream);
 
 /* ---- 3x3 / pad 1 convolutions (model.py:23-28,157-161), channels-last -------
@@ -113,6 +115,8 @@ int pe_conv3x3_wgrad(const float* x, const float* dy, float* dw_oihw, int B, int
                      int Cout, float* workspace, size_t workspace_bytes, void* stream);
 int pe_conv3x3_wgrad_x3(const float* x, const float* dy, float* dw_oihw, int B, int T, int F, int Cin,
                         int Cout, float* workspace, size_t workspace_bytes, void* stream);
+int pe_conv3x3_wgrad_bf16(const float* x, const float* dy, float* dw_oihw, int B, int T, int F, int Cin,
+                          int Cout, float* workspace, size_t workspace_bytes, void* stream);   /* mixed precision */
 int pe_conv3x3_c1_fwd(const float* x, long sb, long st, long sf, const float* w_oihw, float* y, int B,
                       int T, int F, void* stream);
 int pe_conv3x3_c1_wgrad(const float* x, long sb, long st, long sf, const float* dy, float* dw_oihw,
@@ -183,6 +187,8 @@ int pe_lstm_whh_grad(const float* dgates, const float* y, long ldy, float* dwhh,
                      int reverse, float* workspace, size_t workspace_bytes, void* stream);
 int pe_lstm_whh_grad_x3(const float* dgates, const float* y, long ldy, float* dwhh, int B, int T, int H,
                      int reverse, float* workspace, size_t workspace_bytes, void* stream);   /* three-term bf16 split */
+int pe_lstm_whh_grad_bf16(const float* dgates, const float* y, long ldy, float* dwhh, int B, int T, int H,
+                     int reverse, float* workspace, size_t workspace_bytes, void* stream);   /* mixed precision */
 size_t pe_colsum_workspace_bytes(int cols);
 int pe_colsum(const float* x, long rows, int cols, long ld, float* out0, float* out1, void* workspace,
               size_t workspace_bytes, void* stream);

@@ -45,6 +45,7 @@ PROTOTYPES = {
     "pe_gemm_tn_workspace_bytes": (_z, [_i, _i, _i]),
     "pe_gemm_tn": (_i, [_p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _p, _z, _p]),
     "pe_gemm_tn_x3": (_i, [_p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _p, _z, _p]),
+    "pe_gemm_tn_bf16": (_i, [_p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _p, _z, _p]),
     "pe_transpose2d": (_i, [_p, _p, _i, _i, _p]),
     "pe_conv3x3_repack": (_i, [_p, _p, _p, _i, _i, _p]),
     "pe_conv3x3_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
@@ -53,6 +54,7 @@ PROTOTYPES = {
     "pe_conv3x3_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
     "pe_conv3x3_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
     "pe_conv3x3_wgrad_x3": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "pe_conv3x3_wgrad_bf16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
     "pe_conv3x3_c1_fwd": (_i, [_p, _l, _l, _l, _p, _p, _i, _i, _i, _p]),
     "pe_conv3x3_c1_wgrad": (_i, [_p, _l, _l, _l, _p, _p, _i, _i, _i, _p, _z, _p]),
     "pe_bn_workspace_bytes": (_z, [_i]),
@@ -75,6 +77,7 @@ PROTOTYPES = {
     "pe_lstm_whh_grad_workspace_bytes": (_z, [_i, _i, _i]),
     "pe_lstm_whh_grad": (_i, [_p, _p, _l, _p, _i, _i, _i, _i, _p, _z, _p]),
     "pe_lstm_whh_grad_x3": (_i, [_p, _p, _l, _p, _i, _i, _i, _i, _p, _z, _p]),
+    "pe_lstm_whh_grad_bf16": (_i, [_p, _p, _l, _p, _i, _i, _i, _i, _p, _z, _p]),
     "pe_colsum_workspace_bytes": (_z, [_i]),
     "pe_colsum": (_i, [_p, _l, _i, _l, _p, _p, _p, _z, _p]),
     "pe_head_fwd": (_i, [_p, _l, _p, _p, _i, _p, _l, _i, _p]),

@@ -405,14 +405,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_kernel(const float* __r
 // of one channel) come from ds_read_b64_tr_b16, and the border mask becomes a 16-bit AND mask per pixel:
 // Mk16[d][w][k] covers source row k + d of window w for column shift df = d - 1, so the 8 masks of a
 // fragment are one aligned 16-byte read.
+template <int NT>   // 3 = exact three-term split, 1 = operands rounded to bf16 (mixed precision)
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(const float* __restrict__ dy,
                                                                    const float* __restrict__ x,
                                                                    float* __restrict__ ws, int T, int F, int Cin,
                                                                    int Cout, int P, int k_per_split, int tiles_n) {
   constexpr int ST = 96;                                   // bf16 elements per staged row
   constexpr int YIMG = kBK * ST, XIMG = 102 * ST;
-  __shared__ __attribute__((aligned(16))) __bf16 Ys[3 * YIMG];
-  __shared__ __attribute__((aligned(16))) __bf16 Xs[3 * XIMG];
+  __shared__ __attribute__((aligned(16))) __bf16 Ys[NT * YIMG];
+  __shared__ __attribute__((aligned(16))) __bf16 Xs[NT * XIMG];
   __shared__ __attribute__((aligned(16))) unsigned short Mk16[9 * kBK];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm = wv >> 1, wn = wv & 1, r = lane & 31, h = lane >> 5;
@@ -448,10 +449,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(const float* 
     }
   };
   auto store3 = [&](__bf16* img, int img_elems, int off, const float4& v) {
-    const Split3 sp = split3(v);
-    *reinterpret_cast<uint2*>(img + off) = sp.hi;
-    *reinterpret_cast<uint2*>(img + off + img_elems) = sp.mid;
-    *reinterpret_cast<uint2*>(img + off + 2 * img_elems) = sp.lo;
+    if constexpr (NT == 3) {
+      const Split3 sp = split3(v);
+      *reinterpret_cast<uint2*>(img + off) = sp.hi;
+      *reinterpret_cast<uint2*>(img + off + img_elems) = sp.mid;
+      *reinterpret_cast<uint2*>(img + off + 2 * img_elems) = sp.lo;
+    } else {
+      *reinterpret_cast<bf16x4*>(img + off) = to_bf16x4(v);
+    }
   };
   fetch(kb);
   const __bf16* a_rd = Ys + (8 * h + q4) * ST + wm * 32 + 16 * g1 + p4;
@@ -486,22 +491,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(const float* 
     if (k0 + kBK < ke) fetch(k0 + kBK);
 #pragma unroll
     for (int kk = 0; kk < kBK / 16; ++kk) {
-      bf16x8 fa[3];
+      bf16x8 fa[NT];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) fa[c] = tr_fragment(a_rd + c * YIMG + kk * 16 * ST, ST);
+      for (int c = 0; c < NT; ++c) fa[c] = tr_fragment(a_rd + c * YIMG + kk * 16 * ST, ST);
 #pragma unroll
       for (int w = 0; w < 3; ++w)
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
           const uint4 mk = *reinterpret_cast<const uint4*>(Mk16 + (d * 3 + w) * kBK + kk * 16 + 8 * h);
-          bf16x8 fb[3];
+          bf16x8 fb[NT];
 #pragma unroll
-          for (int c = 0; c < 3; ++c) {
+          for (int c = 0; c < NT; ++c) {
             uint4 v = __builtin_bit_cast(uint4, tr_fragment(b_rd + c * XIMG + (w * 34 + kk * 16 + d) * ST, ST));
             v.x &= mk.x; v.y &= mk.y; v.z &= mk.z; v.w &= mk.w;
             fb[c] = __builtin_bit_cast(bf16x8, v);
           }
-          acc[w * 3 + d] = mfma_split(fa, fb, acc[w * 3 + d]);
+          if constexpr (NT == 3) acc[w * 3 + d] = mfma_split(fa, fb, acc[w * 3 + d]);
+          else acc[w * 3 + d] = mfma_bf16(fa[0], fb[0], acc[w * 3 + d]);
         }
     }
   }
@@ -713,7 +719,10 @@ static int conv3x3_wgrad_impl(const float* x, const float* dy, float* dw_oihw, i
   if (wgrad9_ok(Cout, Cin)) {
     const int P = B * T * F, tn = Cin / 64;
     if (MODE == kSplit)
-      hipLaunchKernelGGL(conv3x3_wgrad9_x3_kernel, dim3((Cout / 64) * tn, splits), dim3(256), 0, st, dy, x,
+      hipLaunchKernelGGL(conv3x3_wgrad9_x3_kernel<3>, dim3((Cout / 64) * tn, splits), dim3(256), 0, st, dy, x,
+                         workspace, T, F, Cin, Cout, P, kps, tn);
+    else if (MODE == kBf16)
+      hipLaunchKernelGGL(conv3x3_wgrad9_x3_kernel<1>, dim3((Cout / 64) * tn, splits), dim3(256), 0, st, dy, x,
                          workspace, T, F, Cin, Cout, P, kps, tn);
     else
       hipLaunchKernelGGL(conv3x3_wgrad9_kernel<0>, dim3((Cout / 64) * tn, splits), dim3(256), 0, st, dy, x,
@@ -735,6 +744,11 @@ static int conv3x3_wgrad_impl(const float* x, const float* dy, float* dw_oihw, i
 extern "C" int pe_conv3x3_wgrad(const float* x, const float* dy, float* dw_oihw, int B, int T, int F, int Cin,
                                 int Cout, float* workspace, size_t workspace_bytes, void* stream) {
   return conv3x3_wgrad_impl<kNative>(x, dy, dw_oihw, B, T, F, Cin, Cout, workspace, workspace_bytes, stream);
+}
+
+extern "C" int pe_conv3x3_wgrad_bf16(const float* x, const float* dy, float* dw_oihw, int B, int T, int F, int Cin,
+                                     int Cout, float* workspace, size_t workspace_bytes, void* stream) {
+  return conv3x3_wgrad_impl<kBf16>(x, dy, dw_oihw, B, T, F, Cin, Cout, workspace, workspace_bytes, stream);
 }
 
 extern "C" int pe_conv3x3_wgrad_x3(const float* x, const float* dy, float* dw_oihw, int B, int T, int F, int Cin,

@@ -96,7 +96,7 @@ __global__ void splitk_reduce_kernel(const float* ws, long split_stride, int spl
 void tn_plan(int M, int N, int K, int bm, int bn, int mode, int* splits, int* k_per_split) {
   const int tiles = pe_cdiv(M, bm) * pe_cdiv(N, bn);
   // resident workgroups: 3 per CU (native), 2 per CU when the three-term images fill the LDS
-  const int s = pe_pick_splits(tiles, K, 512, mode == kSplit ? 512 : 768);
+  const int s = pe_pick_splits(tiles, K, 512, mode == kSplit ? 512 : 768);   // (bf16: LDS is small, 768 too)
   int kps = pe_cdiv(K, s);
   kps = (kps + kBK - 1) / kBK * kBK;
   *splits = pe_cdiv(K, kps);
@@ -168,7 +168,7 @@ extern "C" int pe_gemm_nt_x3(const float* A, long lda, const float* B, long ldb,
 extern "C" size_t pe_gemm_tn_workspace_bytes(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   size_t need = 0;
-  for (int mode : {kNative, kSplit}) {                   // one size serves pe_gemm_tn and pe_gemm_tn_x3
+  for (int mode : {kNative, kSplit}) {                   // one size serves every pe_gemm_tn* (bf16 plans like native)
     int splits, kps;
     tn_plan(M, N, K, M <= 64 ? 64 : 128, N <= 64 ? 64 : 128, mode, &splits, &kps);
     const size_t b = splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
@@ -201,4 +201,9 @@ extern "C" int pe_gemm_tn(const float* A, long lda, const float* B, long ldb, fl
 extern "C" int pe_gemm_tn_x3(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
                              int K, int accumulate, float* workspace, size_t workspace_bytes, void* stream) {
   return gemm_tn_impl<kSplit>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, stream);
+}
+
+extern "C" int pe_gemm_tn_bf16(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
+                               int K, int accumulate, float* workspace, size_t workspace_bytes, void* stream) {
+  return gemm_tn_impl<kBf16>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, stream);
 }

@@ -23,7 +23,7 @@ namespace pe {
 constexpr int kBK = 32;
 // precision modes of the tile engines
 constexpr int kNative = 0;    // v_mfma_f32_32x32x2_f32
-constexpr int kBf16 = 1;      // operands rounded to bf16 (mixed precision; NT engines only)
+constexpr int kBf16 = 1;      // operands rounded to bf16 (mixed precision)
 constexpr int kSplit = 2;     // fp32 as three bf16 terms, six bf16 MFMAs per product block (fp32-accurate)
 constexpr int kLdsStride = kBK + 4;
 
@@ -510,7 +510,7 @@ __device__ __forceinline__ void tn_mainloop(AL& al, BL& bl, int k_begin, int k_e
 // cols/2 + 16 dwords the four rows of a half-wave's two blocks fall on disjoint banks.
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 template <int COLS> constexpr int tn_split_stride() { return COLS + 32; }                 // bf16 elements per k-row
-template <int COLS> constexpr int tn_split_floats() { return 3 * kBK * tn_split_stride<COLS>() / 2; }
+template <int COLS, int NT = 3> constexpr int tn_split_floats() { return NT * kBK * tn_split_stride<COLS>() / 2; }
 
 __device__ __forceinline__ s16x4 lds_read_tr(const __bf16* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -526,16 +526,21 @@ __device__ __forceinline__ bf16x8 tr_fragment(const __bf16* p, int stride) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int COLS>
+// NT = 3: the exact three-term split; NT = 1: operands rounded to bf16 (mixed precision)
+template <int COLS, int NT>
 __device__ __forceinline__ void tn_split_store(__bf16* img, int off, const float4& v) {
   constexpr int IMG = kBK * tn_split_stride<COLS>();
-  const Split3 sp = split3(v);
-  *reinterpret_cast<uint2*>(img + off) = sp.hi;
-  *reinterpret_cast<uint2*>(img + off + IMG) = sp.mid;
-  *reinterpret_cast<uint2*>(img + off + 2 * IMG) = sp.lo;
+  if constexpr (NT == 3) {
+    const Split3 sp = split3(v);
+    *reinterpret_cast<uint2*>(img + off) = sp.hi;
+    *reinterpret_cast<uint2*>(img + off + IMG) = sp.mid;
+    *reinterpret_cast<uint2*>(img + off + 2 * IMG) = sp.lo;
+  } else {
+    *reinterpret_cast<bf16x4*>(img + off) = to_bf16x4(v);
+  }
 }
 
-template <int BM, int BN, class AL, class BL>
+template <int BM, int BN, int NT, class AL, class BL>
 __device__ __forceinline__ void tn_mainloop_split(AL& al, BL& bl, int k_begin, int k_end, float* As_f, float* Bs_f,
                                                   f32x16 (&acc)[BM / 64][BN / 64]) {
   constexpr int TM = BM / 64, TN = BN / 64;
@@ -559,9 +564,9 @@ __device__ __forceinline__ void tn_mainloop_split(AL& al, BL& bl, int k_begin, i
   for (int k0 = k_begin; k0 < k_end; k0 += kBK) {
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < SA; ++i) tn_split_store<BM>(As, sta + i * TnGeom<BM>::ROWS * STA, ra[i]);
+    for (int i = 0; i < SA; ++i) tn_split_store<BM, NT>(As, sta + i * TnGeom<BM>::ROWS * STA, ra[i]);
 #pragma unroll
-    for (int i = 0; i < SB; ++i) tn_split_store<BN>(Bs, stb + i * TnGeom<BN>::ROWS * STB, rb[i]);
+    for (int i = 0; i < SB; ++i) tn_split_store<BN, NT>(Bs, stb + i * TnGeom<BN>::ROWS * STB, rb[i]);
     __syncthreads();
     if (k0 + kBK < k_end) {
 #pragma unroll
@@ -571,31 +576,35 @@ __device__ __forceinline__ void tn_mainloop_split(AL& al, BL& bl, int k_begin, i
     }
 #pragma unroll
     for (int kk = 0; kk < kBK / 16; ++kk) {
-      bf16x8 fa[TM][3], fb[TN][3];
+      bf16x8 fa[TM][NT], fb[TN][NT];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) fa[i][c] = tr_fragment(a_rd + c * IMGA + kk * 16 * STA + i * 32, STA);
+        for (int c = 0; c < NT; ++c) fa[i][c] = tr_fragment(a_rd + c * IMGA + kk * 16 * STA + i * 32, STA);
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) fb[j][c] = tr_fragment(b_rd + c * IMGB + kk * 16 * STB + j * 32, STB);
+        for (int c = 0; c < NT; ++c) fb[j][c] = tr_fragment(b_rd + c * IMGB + kk * 16 * STB + j * 32, STB);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_split(fa[i], fb[j], acc[i][j]);
+        for (int j = 0; j < TN; ++j) {
+          if constexpr (NT == 3) acc[i][j] = mfma_split(fa[i], fb[j], acc[i][j]);
+          else acc[i][j] = mfma_bf16(fa[i][0], fb[j][0], acc[i][j]);
+        }
     }
   }
 }
 
 template <int MODE, int COLS> constexpr int tn_lds_floats() {
-  return MODE == kSplit ? tn_split_floats<COLS>() : kBK * COLS;
+  return MODE == kSplit ? tn_split_floats<COLS, 3>() : MODE == kBf16 ? tn_split_floats<COLS, 1>() : kBK * COLS;
 }
 
 template <int MODE, int BM, int BN, class AL, class BL>
 __device__ __forceinline__ void tn_mainloop_mode(AL& al, BL& bl, int k_begin, int k_end, float* As, float* Bs,
                                                  f32x16 (&acc)[BM / 64][BN / 64]) {
-  if constexpr (MODE == kSplit) tn_mainloop_split<BM, BN>(al, bl, k_begin, k_end, As, Bs, acc);
+  if constexpr (MODE == kSplit) tn_mainloop_split<BM, BN, 3>(al, bl, k_begin, k_end, As, Bs, acc);
+  else if constexpr (MODE == kBf16) tn_mainloop_split<BM, BN, 1>(al, bl, k_begin, k_end, As, Bs, acc);
   else tn_mainloop<BM, BN>(al, bl, k_begin, k_end, As, Bs, acc);
 }
 

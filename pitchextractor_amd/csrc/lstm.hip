@@ -351,6 +351,11 @@ extern "C" int pe_lstm_whh_grad_x3(const float* dgates, const float* y, long ldy
   return whh_grad_impl<kSplit>(dgates, y, ldy, dwhh, B, T, H, reverse, workspace, workspace_bytes, stream);
 }
 
+extern "C" int pe_lstm_whh_grad_bf16(const float* dgates, const float* y, long ldy, float* dwhh, int B, int T, int H,
+                                   int reverse, float* workspace, size_t workspace_bytes, void* stream) {
+  return whh_grad_impl<kBf16>(dgates, y, ldy, dwhh, B, T, H, reverse, workspace, workspace_bytes, stream);
+}
+
 extern "C" size_t pe_colsum_workspace_bytes(int cols) { return (size_t)kColsumParts * cols * sizeof(double); }
 
 // out0[c] = out1[c] = sum_r x[r*ld + c]   (out1 optional: b_ih and b_hh share one gradient)

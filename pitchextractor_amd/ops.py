@@ -94,8 +94,8 @@ def _s():
 
 
 # Opt-in mixed precision (reference trainer.py:103 autocast; config training.mixed_precision): when True the
-# k-contiguous MFMA products (conv forward / data gradient, every gemm_nt) round their operands to bf16
-# on the way into LDS and accumulate in fp32.  Everything in HBM stays fp32; False is the parity mode.
+# conv / linear products and their weight gradients round their operands to bf16 on the way into LDS and
+# accumulate in fp32 (the LSTM recurrence, attention and everything in HBM stay fp32); False is the parity mode.
 MATMUL_BF16 = False
 # How fp32 products run (always, for the weight-gradient products; when MATMUL_BF16 is off for the rest):
 #   "x3"     every fp32 operand is split exactly into three bf16 terms and six cross products are
@@ -106,8 +106,11 @@ FP32_MATMUL = os.environ.get("PE_FP32_MATMUL", "x3")
 
 
 def _tn_suffix():
-    """Weight-gradient / k-major products: fp32-accurate in every mode (native or three-term split)."""
+    """Weight-gradient / k-major products: bf16 operands under mixed precision (what autocast's backward does),
+    otherwise fp32-accurate (native or three-term split)."""
     _chk(FP32_MATMUL in ("native", "x3"), "ops.FP32_MATMUL must be 'native' or 'x3'")
+    if MATMUL_BF16:
+        return "_bf16"
     return "_x3" if FP32_MATMUL == "x3" else ""
 
 

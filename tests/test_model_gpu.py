@@ -190,6 +190,26 @@ def test_classification_head_training_steps_match_oracle(hip_device):
     assert ref["f0"] > 0.1                       # the CE term is live (ln 360 * 0.1 ~ 0.59 at init)
 
 
+def test_mixed_precision_training_tracks_fp32(hip_device):
+    """training.mixed_precision (bf16 operands for conv / linear products and their weight gradients, fp32
+    accumulate and state): 12 optimiser steps stay within 2 % of the fp32 loss curve on identical batches."""
+    curves = {}
+    for amp in (False, True):
+        net = build(model_ref.seeded_state(21), 1, 384, hip_device).train()
+        net.block_dropout = 0.0
+        opt, sched = build_optimizer({"params": net.parameters(), "optimizer_params": {},
+                                      "scheduler_params": {"max_lr": 3e-4, "pct_start": 0.0, "epochs": 100,
+                                                           "steps_per_epoch": 8}})
+        tr = Trainer(model=net, criterion={"l1": torch.nn.SmoothL1Loss(), "ce": torch.nn.BCEWithLogitsLoss()},
+                     optimizer=opt, scheduler=sched, device="cuda:0", loss_config={"lambda_f0": 0.1},
+                     logger=logging.getLogger("t"), use_mixed_precision=amp)
+        curves[amp] = np.array([tr.run(b)["loss"] for b in training_batches(12)])
+        assert ops.MATMUL_BF16 is False                         # the scope is per step
+    rel = np.abs(curves[True] - curves[False]) / curves[False]
+    assert rel.max() <= 2e-2, rel
+    assert (curves[True] != curves[False]).any()                # the mode really changes the arithmetic
+
+
 def test_full_batch_is_sample_independent_and_deterministic(hip_device):
     """BASELINE size B=256 in eval mode: every sample's logits equal the same sample run in a batch of 8,
     bit for bit (tile position must not change a row's summation order), and reruns are identical."""

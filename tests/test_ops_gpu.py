@@ -100,6 +100,23 @@ def test_x3_split_is_as_accurate_as_native_fp32(hip_device):
     assert errs["native"] < 2e-5 and errs["x3"] <= 2 * errs["native"], errs
 
 
+def test_weight_gradient_products_bf16_operands(hip_device):
+    """Mixed precision also rounds the operands of the weight-gradient products (gemm_tn, 3x3 wgrad, dW_hh)
+    to bf16, as autocast's backward does: each equals the fp64 product of the rounded operands."""
+    A, B = rnd(3001, 192, seed=1), rnd(3001, 128, seed=2)
+    with ops.matmul_bf16(True):
+        got = ops.gemm_tn(A.to(hip_device), B.to(hip_device))
+    close(got, bf16r(A).T @ bf16r(B))
+    x, dy = rnd(2, 64, 12, 10, seed=3), rnd(2, 128, 12, 10, seed=4)
+    dw = torch.empty(128, 64, 3, 3, device=hip_device)
+    with ops.matmul_bf16(True):
+        ops.conv3x3_wgrad(nhwc(x).to(hip_device), nhwc(dy).to(hip_device), dw)
+    xr = bf16r(x).requires_grad_(False)
+    w = torch.zeros(128, 64, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xr, w, padding=1).backward(bf16r(dy))
+    close(dw, w.grad)
+
+
 def test_gemm_nt_strided_rows(hip_device):
     big = rnd(40, 7, 96, seed=6).to(hip_device)              # rows taken at a fixed time step: ld = 7*96
     A = big[:, 3, 32:96]
