@@ -54,3 +54,26 @@ static inline int pe_pick_splits(int tiles, long K, int min_k_per_split, int res
   }
   return best;
 }
+
+// Ordered sum of `splits` slabs at float4 index i4 (element 4*i4 .. 4*i4+3): s = ((0 + w[0]) + w[1]) + ...,
+// the same order as a plain loop, with the loads issued eight at a time so the reduce kernels run at
+// memory speed instead of one dependent load latency per slab.
+__device__ __forceinline__ float4 pe_ordered_slab_sum4(const float* __restrict__ ws, long slab_stride, int splits,
+                                                       long i4) {
+  const float4* p = reinterpret_cast<const float4*>(ws) + i4;
+  const long st4 = slab_stride >> 2;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  int z = 0;
+  for (; z + 8 <= splits; z += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(long)(z + u) * st4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+  }
+  for (; z < splits; ++z) {
+    const float4 v = p[(long)z * st4];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  return s;
+}

@@ -526,13 +526,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(const float* 
 // sum slabs in split order and scatter to OIHW: dw[(co*Cin + ci)*9 + tap]
 __global__ void conv3x3_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits,
                                             int Cout, int Cin) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // over [tap][co][ci]
+  const int i4 = blockIdx.x * blockDim.x + threadIdx.x;        // float4 index over [tap][co][ci] (Cin % 4 == 0)
   const int n = 9 * Cout * Cin;
-  if (idx >= n) return;
-  float s = 0.f;
-  for (int z = 0; z < splits; ++z) s += ws[(long)z * n + idx];
+  if (i4 * 4 >= n) return;
+  const float4 s = pe_ordered_slab_sum4(ws, n, splits, i4);
+  const int idx = i4 * 4;
   const int ci = idx % Cin, co = (idx / Cin) % Cout, tap = idx / (Cin * Cout);
-  dw[((long)co * Cin + ci) * 9 + tap] = s;
+  float* d = dw + ((long)co * Cin + ci) * 9 + tap;
+  d[0] = s.x; d[9] = s.y; d[18] = s.z; d[27] = s.w;
 }
 
 bool wgrad9_ok(int Cout, int Cin) { return (Cout % 64) == 0 && (Cin % 64) == 0; }
@@ -560,7 +561,7 @@ int launch_wgrad(const float* x, const float* dy, float* dw, float* ws, int B, i
                      tn, n_tiles, n_chunks);
   PE_LAUNCH_CHECK();
   const int n = 9 * Cout * Cin;
-  hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(pe_cdiv(n, 256)), dim3(256), 0, st, ws, dw, splits, Cout,
+  hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(pe_cdiv(n / 4, 256)), dim3(256), 0, st, ws, dw, splits, Cout,
                      Cin);
   PE_LAUNCH_CHECK();
   return PE_OK;
@@ -605,29 +606,41 @@ __global__ __launch_bounds__(256) void conv3x3_c1_fwd_kernel(const float* __rest
 __global__ __launch_bounds__(256) void conv3x3_c1_wgrad_kernel(const float* __restrict__ x, long sb, long st_,
                                                                long sf, const float* __restrict__ dy,
                                                                float* __restrict__ partial, int B, int T, int F) {
-  __shared__ float red[4][64][9];
-  const int co = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  float acc[9];
+  // 16 threads per pixel, 4 output channels each (one float4 of dY per thread); 16 pixels per block pass;
+  // the nine taps of a pixel are read once per 16-thread group (same address: one broadcast load).
+  __shared__ float red[16][64][9];
+  const int q = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  float acc[4][9];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) acc[k] = 0.f;
-  const long P = (long)B * T * F;
-  for (long p = (long)blockIdx.x * 4 + grp; p < P; p += (long)gridDim.x * 4) {
-    const int f = (int)(p % F), t = (int)((p / F) % T);
-    const long b = p / ((long)F * T);
-    const float g = dy[p * 64 + co];
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[c][k] = 0.f;
+  const int P = B * T * F;                                     // < 2^31 (checked by the host)
+  for (int p = blockIdx.x * 16 + grp; p < P; p += gridDim.x * 16) {
+    const int f = p % F, bt = p / F, t = bt % T, b = bt / T;
+    const float4 g = *reinterpret_cast<const float4*>(dy + (long)p * 64 + q * 4);
+    const float* xb = x + b * sb;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       const int tt = t + k / 3 - 1, ff = f + k % 3 - 1;
-      const float xv = (tt >= 0 && tt < T && ff >= 0 && ff < F) ? x[b * sb + tt * st_ + ff * sf] : 0.f;
-      acc[k] = fmaf(g, xv, acc[k]);
+      const float xv = (tt >= 0 && tt < T && ff >= 0 && ff < F) ? xb[tt * st_ + ff * sf] : 0.f;
+      acc[0][k] = fmaf(g.x, xv, acc[0][k]);
+      acc[1][k] = fmaf(g.y, xv, acc[1][k]);
+      acc[2][k] = fmaf(g.z, xv, acc[2][k]);
+      acc[3][k] = fmaf(g.w, xv, acc[3][k]);
     }
   }
 #pragma unroll
-  for (int k = 0; k < 9; ++k) red[grp][co][k] = acc[k];
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) red[grp][q * 4 + c][k] = acc[c][k];
   __syncthreads();
   for (int i = threadIdx.x; i < 64 * 9; i += 256) {
     const int c = i / 9, k = i % 9;
-    partial[(long)blockIdx.x * 576 + i] = (red[0][c][k] + red[1][c][k]) + (red[2][c][k] + red[3][c][k]);
+    float s = 0.f;
+#pragma unroll
+    for (int gq = 0; gq < 16; ++gq) s += red[gq][c][k];
+    partial[(long)blockIdx.x * 576 + i] = s;
   }
 }
 
@@ -729,7 +742,7 @@ static int conv3x3_wgrad_impl(const float* x, const float* dy, float* dw_oihw, i
                          workspace, T, F, Cin, Cout, P, kps, tn);
     PE_LAUNCH_CHECK();
     const int n = 9 * Cout * Cin;
-    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(pe_cdiv(n, 256)), dim3(256), 0, st, workspace, dw_oihw,
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(pe_cdiv(n / 4, 256)), dim3(256), 0, st, workspace, dw_oihw,
                        splits, Cout, Cin);
     PE_LAUNCH_CHECK();
     return PE_OK;
@@ -770,6 +783,7 @@ extern "C" int pe_conv3x3_c1_fwd(const float* x, long sb, long st, long sf, cons
 extern "C" int pe_conv3x3_c1_wgrad(const float* x, long sb, long st, long sf, const float* dy, float* dw_oihw,
                                    int B, int T, int F, float* workspace, size_t workspace_bytes, void* stream) {
   if (!x || !dy || !dw_oihw || B <= 0 || T <= 0 || F <= 0) return PE_E_ARG;
+  if ((long)B * T * F >= (1L << 31) - 65536) return PE_E_UNSUPPORTED;          // 32-bit pixel index in the kernel
   if (!workspace || workspace_bytes < (size_t)kC1WgradBlocks * 576 * sizeof(float)) return PE_E_WORKSPACE;
   hipLaunchKernelGGL(conv3x3_c1_wgrad_kernel, dim3(kC1WgradBlocks), dim3(256), 0, pe_stream(stream), x, sb, st, sf,
                      dy, workspace, B, T, F);

@@ -83,14 +83,15 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(KRowLoader<BM> al, KRowLoa
 }
 
 __global__ void splitk_reduce_kernel(const float* ws, long split_stride, int splits, float* C, long ldc,
-                                     int M, int N, int accumulate) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)M * N) return;
-  const int row = (int)(idx / N), col = (int)(idx % N);
-  float s = 0.f;
-  for (int z = 0; z < splits; ++z) s += ws[(long)z * split_stride + idx];
-  float* d = C + (long)row * ldc + col;
-  *d = accumulate ? *d + s : s;
+                                     int M, int N, int accumulate) {   // N % 4 == 0: a float4 stays inside one row
+  const long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i4 * 4 >= (long)M * N) return;
+  const float4 s = pe_ordered_slab_sum4(ws, split_stride, splits, i4);
+  const long idx = i4 * 4;
+  const int row = (int)(idx / N), col = (int)(idx - (long)row * N);
+  float* d = C + (long)row * ldc + col;                          // C may be an unaligned view: scalar stores
+  if (accumulate) { d[0] += s.x; d[1] += s.y; d[2] += s.z; d[3] += s.w; }
+  else { d[0] = s.x; d[1] = s.y; d[2] = s.z; d[3] = s.w; }
 }
 
 void tn_plan(int M, int N, int K, int bm, int bn, int mode, int* splits, int* k_per_split) {
@@ -123,7 +124,7 @@ int launch_tn(const float* A, long lda, const float* B, long ldb, float* C, long
                      (long)M * N, M, N, K, kps, tn, 0);
   PE_LAUNCH_CHECK();
   const long total = (long)M * N;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(pe_cdiv(total, 256)), dim3(256), 0, st, ws, (long)M * N, splits,
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(pe_cdiv(total / 4, 256)), dim3(256), 0, st, ws, (long)M * N, splits,
                      C, ldc, M, N, accumulate);
   PE_LAUNCH_CHECK();
   return PE_OK;

@@ -219,12 +219,12 @@ __global__ __launch_bounds__(256) void lstm_whh_grad_kernel(KRowLoader<BM> al, S
   });
 }
 
-__global__ void slab_reduce_kernel(const float* ws, long n, int splits, float* out) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n) return;
-  float s = 0.f;
-  for (int z = 0; z < splits; ++z) s += ws[(long)z * n + idx];
-  out[idx] = s;
+__global__ void slab_reduce_kernel(const float* ws, long n, int splits, float* out) {   // n % 4 == 0
+  const long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i4 * 4 >= n) return;
+  const float4 s = pe_ordered_slab_sum4(ws, n, splits, i4);
+  float* d = out + 4 * i4;                             // `out` may be an unaligned view of the flat gradient buffer
+  d[0] = s.x; d[1] = s.y; d[2] = s.z; d[3] = s.w;
 }
 
 void whh_plan(int M, int N, int K, int mode, int* splits, int* kps) {
@@ -336,7 +336,7 @@ static int whh_grad_impl(const float* dgates, const float* y, long ldy, float* d
                      workspace, (long)N, (long)M * N, M, N, K, kps, tn);
   PE_LAUNCH_CHECK();
   const long n = (long)M * N;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(pe_cdiv(n, 256)), dim3(256), 0, st, workspace, n, splits, dwhh);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(pe_cdiv(n / 4, 256)), dim3(256), 0, st, workspace, n, splits, dwhh);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }
