@@ -112,6 +112,10 @@ def main():
     ap.add_argument("--fp32-matmul", choices=["native", "x3"], default=None,
                     help="fp32 products on v_mfma_f32_32x32x2_f32 (native) or as an exact three-term bf16 split "
                          "on the bf16 MFMA pipe (x3, fp32-accurate); default: PE_FP32_MATMUL or the library default")
+    ap.add_argument("--family-timing", action="store_true",
+                    help="HIP events around EVERY C-ABI call (kernel_families_ms_per_step); by default only the "
+                         "roofline kernel's launches are bracketed, which keeps ~1400 event records per step out "
+                         "of the timed region")
     args = ap.parse_args()
     bf16 = args.precision == "bf16"
 
@@ -170,7 +174,9 @@ def main():
             print(f"[bench] warmup {i}: {time.perf_counter() - t_w:.3f} s loss {last['loss']:.4f}", file=sys.stderr,
                   flush=True)
     barrier()
-    ops.TIMER = ops.KernelTimer()
+    x3 = ops.FP32_MATMUL == "x3"
+    conv_key = "pe_conv3x3_fwd" + ("_bf16" if bf16 else "_x3" if x3 else "")
+    ops.TIMER = ops.KernelTimer(None if args.family_timing else {conv_key})
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = tr.run(batch)
@@ -189,8 +195,6 @@ def main():
         ms = elapsed / args.steps * 1e3
         frames = args.batch * world * FRAMES * args.steps
         summ = timer.summary()
-        x3 = ops.FP32_MATMUL == "x3"
-        conv_key = "pe_conv3x3_fwd" + ("_bf16" if bf16 else "_x3" if x3 else "")
         conv = summ.get(conv_key)
         roof = None
         if conv:

@@ -59,8 +59,9 @@ class KernelTimer:
     """Optional HIP-event timing of every C-ABI call (bench.py): events are recorded on the stream
     the kernels are launched on and read back after the timed region, so nothing synchronises."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.records = {}
+        self.only = None if only is None else frozenset(only)     # time just these entry points (None = all)
 
     def add(self, name, start, end, work):
         self.records.setdefault(name, []).append((start, end, work))
@@ -79,7 +80,7 @@ TIMER: KernelTimer | None = None
 
 def _call(name, *args, work=0.0):
     lib = _lib.load()
-    if TIMER is None:
+    if TIMER is None or (TIMER.only is not None and name not in TIMER.only):
         _lib.check(getattr(lib, name)(*args), name)
         return
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
