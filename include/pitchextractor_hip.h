@@ -182,6 +182,14 @@ int pe_lstm_fwd_persistent(int ncells, const float* const* whh, float* const* ga
 int pe_lstm_bwd_persistent(int ncells, const float* const* whh_t, float* const* gates,
                            const float* const* cbuf, const float* const* dy, const int* reverse, long lddy,
                            int B, int T, int H, unsigned* sync, void* stream);
+/* same recurrences with the recurrent products as the exact three-term bf16 split (H % 64 == 0; other
+ * hidden sizes run the native fp32 MFMA form) */
+int pe_lstm_fwd_persistent_x3(int ncells, const float* const* whh, float* const* gates, float* const* y,
+                           float* const* cbuf, const int* reverse, long ldy, int B, int T, int H,
+                           unsigned* sync, void* stream);
+int pe_lstm_bwd_persistent_x3(int ncells, const float* const* whh_t, float* const* gates,
+                           const float* const* cbuf, const float* const* dy, const int* reverse, long lddy,
+                           int B, int T, int H, unsigned* sync, void* stream);
 size_t pe_lstm_whh_grad_workspace_bytes(int B, int T, int H);
 int pe_lstm_whh_grad(const float* dgates, const float* y, long ldy, float* dwhh, int B, int T, int H,
                      int reverse, float* workspace, size_t workspace_bytes, void* stream);

@@ -53,6 +53,37 @@ struct PBwdCells {
 
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// X3 variants: the recurrent products run as the exact three-term bf16 split (gemm_engine.h).  The W_hh
+// slice is split once; its hi and mid terms stay in registers for the whole sequence, the lo terms of the
+// last blocks live in LDS (they feed one product in six and the register file is full).  The h / dgates
+// rows are split per use, one block ahead of the MFMAs that consume them.  One MFMA k-block = the 8 k of
+// each lane half (the halves own disjoint k ranges; any pairing is a valid k order).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split8(const float4& p, const float4& q, bf16x8 (&out)[3]) {
+  const f32x2 v[4] = {{p.x, p.y}, {p.z, p.w}, {q.x, q.y}, {q.z, q.w}};
+  u32x4 a, b, c;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const u32x2 u0 = __builtin_bit_cast(u32x2, v[i]);
+    const f32x2 r1 = v[i] - __builtin_bit_cast(f32x2, u0 & 0xffff0000u);
+    const u32x2 u1 = __builtin_bit_cast(u32x2, r1);
+    const f32x2 r2 = r1 - __builtin_bit_cast(f32x2, u1 & 0xffff0000u);
+    const u32x2 u2 = __builtin_bit_cast(u32x2, r2);
+    a[i] = __builtin_amdgcn_perm(u0[1], u0[0], 0x07060302u);
+    b[i] = __builtin_amdgcn_perm(u1[1], u1[0], 0x07060302u);
+    c[i] = __builtin_amdgcn_perm(u2[1], u2[0], 0x07060302u);
+  }
+  out[0] = __builtin_bit_cast(bf16x8, a);
+  out[1] = __builtin_bit_cast(bf16x8, b);
+  out[2] = __builtin_bit_cast(bf16x8, c);
+}
+constexpr int kTa[6] = {2, 0, 1, 1, 0, 0}, kTb[6] = {0, 2, 1, 0, 1, 0};   // (a term, b term), small first
+// blocks whose W lo term stays in registers; the rest (at most 32 KB per workgroup) goes to LDS
+template <int H> constexpr int fwd_lo_reg_blocks() { return (H / 64) <= 1 ? (H / 64) : 1; }
+template <int H> constexpr int bwd_lo_reg_blocks() { return (H / 16) <= 16 ? (H / 16) : 16; }
+
 // 16-byte write-through (sc1) store: the data leaves for memory, no release fence needed later.
 __device__ __forceinline__ void store_sc1(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, float4 v) {
   u32x4 d = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
@@ -95,7 +126,7 @@ __device__ __forceinline__ void group_wait(unsigned* ctr, unsigned target, unsig
 }
 
 // --------------------------------------------------------------------------------------- forward
-template <int H>
+template <int H, bool X3>
 __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_kernel(const PFwdCells cells, int B, int T, long ldy,
                                                                      unsigned y_bytes, unsigned* sync) {
   constexpr int KQ = H / 4, KH = KQ / 2, NV = KH / 4, NJ = H / 32;
@@ -104,7 +135,9 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_kernel(const PFwdC
   static_assert(H % 32 == 0, "hidden size is a multiple of 32");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                                 // [32][ASTR]
-  float* red = smem + 32 * ASTR;                    // [4][32][kRs]
+  // X3: the partial tiles reuse the operand rows' space (one more barrier per item buys 50 KB of LDS for
+  // W lo terms, i.e. 48 registers per lane)
+  float* red = X3 ? smem : smem + 32 * ASTR;        // [4][32][kRs]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const int nbt = (B + 63) / 64;
@@ -119,14 +152,31 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_kernel(const PFwdC
   const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(y, 0, y_bytes, 0x00020000);
 
   // W_hh slice of this wave / lane: rows {g*H + j0 + r}, k = wv*KQ + hh*KH + s
-  float bw[4][KH];
+  constexpr int NB = X3 ? KH / 8 : 1;               // 8-k blocks per lane (X3)
+  constexpr int NBR = X3 ? fwd_lo_reg_blocks<H>() : 1;
+  static_assert(!X3 || KH % 8 == 0, "X3 needs H % 64 == 0");
+  float bw[X3 ? 1 : 4][X3 ? 1 : KH];
+  bf16x8 bwhm[X3 ? 4 : 1][NB][2], bwlo[X3 ? 4 : 1][NBR];
+  uint4* wlo_lds = reinterpret_cast<uint4*>(smem + (4 * 32 * kRs > 32 * ASTR ? 4 * 32 * kRs : 32 * ASTR));   // [4][NB - NBR][256]
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const float* src = cells.whh[cell] + (long)(g * H + j0 + r) * H + wv * KQ + hh * KH;
+    if constexpr (X3) {
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      const float4 t4 = *reinterpret_cast<const float4*>(src + 4 * v);
-      bw[g][4 * v] = t4.x; bw[g][4 * v + 1] = t4.y; bw[g][4 * v + 2] = t4.z; bw[g][4 * v + 3] = t4.w;
+      for (int b = 0; b < NB; ++b) {
+        bf16x8 t3[3];
+        split8(*reinterpret_cast<const float4*>(src + 8 * b), *reinterpret_cast<const float4*>(src + 8 * b + 4), t3);
+        bwhm[g][b][0] = t3[0];
+        bwhm[g][b][1] = t3[1];
+        if (b < NBR) bwlo[g][b < NBR ? b : 0] = t3[2];
+        else wlo_lds[(g * (NB - NBR) + (b - NBR)) * 256 + tid] = __builtin_bit_cast(uint4, t3[2]);
+      }
+    } else {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const float4 t4 = *reinterpret_cast<const float4*>(src + 4 * v);
+        bw[g][4 * v] = t4.x; bw[g][4 * v + 1] = t4.y; bw[g][4 * v + 2] = t4.z; bw[g][4 * v + 3] = t4.w;
+      }
     }
   }
   const int prow = tid >> 3, pq = tid & 7;          // cell-update item: row prow, hidden units j0 + 4 pq .. +3
@@ -159,10 +209,13 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_kernel(const PFwdC
       const int pb = rb0 + prow;
       const long prow_i = (long)pb * T + t;
       float4 xp[4];
+      auto load_xp = [&]() {
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-        xp[g] = pb < B ? *reinterpret_cast<const float4*>(gates + prow_i * 4 * H + g * H + j0 + 4 * pq)
-                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int g = 0; g < 4; ++g)
+          xp[g] = pb < B ? *reinterpret_cast<const float4*>(gates + prow_i * 4 * H + g * H + j0 + 4 * pq)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+      };
+      if (!X3) load_xp();                           // X3: after the MFMA phase (the register file is full during it)
       f32x16 acc[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g)
@@ -177,12 +230,36 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_kernel(const PFwdC
         }
         __syncthreads();
       }
-      // next item's operand rows: (step, 1) after (step, 0); (step + 1, 0) after (step, 1)
-      {
+      // next item's operand rows: (step, 1) after (step, 0); (step + 1, 0) after (step, 1).  Native form:
+      // fetched before the MFMA phase (hidden under it).  X3: the register file is full of W terms during
+      // the MFMAs, so the fetch is issued right after them and lands under the cell update instead.
+      auto fetch_next = [&]() {
         const int step_n = hf == 0 ? step : step + 1, hf_n = hf ^ 1;
         if (step_n > 0 && step_n < T) fetch(step_n, hf_n);
+      };
+      if (!X3) fetch_next();
+      if (X3 && step > 0) {
+        if constexpr (X3) {
+          const float* asrc = As + r * ASTR + wv * KQ + hh * KH;
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            bf16x8 fa[3];                             // 36 VALU per 24 MFMAs: cheap enough not to pipeline
+            split8(*reinterpret_cast<const float4*>(asrc + 8 * b), *reinterpret_cast<const float4*>(asrc + 8 * b + 4),
+                   fa);
+            bf16x8 wl[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              wl[g] = b < NBR ? bwlo[g][b < NBR ? b : 0]
+                              : __builtin_bit_cast(bf16x8, wlo_lds[(g * (NB - NBR) + (b - NBR)) * 256 + tid]);
+#pragma unroll
+            for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+              for (int g = 0; g < 4; ++g)
+                acc[g] = mfma_bf16(fa[kTa[t6]], kTb[t6] == 2 ? wl[g] : bwhm[g][b][kTb[t6]], acc[g]);
+          }
+        }
       }
-      if (step > 0) {
+      if (!X3 && step > 0) {
         // operands come out of LDS in two chunks to keep the live register set small
         constexpr int AC = (NV % 2 == 0) ? NV / 2 : NV;
         const float* asrc = As + r * ASTR + wv * KQ + hh * KH;
@@ -199,6 +276,11 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_kernel(const PFwdC
 #pragma unroll
             for (int g = 0; g < 4; ++g) acc[g] = mfma32(av[s], bw[g][ch * 4 * AC + s], acc[g]);
         }
+      }
+      if (X3) {
+        load_xp();
+        fetch_next();
+        __syncthreads();                            // every wave is done reading As before red overwrites it
       }
 #pragma unroll
       for (int g = 0; g < 4; ++g)
@@ -250,7 +332,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_kernel(const PFwdC
 // --------------------------------------------------------------------------------------- backward
 // dh_t = dY_t + dgates_{t+1} . W_hh  (K = 4H: wave w owns gate block w; each lane half takes H/2
 // contiguous k, streamed through LDS in chunks of CH per lane).  W_hh^T rows j0 + r stay in registers.
-template <int H>
+template <int H, bool X3>
 __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_kernel(const PBwdCells cells, int B, int T, long lddy,
                                                                      unsigned g_bytes, unsigned* sync) {
   constexpr int KH = H / 2, NJ = H / 32, K = 4 * H;
@@ -277,13 +359,30 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_kernel(const PBwdC
   unsigned* ctr = sync + kCtrStride * (1 + (cell * nbt + bt) * 2);
   const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(gates, 0, g_bytes, 0x00020000);
 
-  float bw[KH];
+  constexpr int NBK = X3 ? KH / 8 : 1;              // 8-k blocks per lane (X3)
+  constexpr int NBR = X3 ? bwd_lo_reg_blocks<H>() : 1;
+  static_assert(!X3 || (KH % 8 == 0 && CH % 8 == 0), "X3 needs H % 16 == 0");
+  float bw[X3 ? 1 : KH];
+  bf16x8 bwhm[NBK][2], bwlo[NBR];
+  uint4* wlo_lds = reinterpret_cast<uint4*>(smem + 2 * 32 * ASTR + 4 * 32 * kRb);   // [NBK - NBR][256]
   {
     const float* src = cells.whh_t[cell] + (long)(j0 + r) * K + wv * H + hh * KH;
+    if constexpr (X3) {
 #pragma unroll
-    for (int v = 0; v < KH / 4; ++v) {
-      const float4 t4 = *reinterpret_cast<const float4*>(src + 4 * v);
-      bw[4 * v] = t4.x; bw[4 * v + 1] = t4.y; bw[4 * v + 2] = t4.z; bw[4 * v + 3] = t4.w;
+      for (int b = 0; b < NBK; ++b) {
+        bf16x8 t3[3];
+        split8(*reinterpret_cast<const float4*>(src + 8 * b), *reinterpret_cast<const float4*>(src + 8 * b + 4), t3);
+        bwhm[b][0] = t3[0];
+        bwhm[b][1] = t3[1];
+        if (b < NBR) bwlo[b < NBR ? b : 0] = t3[2];
+        else wlo_lds[(b - NBR) * 256 + tid] = __builtin_bit_cast(uint4, t3[2]);
+      }
+    } else {
+#pragma unroll
+      for (int v = 0; v < KH / 4; ++v) {
+        const float4 t4 = *reinterpret_cast<const float4*>(src + 4 * v);
+        bw[4 * v] = t4.x; bw[4 * v + 1] = t4.y; bw[4 * v + 2] = t4.z; bw[4 * v + 3] = t4.w;
+      }
     }
   }
   const int prow = tid >> 3, pq = tid & 7;
@@ -340,9 +439,9 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_kernel(const PBwdC
         in_c = *reinterpret_cast<const float4*>(cb + prow_i * H + j);
         if (has_prev) in_cp = *reinterpret_cast<const float4*>(cb + ((long)pb * T + tp) * H + j);
       }
-      f32x16 acc;
+      f32x16 acc, acc2;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+      for (int q = 0; q < 16; ++q) acc[q] = acc2[q] = 0.f;
       if (step > 0) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
@@ -360,16 +459,39 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_kernel(const PBwdC
           else fetch_next(step, hf);
           constexpr int AC = (CH / 4) % 2 == 0 ? CH / 8 : CH / 4;     // float4 per operand sub-chunk
           const float* asrc = cur + r * ASTR + (wv * 2 + hh) * CH;
+          if constexpr (X3) {
+            // two accumulators (even / odd blocks); the next block's operand is split under this block's MFMAs
+            bf16x8 fa[3];
+            split8(*reinterpret_cast<const float4*>(asrc), *reinterpret_cast<const float4*>(asrc + 4), fa);
 #pragma unroll
-          for (int sc = 0; sc < (CH / 4) / AC; ++sc) {
-            float av[4 * AC];
+            for (int b = 0; b < CH / 8; ++b) {
+              const int gb = c * (CH / 8) + b;                          // block index within this lane's k range
+              bf16x8 fn[3];
+              if (b + 1 < CH / 8)
+                split8(*reinterpret_cast<const float4*>(asrc + 8 * (b + 1)),
+                       *reinterpret_cast<const float4*>(asrc + 8 * (b + 1) + 4), fn);
+              const bf16x8 wl = gb < NBR ? bwlo[gb < NBR ? gb : 0]
+                                         : __builtin_bit_cast(bf16x8, wlo_lds[(gb - NBR) * 256 + tid]);
 #pragma unroll
-            for (int v = 0; v < AC; ++v) {
-              const float4 t4 = *reinterpret_cast<const float4*>(asrc + 4 * (sc * AC + v));
-              av[4 * v] = t4.x; av[4 * v + 1] = t4.y; av[4 * v + 2] = t4.z; av[4 * v + 3] = t4.w;
+              for (int t6 = 0; t6 < 6; ++t6) {
+                const bf16x8 wt = kTb[t6] == 2 ? wl : bwhm[gb][kTb[t6]];
+                if (b & 1) acc2 = mfma_bf16(fa[kTa[t6]], wt, acc2);
+                else acc = mfma_bf16(fa[kTa[t6]], wt, acc);
+              }
+              if (b + 1 < CH / 8) { fa[0] = fn[0]; fa[1] = fn[1]; fa[2] = fn[2]; }
             }
+          } else {
 #pragma unroll
-            for (int s2 = 0; s2 < 4 * AC; ++s2) acc = mfma32(av[s2], bw[c * CH + sc * 4 * AC + s2], acc);
+            for (int sc = 0; sc < (CH / 4) / AC; ++sc) {
+              float av[4 * AC];
+#pragma unroll
+              for (int v = 0; v < AC; ++v) {
+                const float4 t4 = *reinterpret_cast<const float4*>(asrc + 4 * (sc * AC + v));
+                av[4 * v] = t4.x; av[4 * v + 1] = t4.y; av[4 * v + 2] = t4.z; av[4 * v + 3] = t4.w;
+              }
+#pragma unroll
+              for (int s2 = 0; s2 < 4 * AC; ++s2) acc = mfma32(av[s2], bw[c * CH + sc * 4 * AC + s2], acc);
+            }
           }
         }
       } else {
@@ -378,7 +500,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_kernel(const PBwdC
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
-        red[(wv * 32 + row) * kRb + r] = acc[q];
+        red[(wv * 32 + row) * kRb + r] = X3 ? acc[q] + acc2[q] : acc[q];
       }
       __syncthreads();
       if (pb < B) {
@@ -431,41 +553,46 @@ int device_cus() {
   return cus;
 }
 
-template <int H>
-constexpr size_t fwd_lds() { return (size_t)(32 * (H + 4) + 4 * 32 * kRs) * sizeof(float); }
+template <int H, bool X3>
+constexpr size_t fwd_lds() {
+  constexpr int NB = H / 64, NBR = X3 ? fwd_lo_reg_blocks<H>() : NB;
+  constexpr size_t as = 32 * (H + 4), rd = 4 * 32 * kRs;
+  return X3 ? (as > rd ? as : rd) * sizeof(float) + (size_t)4 * (NB - NBR) * 256 * 16 : (as + rd) * sizeof(float);
+}
 
-template <int H>
+template <int H, bool X3>
 constexpr size_t bwd_lds() {
   constexpr int KH = H / 2;
   constexpr int CH = (KH % 48 == 0) ? 48 : 16;
-  return (size_t)(2 * 32 * (8 * CH + 4) + 4 * 32 * kRb) * sizeof(float);
+  constexpr int NBK = KH / 8, NBR = X3 ? bwd_lo_reg_blocks<H>() : NBK;
+  return (size_t)(2 * 32 * (8 * CH + 4) + 4 * 32 * kRb) * sizeof(float) + (X3 ? (size_t)(NBK - NBR) * 256 * 16 : 0);
 }
 
-template <int H>
+template <int H, bool X3>
 int launch_fwd(const PFwdCells& cells, int grid, int B, int T, long ldy, unsigned* sync, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
-    PE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_persistent_kernel<H>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds<H>()));
+    PE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_persistent_kernel<H, X3>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds<H, X3>()));
     attr = true;
   }
   const unsigned y_bytes = (unsigned)((size_t)B * T * ldy * sizeof(float));
-  hipLaunchKernelGGL(lstm_fwd_persistent_kernel<H>, dim3(grid), dim3(256), fwd_lds<H>(), st, cells, B, T, ldy, y_bytes,
+  hipLaunchKernelGGL((lstm_fwd_persistent_kernel<H, X3>), dim3(grid), dim3(256), (fwd_lds<H, X3>()), st, cells, B, T, ldy, y_bytes,
                      sync);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }
 
-template <int H>
+template <int H, bool X3>
 int launch_bwd(const PBwdCells& cells, int grid, int B, int T, long lddy, unsigned* sync, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
-    PE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_persistent_kernel<H>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds<H>()));
+    PE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_persistent_kernel<H, X3>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds<H, X3>()));
     attr = true;
   }
   const unsigned g_bytes = (unsigned)((size_t)B * T * 4 * H * sizeof(float));
-  hipLaunchKernelGGL(lstm_bwd_persistent_kernel<H>, dim3(grid), dim3(256), bwd_lds<H>(), st, cells, B, T, lddy,
+  hipLaunchKernelGGL((lstm_bwd_persistent_kernel<H, X3>), dim3(grid), dim3(256), (bwd_lds<H, X3>()), st, cells, B, T, lddy,
                      g_bytes, sync);
   PE_LAUNCH_CHECK();
   return PE_OK;
@@ -488,9 +615,9 @@ extern "C" int pe_lstm_persistent_supported(int ncells, int B, int H) {
   return grid <= device_cus() ? 1 : 0;
 }
 
-extern "C" int pe_lstm_fwd_persistent(int ncells, const float* const* whh, float* const* gates, float* const* y,
-                                      float* const* cbuf, const int* reverse, long ldy, int B, int T, int H,
-                                      unsigned* sync, void* stream) {
+static int lstm_fwd_persistent_impl(bool x3, int ncells, const float* const* whh, float* const* gates,
+                                    float* const* y, float* const* cbuf, const int* reverse, long ldy, int B, int T,
+                                    int H, unsigned* sync, void* stream) {
   if (!whh || !gates || !y || !cbuf || !reverse || !sync || T <= 0) return PE_E_ARG;
   if (!pe_lstm_persistent_supported(ncells, B, H) || (ldy & 3)) return PE_E_UNSUPPORTED;
   if ((size_t)B * T * ldy * sizeof(float) >= (1ull << 32)) return PE_E_UNSUPPORTED;      // 32-bit buffer offsets
@@ -504,18 +631,32 @@ extern "C" int pe_lstm_fwd_persistent(int ncells, const float* const* whh, float
   // word 0 is the sticky error flag (cleared only by the owner of the buffer); counters start at line 1
   PE_CHECK_HIP(hipMemsetAsync(sync + kCtrStride, 0, pe_lstm_persistent_sync_bytes(ncells, B) - kCtrStride * 4, st));
   const int grid = ncells * ((B + 63) / 64) * (H / 32);
-  switch (H) {
-    case 32: return launch_fwd<32>(cells, grid, B, T, ldy, sync, st);
-    case 64: return launch_fwd<64>(cells, grid, B, T, ldy, sync, st);
-    case 96: return launch_fwd<96>(cells, grid, B, T, ldy, sync, st);
-    case 384: return launch_fwd<384>(cells, grid, B, T, ldy, sync, st);
+  switch (H) {                                   // the split form needs H % 64 == 0; other sizes stay native
+    case 32: return launch_fwd<32, false>(cells, grid, B, T, ldy, sync, st);
+    case 64: return x3 ? launch_fwd<64, true>(cells, grid, B, T, ldy, sync, st)
+                       : launch_fwd<64, false>(cells, grid, B, T, ldy, sync, st);
+    case 96: return launch_fwd<96, false>(cells, grid, B, T, ldy, sync, st);
+    case 384: return x3 ? launch_fwd<384, true>(cells, grid, B, T, ldy, sync, st)
+                        : launch_fwd<384, false>(cells, grid, B, T, ldy, sync, st);
   }
   return PE_E_UNSUPPORTED;
 }
 
-extern "C" int pe_lstm_bwd_persistent(int ncells, const float* const* whh_t, float* const* gates,
-                                      const float* const* cbuf, const float* const* dy, const int* reverse,
-                                      long lddy, int B, int T, int H, unsigned* sync, void* stream) {
+extern "C" int pe_lstm_fwd_persistent(int ncells, const float* const* whh, float* const* gates, float* const* y,
+                                      float* const* cbuf, const int* reverse, long ldy, int B, int T, int H,
+                                      unsigned* sync, void* stream) {
+  return lstm_fwd_persistent_impl(false, ncells, whh, gates, y, cbuf, reverse, ldy, B, T, H, sync, stream);
+}
+
+extern "C" int pe_lstm_fwd_persistent_x3(int ncells, const float* const* whh, float* const* gates, float* const* y,
+                                         float* const* cbuf, const int* reverse, long ldy, int B, int T, int H,
+                                         unsigned* sync, void* stream) {
+  return lstm_fwd_persistent_impl(true, ncells, whh, gates, y, cbuf, reverse, ldy, B, T, H, sync, stream);
+}
+
+static int lstm_bwd_persistent_impl(bool x3, int ncells, const float* const* whh_t, float* const* gates,
+                                    const float* const* cbuf, const float* const* dy, const int* reverse, long lddy,
+                                    int B, int T, int H, unsigned* sync, void* stream) {
   if (!whh_t || !gates || !cbuf || !dy || !reverse || !sync || T <= 0) return PE_E_ARG;
   if (!pe_lstm_persistent_supported(ncells, B, H) || (lddy & 3)) return PE_E_UNSUPPORTED;
   if ((size_t)B * T * 4 * H * sizeof(float) >= (1ull << 32)) return PE_E_UNSUPPORTED;
@@ -529,10 +670,24 @@ extern "C" int pe_lstm_bwd_persistent(int ncells, const float* const* whh_t, flo
   PE_CHECK_HIP(hipMemsetAsync(sync + kCtrStride, 0, pe_lstm_persistent_sync_bytes(ncells, B) - kCtrStride * 4, st));
   const int grid = ncells * ((B + 63) / 64) * (H / 32);
   switch (H) {
-    case 32: return launch_bwd<32>(cells, grid, B, T, lddy, sync, st);
-    case 64: return launch_bwd<64>(cells, grid, B, T, lddy, sync, st);
-    case 96: return launch_bwd<96>(cells, grid, B, T, lddy, sync, st);
-    case 384: return launch_bwd<384>(cells, grid, B, T, lddy, sync, st);
+    case 32: return launch_bwd<32, false>(cells, grid, B, T, lddy, sync, st);
+    case 64: return x3 ? launch_bwd<64, true>(cells, grid, B, T, lddy, sync, st)
+                       : launch_bwd<64, false>(cells, grid, B, T, lddy, sync, st);
+    case 96: return launch_bwd<96, false>(cells, grid, B, T, lddy, sync, st);
+    case 384: return x3 ? launch_bwd<384, true>(cells, grid, B, T, lddy, sync, st)
+                        : launch_bwd<384, false>(cells, grid, B, T, lddy, sync, st);
   }
   return PE_E_UNSUPPORTED;
+}
+
+extern "C" int pe_lstm_bwd_persistent(int ncells, const float* const* whh_t, float* const* gates,
+                                      const float* const* cbuf, const float* const* dy, const int* reverse,
+                                      long lddy, int B, int T, int H, unsigned* sync, void* stream) {
+  return lstm_bwd_persistent_impl(false, ncells, whh_t, gates, cbuf, dy, reverse, lddy, B, T, H, sync, stream);
+}
+
+extern "C" int pe_lstm_bwd_persistent_x3(int ncells, const float* const* whh_t, float* const* gates,
+                                         const float* const* cbuf, const float* const* dy, const int* reverse,
+                                         long lddy, int B, int T, int H, unsigned* sync, void* stream) {
+  return lstm_bwd_persistent_impl(true, ncells, whh_t, gates, cbuf, dy, reverse, lddy, B, T, H, sync, stream);
 }

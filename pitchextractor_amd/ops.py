@@ -115,6 +115,14 @@ def _tn_suffix():
     return "_x3" if FP32_MATMUL == "x3" else ""
 
 
+# which persistent LSTM recurrences use the three-term split when FP32_MATMUL == "x3" (tools/bench_lstm.py)
+LSTM_X3 = {"fwd": os.environ.get("PE_LSTM_X3_FWD", "1") == "1", "bwd": os.environ.get("PE_LSTM_X3_BWD", "1") == "1"}
+
+
+def _lstm_suffix(which):
+    return "_x3" if (FP32_MATMUL == "x3" and LSTM_X3[which]) else ""
+
+
 def _nt_suffix():
     if MATMUL_BF16:
         return "_bf16"
@@ -462,7 +470,7 @@ def lstm_fwd(whh, gates, y_slices, cbuf, reverse, B, T, H):
     dev = gates[0].device
     if _persistent_ok(n, B, H, dev):
         sync = _lstm_sync(n, B, dev)
-        _call("pe_lstm_fwd_persistent", n, _ptr_array(whh), _ptr_array(gates), _ptr_array(y_slices),
+        _call("pe_lstm_fwd_persistent" + _lstm_suffix("fwd"), n, _ptr_array(whh), _ptr_array(gates), _ptr_array(y_slices),
               _ptr_array(cbuf), _int_array(reverse), ldy, B, T, H, sync.data_ptr(), _s(),
               work=2.0 * n * B * (T - 1) * 4 * H * H)
         return
@@ -487,7 +495,7 @@ def lstm_bwd(whh_t, gates, cbuf, dy_slices, dcarry, reverse, B, T, H):
     dev = gates[0].device
     if _persistent_ok(n, B, H, dev):
         sync = _lstm_sync(n, B, dev)
-        _call("pe_lstm_bwd_persistent", n, _ptr_array(whh_t), _ptr_array(gates), _ptr_array(cbuf),
+        _call("pe_lstm_bwd_persistent" + _lstm_suffix("bwd"), n, _ptr_array(whh_t), _ptr_array(gates), _ptr_array(cbuf),
               _ptr_array(dy_slices), _int_array(reverse), ld, B, T, H, sync.data_ptr(), _s(),
               work=2.0 * n * B * (T - 1) * 4 * H * H)
         return
