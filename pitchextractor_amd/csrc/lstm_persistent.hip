@@ -22,6 +22,11 @@
 // (L1-bypassing), which replaces the acquire fence (guide: Valid forms, first table row).  Spins are bounded (sticky error word, all later waits fall through); counters are
 // zeroed by a memset node in front of every launch; the grid (<= 192 workgroups at one per CU)
 // must be co-resident, so the host refuses shapes that exceed the device's CU count.
+//
+// Template flag X3 (the *_x3 entry points, H % 64 == 0): the recurrent products run on the bf16 MFMA pipe
+// as the exact three-term split of gemm_engine.h -- W hi/mid terms in registers, lo terms in LDS, operand
+// rows split per use -- 144 v_mfma_f32_32x32x16_bf16 per item and wave instead of 192 fp32 MFMAs of
+// twice the cycles.  Everything about the hand-off protocol is identical in both forms.
 #include "gemm_engine.h"
 
 namespace {
