@@ -146,7 +146,8 @@ static int gemm_nt_impl(const float* A, long lda, const float* B, long ldb, floa
   hipStream_t st = pe_stream(stream);
   if (N <= 32) return launch_nt<Tile<128, 32, 4, 1>, MODE>(al, bl, ep, M, N, K, st);
   if (N <= 64) return launch_nt<Tile<256, 64, 4, 1>, MODE>(al, bl, ep, M, N, K, st);
-  if (N % 192 == 0 && N % 128 != 0) return launch_nt<Tile<128, 192, 2, 2>, MODE>(al, bl, ep, M, N, K, st);
+  if (N % 192 == 0 && (N % 128 != 0 || MODE != kNative))     // bf16-term modes: the wider tile stages 17 % fewer rows per MFMA
+    return launch_nt<Tile<128, 192, 2, 2>, MODE>(al, bl, ep, M, N, K, st);
   return launch_nt<Tile<128, 128, 2, 2>, MODE>(al, bl, ep, M, N, K, st);
 }
 
