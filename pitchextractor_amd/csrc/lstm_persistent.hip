@@ -130,6 +130,22 @@ __device__ __forceinline__ void group_wait(unsigned* ctr, unsigned target, unsig
   __syncthreads();
 }
 
+// Workgroup -> (group, member).  A group's NJ workgroups all read the same operand rows (h_{t-1} forward,
+// dgates_{t+1} backward) and hand each other their results, so they are placed on ONE XCD (hardware
+// dispatches workgroup b to XCD b % 8): the 12-fold re-read then hits that XCD's L2 instead of crossing
+// the fabric (PMC: 13 GB per backward launch with the round-robin order) and the sc1 hand-off stays local.
+__device__ __forceinline__ void group_of_block(int NJ, int& jt, int& gidx) {
+  const int ngroups = gridDim.x / NJ;
+  if ((ngroups & 7) == 0) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    gidx = xcd * (ngroups >> 3) + slot / NJ;
+    jt = slot % NJ;
+  } else {
+    gidx = blockIdx.x / NJ;
+    jt = blockIdx.x % NJ;
+  }
+}
+
 // --------------------------------------------------------------------------------------- forward
 template <int H, bool X3>
 __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_kernel(const PFwdCells cells, int B, int T, long ldy,
@@ -146,7 +162,9 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_kernel(const PFwdC
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const int nbt = (B + 63) / 64;
-  const int jt = blockIdx.x % NJ, bt = (blockIdx.x / NJ) % nbt, cell = blockIdx.x / (NJ * nbt);
+  int jt, gidx;
+  group_of_block(NJ, jt, gidx);                    // the NJ workgroups of a group share one XCD
+  const int bt = gidx % nbt, cell = gidx / nbt;
   const int j0 = jt * 32, b0 = bt * 64;
   const int rev = cells.reverse[cell];
   float* y = cells.y[cell];
@@ -354,7 +372,9 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_kernel(const PBwdC
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const int nbt = (B + 63) / 64;
-  const int jt = blockIdx.x % NJ, bt = (blockIdx.x / NJ) % nbt, cell = blockIdx.x / (NJ * nbt);
+  int jt, gidx;
+  group_of_block(NJ, jt, gidx);                    // the NJ workgroups of a group share one XCD
+  const int bt = gidx % nbt, cell = gidx / nbt;
   const int j0 = jt * 32, b0 = bt * 64;
   const int rev = cells.reverse[cell];
   float* gates = cells.gates[cell];
