@@ -208,20 +208,20 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_kernel(const PFwdC
 
   // Software pipeline over items (step, half): while item i runs its MFMAs, the h rows of item i+1
   // (published a half-phase ago by the group) are already in flight into `stage`.
-  constexpr int NST = (32 * ROW4) / 256;
+  constexpr int NST = ROW4 / 8;                     // float4 per thread: 8 threads cover a row in NST passes
+  static_assert(ROW4 % 8 == 0, "hidden size is a multiple of 32");
   float4 stage[NST];
   auto fetch = [&](int step_n, int hf_n) {            // wait for + load h_{t-1} rows of item (step_n, hf_n)
     const int tn_ = rev ? T - 1 - step_n : step_n;
     const int tpn = rev ? tn_ + 1 : tn_ - 1;
     group_wait(ctr + kCtrStride * hf_n, (unsigned)(NJ * step_n), err);
+    // staging assignment: 8 threads per row, float4 column (tid & 7) + 8 j -- one multiply per fetch and an
+    // immediate offset per load (byte offsets fit 32 bits: checked by the host)
+    const int brow = b0 + 32 * hf_n + (tid >> 3);
+    const unsigned base = ((unsigned)(brow * T + tpn) * (unsigned)ldy + (unsigned)(tid & 7) * 4u) * 4u;
 #pragma unroll
-    for (int v = 0; v < NST; ++v) {
-      const int idx = tid + 256 * v;
-      const int row = idx / ROW4, c4 = idx - row * ROW4;
-      stage[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (b0 + 32 * hf_n + row < B)
-        stage[v] = load_sc1(yrs, (unsigned)((((long)(b0 + 32 * hf_n + row) * T + tpn) * ldy + c4 * 4) * 4));
-    }
+    for (int v = 0; v < NST; ++v)
+      stage[v] = brow < B ? load_sc1(yrs, base + (unsigned)v * 128u) : make_float4(0.f, 0.f, 0.f, 0.f);
   };
 
   for (int step = 0; step < T; ++step) {
@@ -245,12 +245,9 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_kernel(const PFwdC
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[g][q] = 0.f;
       if (step > 0) {
+        float* adst = As + (tid >> 3) * ASTR + (tid & 7) * 4;
 #pragma unroll
-        for (int v = 0; v < NST; ++v) {
-          const int idx = tid + 256 * v;
-          const int row = idx / ROW4, c4 = idx - row * ROW4;
-          *reinterpret_cast<float4*>(As + row * ASTR + c4 * 4) = stage[v];
-        }
+        for (int v = 0; v < NST; ++v) *reinterpret_cast<float4*>(adst + 32 * v) = stage[v];
         __syncthreads();
       }
       // next item's operand rows: (step, 1) after (step, 0); (step + 1, 0) after (step, 1).  Native form:
@@ -419,17 +416,19 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_kernel(const PBwdC
   // `stage` always holds the chunk that is committed next; across items it carries chunk 0 of the
   // next (step, half), fetched behind that item's group wait while this item still computes.
   float4 stage[NLD];
+  // staging assignment: 8 threads per row, float4 column (tid & 7) + 8 v of the chunk's 8*CH staged floats;
+  // 32-bit offsets (checked by the host), one multiply per chunk
   auto load_chunk = [&](int rb0_, int tn_, int c) {
-    int tid_o = tid;
-    asm volatile("" : "+v"(tid_o));                   // keep the address math inside the loop (no hoist + spill)
+    int t7 = tid & 7;
+    asm volatile("" : "+v"(t7));                      // keep the (cheap) column math in place: hoisting it spills
+    const int brow = rb0_ + (tid >> 3);
+    const unsigned rowbase = (unsigned)(brow * T + tn_) * (unsigned)K;
 #pragma unroll
     for (int v = 0; v < NLD; ++v) {
-      const int idx = tid_o + 256 * v;
-      const int row = idx / ROW4, c4 = idx - row * ROW4;
-      const int seg = (c4 * 4) / CH, e = c4 * 4 - seg * CH;
+      const int el = (t7 + 8 * v) * 4;
+      const int seg = el / CH, e = el - seg * CH;
       const int k = (seg >> 1) * H + (seg & 1) * KH + c * CH + e;
-      stage[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (rb0_ + row < B) stage[v] = load_sc1(grs, (unsigned)((((long)(rb0_ + row) * T + tn_) * K + k) * 4));
+      stage[v] = brow < B ? load_sc1(grs, (rowbase + (unsigned)k) * 4u) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto fetch_next = [&](int step, int hf) {          // (step, 0) -> (step, 1) -> (step + 1, 0)
@@ -471,14 +470,9 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_kernel(const PBwdC
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
           float* cur = As0 + (c & 1) * 32 * ASTR;
-          int tid_c = tid;
-          asm volatile("" : "+v"(tid_c));
+          float* adst = cur + (tid >> 3) * ASTR + (tid & 7) * 4;
 #pragma unroll
-          for (int v = 0; v < NLD; ++v) {
-            const int idx = tid_c + 256 * v;
-            const int row = idx / ROW4, c4 = idx - row * ROW4;
-            *reinterpret_cast<float4*>(cur + row * ASTR + c4 * 4) = stage[v];
-          }
+          for (int v = 0; v < NLD; ++v) *reinterpret_cast<float4*>(adst + 32 * v) = stage[v];
           __syncthreads();
           if (c + 1 < NCH) load_chunk(rb0, tn, c + 1);
           else fetch_next(step, hf);
