@@ -56,7 +56,19 @@ struct PBwdCells {
   int reverse[kMaxCells];
 };
 
-__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Gate non-linearities on the hardware exp2 / rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each).  The libm expf /
+// tanhf cost ~650 VALU instructions per thread and item (s_memtime: 4 260 of 16 900 cycles of a forward
+// item); these cost ~150 and agree with them to ~3e-7 (tests/test_ops_gpu.py holds the layer to 1e-5).
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + fast_exp(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) {
+  const float ax = fabsf(x), x2 = x * x;
+  const float e = fast_exp(-2.0f * ax);
+  const float big = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);          // |x| >= 0.25: no harmful cancellation
+  const float small = ax * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 62.0f / 2835.0f, -17.0f / 315.0f), 2.0f / 15.0f),
+                                         -1.0f / 3.0f), 1.0f);             // odd series, next term < 2e-9 at 0.25
+  return copysignf(ax < 0.25f ? small : big, x);
+}
 
 // X3 variants: the recurrent products run as the exact three-term bf16 split (gemm_engine.h).  The W_hh
 // slice is split once; its hi and mid terms stay in registers for the whole sequence, the lo terms of the
@@ -84,7 +96,9 @@ __device__ __forceinline__ void split8(const float4& p, const float4& q, bf16x8 
   out[1] = __builtin_bit_cast(bf16x8, b);
   out[2] = __builtin_bit_cast(bf16x8, c);
 }
-constexpr int kTa[6] = {2, 0, 1, 1, 0, 0}, kTb[6] = {0, 2, 1, 0, 1, 0};   // (a term, b term), small first
+// (a term, b term) of the six products.  a_hi x W_lo goes last: W_lo may come from LDS, and its read then
+// completes under the five products that do not need it.
+constexpr int kTa[6] = {2, 1, 1, 0, 0, 0}, kTb[6] = {0, 1, 0, 1, 0, 2};
 // blocks whose W lo term stays in registers; the rest (at most 32 KB per workgroup) goes to LDS
 template <int H> constexpr int fwd_lo_reg_blocks() { return (H / 64) <= 1 ? (H / 64) : 1; }
 template <int H> constexpr int bwd_lo_reg_blocks() { return (H / 16) <= 16 ? (H / 16) : 16; }
@@ -275,7 +289,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_kernel(const PFwdC
             for (int t6 = 0; t6 < 6; ++t6)
 #pragma unroll
               for (int g = 0; g < 4; ++g)
-                acc[g] = mfma_bf16(fa[kTa[t6]], kTb[t6] == 2 ? wl[g] : bwhm[g][b][kTb[t6]], acc[g]);
+                acc[g] = mfma_bf16(kTb[t6] == 2 ? wl[g] : bwhm[g][b][kTb[t6]], fa[kTa[t6]], acc[g]);
           }
         }
       }
@@ -294,7 +308,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_kernel(const PFwdC
 #pragma unroll
           for (int s = 0; s < 4 * AC; ++s)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = mfma32(av[s], bw[g][ch * 4 * AC + s], acc[g]);
+            for (int g = 0; g < 4; ++g) acc[g] = mfma32(bw[g][ch * 4 * AC + s], av[s], acc[g]);
         }
       }
       if (X3) {
@@ -302,13 +316,14 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_kernel(const PFwdC
         fetch_next();
         __syncthreads();                            // every wave is done reading As before red overwrites it
       }
+      // W is the MFMA A operand, so a lane holds 4 consecutive hidden units of ONE batch row per register
+      // quad: the partial tiles go out as 16 ds_write_b128 instead of 64 ds_write_b32
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
-          red[(wv * 32 + row) * kRs + g * 32 + r] = acc[g][q];
-        }
+        for (int q4 = 0; q4 < 4; ++q4)
+          *reinterpret_cast<float4*>(red + (wv * 32 + r) * kRs + g * 32 + 8 * q4 + 4 * hh) =
+              make_float4(acc[g][4 * q4], acc[g][4 * q4 + 1], acc[g][4 * q4 + 2], acc[g][4 * q4 + 3]);
       __syncthreads();
       if (pb < B) {
         float4 pre[4];
@@ -326,7 +341,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_kernel(const PFwdC
         }
         const float4 gi = make_float4(sigm(pre[0].x), sigm(pre[0].y), sigm(pre[0].z), sigm(pre[0].w));
         const float4 gf = make_float4(sigm(pre[1].x), sigm(pre[1].y), sigm(pre[1].z), sigm(pre[1].w));
-        const float4 gg = make_float4(tanhf(pre[2].x), tanhf(pre[2].y), tanhf(pre[2].z), tanhf(pre[2].w));
+        const float4 gg = make_float4(tanh_fast(pre[2].x), tanh_fast(pre[2].y), tanh_fast(pre[2].z), tanh_fast(pre[2].w));
         const float4 go = make_float4(sigm(pre[3].x), sigm(pre[3].y), sigm(pre[3].z), sigm(pre[3].w));
         float4 cn;
         cn.x = gf.x * creg[hf].x + gi.x * gg.x;
@@ -334,7 +349,8 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_kernel(const PFwdC
         cn.z = gf.z * creg[hf].z + gi.z * gg.z;
         cn.w = gf.w * creg[hf].w + gi.w * gg.w;
         creg[hf] = cn;
-        const float4 hv = make_float4(go.x * tanhf(cn.x), go.y * tanhf(cn.y), go.z * tanhf(cn.z), go.w * tanhf(cn.w));
+        const float4 hv = make_float4(go.x * tanh_fast(cn.x), go.y * tanh_fast(cn.y), go.z * tanh_fast(cn.z),
+                                      go.w * tanh_fast(cn.w));
         // h_t first and write-through: it is what the other workgroups wait for
         store_sc1(yrs, (unsigned)((prow_i * ldy + j0 + 4 * pq) * 4), hv);
         float* gp = gates + prow_i * 4 * H + j0 + 4 * pq;
@@ -540,7 +556,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_kernel(const PBwdC
         float oi[4], of[4], og[4], oo[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float tc = tanhf(cn[e]);
+          const float tc = tanh_fast(cn[e]);
           const float dc = dhv[e] * go[e] * (1.f - tc * tc) + dcv[e];
           oi[e] = dc * gg[e] * gi[e] * (1.f - gi[e]);
           of[e] = dc * cp[e] * gf[e] * (1.f - gf[e]);
