@@ -207,7 +207,7 @@ def main():
                                                            f"is {MFMA_F32_PEAK_TFLOPS} TFLOP/s")
             else:
                 peak, note = MFMA_F32_PEAK_TFLOPS, "fp32 MFMA (32x32x2) peak"
-            roof = {"bound": "mfma", "kernel": "conv3x3_kernel (implicit-GEMM fwd + dgrad launches)",
+            roof = {"bound": "mfma", "kernel": ("conv3x3_kernel (implicit-GEMM fwd + dgrad launches)" if not (bf16 or x3) else "conv3x3_halo_kernel (halo-staged implicit-GEMM fwd + dgrad launches)"),
                     "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak,
                     "peak_note": note, "traffic": pmc_traffic(conv_key),
                     "avg_launch_ms": conv["avg_ms"], "launches_per_step": conv["calls"] / args.steps}
