@@ -85,7 +85,8 @@ int launch_conv(const float* x, const float* wp, float* y, int B, int T, int F, 
 // bytes reach the fabric).  This kernel stages, per 32-channel chunk, the whole input window of its 128
 // output pixels once -- the 128 + 2F + 2 consecutive pixels [p0 - F - 1, p0 + 128 + F] -- and lets the nine
 // taps read it at nine row offsets; only the weights change per tap.  A neighbour that the flat offset
-// takes across an image border (other time row / other utterance) is masked per output pixel and tap.
+// takes across an image border (other time row / other utterance) is redirected, per output pixel and
+// tap, to an all-zero row of the image.
 //
 // bf16-term images in LDS are [row][32 k] with NO padding: the 16-byte chunk c of a row sits at chunk
 // c ^ ((row >> 2) & 3), which keeps ds_read_b128 fragment reads (32 consecutive rows at any offset) and the
@@ -116,7 +117,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const float* __res
                                                               int C, int N, int P, int tiles_m, int tiles_n) {
   constexpr int NT = MODE == kSplit ? 3 : 1;
   constexpr int TM = 2, TN = BN / 64, WN = BN / 2;
-  constexpr int AIMG = PASSES * 32 * 32, BIMG = BN * 32;           // bf16 elements per image
+  constexpr int ZR = PASSES * 32;                                  // an all-zero row behind the window
+  constexpr int AIMG = (ZR + 4) * 32, BIMG = BN * 32;              // bf16 elements per image
   constexpr int BL = BN / 32;                                      // weight float4 per thread per stage
   __shared__ __attribute__((aligned(16))) __bf16 As[NT * AIMG];
   __shared__ __attribute__((aligned(16))) __bf16 Bs[NT * BIMG];
@@ -173,6 +175,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const float* __res
 #pragma unroll
       for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
 
+  if (tid < 8) {
+#pragma unroll
+    for (int c = 0; c < NT; ++c) *reinterpret_cast<uint2*>(As + c * AIMG + ZR * 32 + tid * 4) = make_uint2(0u, 0u);
+  }
   fetch_a(0);
   fetch_b(0);
   const int nstages = nchunks * 9;
@@ -196,14 +202,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const float* __res
         bf16x8 fa[TM][NT], fb[TN][NT];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-          const int row = wm * 64 + i * 32 + r + shift;
-          const unsigned m = (vbits[i] >> tap) & 1u ? 0xffffffffu : 0u;
+          // a neighbour across an image border reads the zero row instead: one select on the address in place
+          // of masking every fragment register (VALU beside the MFMAs costs matrix-pipe issue time)
+          const int row = (vbits[i] >> tap) & 1u ? wm * 64 + i * 32 + r + shift : ZR;
 #pragma unroll
-          for (int c = 0; c < NT; ++c) {
-            uint4 v = *reinterpret_cast<const uint4*>(As + c * AIMG + swz_off(row, kk * 2 + h));
-            v.x &= m; v.y &= m; v.z &= m; v.w &= m;
-            fa[i][c] = __builtin_bit_cast(bf16x8, v);
-          }
+          for (int c = 0; c < NT; ++c)
+            fa[i][c] = *reinterpret_cast<const bf16x8*>(As + c * AIMG + swz_off(row, kk * 2 + h));
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
