@@ -157,14 +157,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const float* __res
       if (wr < WR && q >= 0 && q < P) ra[ps] = *reinterpret_cast<const float4*>(x + q * C + cc * 32 + piece * 4);
     }
   };
+  // weight rows of this thread: the 64-bit row offsets are formed once, a stage adds a wave-uniform k offset
+  const float* wrow[BL];
+#pragma unroll
+  for (int i = 0; i < BL; ++i) {
+    const int n = n0 + i * 32 + srow;
+    wrow[i] = wp + (long)(n < N ? n : 0) * K + piece * 4;
+  }
   auto fetch_b = [&](int stage) {                                  // stage = cc * 9 + tap
     const int cc = stage / 9, tap = stage - cc * 9;
-    const int k0 = tap * C + cc * 32 + piece * 4;
+    const int k0 = tap * C + cc * 32;
 #pragma unroll
-    for (int i = 0; i < BL; ++i) {
-      const int n = n0 + i * 32 + srow;
-      rb[i] = n < N ? *reinterpret_cast<const float4*>(wp + (long)n * K + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int i = 0; i < BL; ++i)
+      rb[i] = n0 + i * 32 + srow < N ? *reinterpret_cast<const float4*>(wrow[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
   };
 
   f32x16 acc[TM][TN];
