@@ -16,7 +16,12 @@
  *     F = mel/frequency axis, C = channels); conv weights are handed over in
  *     the reference's OIHW order and repacked on the device;
  *   - return value: 0 = ok, negative = invalid argument (PE_E_*), positive =
- *     hipError_t of a failed runtime call.
+ *     hipError_t of a failed runtime call;
+ *   - MFMA-bound entry points come in up to three forms with one contract:
+ *       name       fp32 products on v_mfma_f32_32x32x2_f32;
+ *       name_x3    fp32-accurate products as an exact three-term bf16 split on
+ *                  v_mfma_f32_32x32x16_bf16 (the host side's default);
+ *       name_bf16  operands rounded to bf16, fp32 accumulate (mixed precision).
  */
 #ifndef PITCHEXTRACTOR_HIP_H
 #define PITCHEXTRACTOR_HIP_H
