@@ -239,15 +239,36 @@ void whh_plan(int M, int N, int K, int mode, int* splits, int* kps) {
 // ------------------------------------------------------------------ column sums (bias gradients)
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, long rows, int cols,
                                                              long ld, double* __restrict__ partial) {
-  // grid.x over column blocks of 256, grid.y over row chunks
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cols) return;
+  // grid.x over column blocks of 256 (64 float4 quads), grid.y over row chunks; the block's 4 row lanes take
+  // every 4th row of the chunk with float4 loads, four rows in flight per lane (cols % 4 == 0, ld % 4 == 0)
+  __shared__ double red[4][256];
+  const int q = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = blockIdx.x * 256 + q * 4;
   const long chunk = (rows + gridDim.y - 1) / gridDim.y;
   const long r0 = (long)blockIdx.y * chunk;
   const long r1 = r0 + chunk < rows ? r0 + chunk : rows;
-  double s = 0;
-  for (long r = r0; r < r1; ++r) s += x[r * ld + c];
-  partial[(long)blockIdx.y * cols + c] = s;
+  double s[4] = {0, 0, 0, 0};
+  if (c < cols) {
+    long r = r0 + ry;
+    for (; r + 12 < r1; r += 16) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(x + (r + 4 * u) * ld + c);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { s[0] += v[u].x; s[1] += v[u].y; s[2] += v[u].z; s[3] += v[u].w; }
+    }
+    for (; r < r1; r += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(x + r * ld + c);
+      s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[ry][q * 4 + e] = s[e];
+  __syncthreads();
+  const int cc = blockIdx.x * 256 + threadIdx.x;
+  if (cc < cols)
+    partial[(long)blockIdx.y * cols + cc] = (red[0][threadIdx.x] + red[1][threadIdx.x]) +
+                                            (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 __global__ void colsum_final_kernel(const double* __restrict__ partial, int nparts, int cols, float* out0,
@@ -362,6 +383,7 @@ extern "C" size_t pe_colsum_workspace_bytes(int cols) { return (size_t)kColsumPa
 extern "C" int pe_colsum(const float* x, long rows, int cols, long ld, float* out0, float* out1, void* workspace,
                          size_t workspace_bytes, void* stream) {
   if (!x || !out0 || rows <= 0 || cols <= 0) return PE_E_ARG;
+  if ((cols & 3) || (ld & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) return PE_E_UNSUPPORTED;   // float4 loads
   if (!workspace || workspace_bytes < pe_colsum_workspace_bytes(cols)) return PE_E_WORKSPACE;
   double* partial = reinterpret_cast<double*>(workspace);
   const int parts = rows < kColsumParts ? (int)rows : kColsumParts;

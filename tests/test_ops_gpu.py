@@ -405,6 +405,15 @@ def test_bins_ce_loss_matches_float64_oracle(hip_device):
     assert out4[1].item() == 0.0 and (d_logits == 0).all()
 
 
+@pytest.mark.parametrize("rows,cols", [(1000, 360), (49152 // 8, 1536), (3, 8), (257, 512)])
+def test_colsum(hip_device, rows, cols):
+    x = rnd(rows, cols, seed=9)
+    a, b = torch.empty(cols, device=hip_device), torch.empty(cols, device=hip_device)
+    ops.colsum(x.to(hip_device), a, b)
+    close(a, x.double().sum(0), tol=1e-6)
+    assert torch.equal(a, b)
+
+
 def test_adamw_matches_torch(hip_device):
     n = 1003
     p0, grads = rnd(n, seed=1), [rnd(n, seed=10 + i) for i in range(6)]
