@@ -342,7 +342,17 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
     const int fo = (int)(op % Fout);
     const float* xp = x + ((row * Fin + (long)fo * pool) * C + q * 4);
     float4 m = *reinterpret_cast<const float4*>(xp);
-    for (int j = 1; j < pool; ++j) {
+    int j = 1;
+    for (; j + 4 <= pool; j += 4) {                               // four window rows in flight
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(xp + (long)(j + u) * C);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        m.x = fmaxf(m.x, v[u].x); m.y = fmaxf(m.y, v[u].y); m.z = fmaxf(m.z, v[u].z); m.w = fmaxf(m.w, v[u].w);
+      }
+    }
+    for (; j < pool; ++j) {
       const float4 v = *reinterpret_cast<const float4*>(xp + (long)j * C);
       m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
     }
@@ -355,20 +365,43 @@ __global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const float* __res
                                                               const float* __restrict__ dy, float* __restrict__ dx,
                                                               long n_out_pix, int Fin, int C, int pool, long lddy,
                                                               int coff) {
-  const int Fout = Fin / pool;
-  const long total = n_out_pix * C;
+  // one thread per (window, channel quad): float4 loads, four window rows in flight, first maximum wins
+  const int Fout = Fin / pool, quads = C >> 2;
+  const long total = n_out_pix * quads;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int c = (int)(i % C);
-    const long op = i / C, row = op / Fout;
-    const int fo = (int)(op % Fout);
-    const long base = (row * Fin + (long)fo * pool) * C + c;
-    float best = x[base];
-    int arg = 0;
-    for (int j = 1; j < pool; ++j) {
-      const float v = x[base + (long)j * C];
-      if (v > best) { best = v; arg = j; }
+    const long op = i / quads;
+    const int c = (int)(i - op * quads) * 4;
+    const long row = op / Fout;
+    const int fo = (int)(op - row * Fout);
+    const float* xp = x + (row * Fin + (long)fo * pool) * C + c;
+    float4 best = *reinterpret_cast<const float4*>(xp);
+    int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    int jn = 1;
+    for (; jn + 4 <= pool; jn += 4) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(xp + (long)(jn + u) * C);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (v[u].x > best.x) { best.x = v[u].x; a0 = jn + u; }
+        if (v[u].y > best.y) { best.y = v[u].y; a1 = jn + u; }
+        if (v[u].z > best.z) { best.z = v[u].z; a2 = jn + u; }
+        if (v[u].w > best.w) { best.w = v[u].w; a3 = jn + u; }
+      }
     }
-    dx[base + (long)arg * C] += dy[op * lddy + coff + c];
+    for (; jn < pool; ++jn) {
+      const float4 v = *reinterpret_cast<const float4*>(xp + (long)jn * C);
+      if (v.x > best.x) { best.x = v.x; a0 = jn; }
+      if (v.y > best.y) { best.y = v.y; a1 = jn; }
+      if (v.z > best.z) { best.z = v.z; a2 = jn; }
+      if (v.w > best.w) { best.w = v.w; a3 = jn; }
+    }
+    const float4 g = *reinterpret_cast<const float4*>(dy + op * lddy + coff + c);
+    float* dp = dx + (row * Fin + (long)fo * pool) * C + c;
+    dp[(long)a0 * C] += g.x;
+    dp[(long)a1 * C + 1] += g.y;
+    dp[(long)a2 * C + 2] += g.z;
+    dp[(long)a3 * C + 3] += g.w;
   }
 }
 
@@ -586,9 +619,10 @@ extern "C" int pe_maxpool_fwd(const float* x, float* y, long rows, int Fin, int 
 extern "C" int pe_maxpool_bwd_add(const float* x, const float* dy, float* dx, long rows, int Fin, int C, int pool,
                                   long lddy, int coff, void* stream) {
   if (!x || !dy || !dx || rows <= 0 || Fin <= 0 || pool <= 0 || C <= 0) return PE_E_ARG;
+  if ((C & 3) || (lddy & 3) || (coff & 3)) return PE_E_UNSUPPORTED;
   const long n_out = rows * (Fin / pool);
-  hipLaunchKernelGGL(maxpool_bwd_add_kernel, dim3(ew_grid(n_out * C)), dim3(256), 0, pe_stream(stream), x, dy, dx,
-                     n_out, Fin, C, pool, lddy, coff);
+  hipLaunchKernelGGL(maxpool_bwd_add_kernel, dim3(ew_grid(n_out * (C / 4))), dim3(256), 0, pe_stream(stream), x, dy,
+                     dx, n_out, Fin, C, pool, lddy, coff);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }
