@@ -434,18 +434,28 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_kernel(const PBwdC
   float4 stage[NLD];
   // staging assignment: 8 threads per row, float4 column (tid & 7) + 8 v of the chunk's 8*CH staged floats;
   // 32-bit offsets (checked by the host), one multiply per chunk
-  auto load_chunk = [&](int rb0_, int tn_, int c) {
-    int t7 = tid & 7;
-    asm volatile("" : "+v"(t7));                      // keep the (cheap) column math in place: hoisting it spills
-    const int brow = rb0_ + (tid >> 3);
-    const unsigned rowbase = (unsigned)(brow * T + tn_) * (unsigned)K;
+  // Staged column 4*(t7 + 8 v) of a chunk advances by 32 floats per v, i.e. by two lane-half segments every
+  // CH / 16 loads: k(v + CH/16) = k(v) + H.  Only the first CH / 16 offsets are computed (once per kernel).
+  constexpr int PER = CH / 16;
+  int kbase[PER];
 #pragma unroll
-    for (int v = 0; v < NLD; ++v) {
-      const int el = (t7 + 8 * v) * 4;
-      const int seg = el / CH, e = el - seg * CH;
-      const int k = (seg >> 1) * H + (seg & 1) * KH + c * CH + e;
-      stage[v] = brow < B ? load_sc1(grs, (rowbase + (unsigned)k) * 4u) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int n = 0; n < PER; ++n) {
+    const int el = ((tid & 7) + 8 * n) * 4;
+    const int seg = el / CH, e = el - seg * CH;
+    kbase[n] = (seg >> 1) * H + (seg & 1) * KH + e;
+  }
+  auto load_chunk = [&](int rb0_, int tn_, int c) {
+    const int brow = rb0_ + (tid >> 3);
+    const unsigned rowbase = ((unsigned)(brow * T + tn_) * (unsigned)K + (unsigned)(c * CH)) * 4u;
+    unsigned kb[PER];
+#pragma unroll
+    for (int n = 0; n < PER; ++n) {
+      kb[n] = rowbase + (unsigned)kbase[n] * 4u;
+      asm volatile("" : "+v"(kb[n]));                 // one add per load below; precomputing all NLD offsets spills
     }
+#pragma unroll
+    for (int v = 0; v < NLD; ++v)
+      stage[v] = brow < B ? load_sc1(grs, kb[v % PER] + (unsigned)((v / PER) * H) * 4u) : make_float4(0.f, 0.f, 0.f, 0.f);
   };
   auto fetch_next = [&](int step, int hf) {          // (step, 0) -> (step, 1) -> (step + 1, 0)
     const int step_n = hf == 0 ? step : step + 1, hf_n = hf ^ 1;
