@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--fp32-matmul", choices=["native", "x3"], default=None,
                     help="fp32 products on v_mfma_f32_32x32x2_f32 (native) or as an exact three-term bf16 split "
                          "on the bf16 MFMA pipe (x3, fp32-accurate); default: PE_FP32_MATMUL or the library default")
+    ap.add_argument("--no-native-ref", action="store_true",
+                    help="skip the 7 extra steps that time the native fp32 MFMA form for the fp32_native_mfma field")
     ap.add_argument("--family-timing", action="store_true",
                     help="HIP events around EVERY C-ABI call (kernel_families_ms_per_step); by default only the "
                          "roofline kernel's launches are bracketed, which keeps ~1400 event records per step out "
@@ -191,6 +193,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the same step with the fp32 products on the native fp32 MFMA instructions, for reference (N = 1 only,
+    # a few steps after the timed region; never part of `value`)
+    native_ref = None
+    if world == 1 and x3 and not bf16 and not args.no_native_ref:
+        ops.FP32_MATMUL = "native"
+        try:
+            for _ in range(2):
+                tr.run(batch)
+            torch.cuda.synchronize(dev)
+            t_n = time.perf_counter()
+            for _ in range(5):
+                tr.run(batch)
+            torch.cuda.synchronize(dev)
+            ms_n = (time.perf_counter() - t_n) / 5 * 1e3
+            native_ref = {"ms_per_step": ms_n, "value": args.batch * FRAMES / (ms_n * 1e-3), "unit": "mel-frames/s",
+                          "steps": 5, "note": "PE_FP32_MATMUL=native: v_mfma_f32_32x32x2_f32 for every fp32 product"}
+        finally:
+            ops.FP32_MATMUL = "x3"
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         frames = args.batch * world * FRAMES * args.steps
@@ -226,6 +247,8 @@ def main():
                        "real_frames_per_utterance": 161, "parallelism": f"dp{world}"},
             "loss": last["loss"], "roofline": roof, "kernel_families_ms_per_step": families,
         }
+        if native_ref is not None:
+            line["fp32_native_mfma"] = native_ref
         if world == 1 and not args.no_cpu_baseline and args.head == "bilstm" and not bf16:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
