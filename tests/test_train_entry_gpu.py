@@ -1,0 +1,43 @@
+"""train.py end to end on the HIP path: the reference's CLI (train.py:45-150) with a YAML of the reference's keys,
+a tiny synthetic dataset on disk (wav + cached F0, the reference's file layout), two epochs, checkpoints."""
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from pitchextractor_amd import synthetic
+from tests.test_data_layer import write_wav
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_train_py_runs_two_epochs_and_checkpoints(tmp_path, hip_device):
+    lines = []
+    for i in range(8):
+        wave, f0, _ = synthetic.utterance(i, duration=2.0)
+        p = tmp_path / f"u{i}.wav"
+        write_wav(p, wave, 24000, "float32")
+        np.save(str(p) + "_f0.npy", f0)
+        lines.append(f"{p}|0\n")
+    (tmp_path / "train_list.txt").write_text("".join(lines[:6]))
+    (tmp_path / "val_list.txt").write_text("".join(lines[6:]))
+    cfg = yaml.safe_load((ROOT / "Configs" / "config.yml").read_text())
+    cfg.update(log_dir=str(tmp_path / "ckpt"), save_freq=1, epochs=2, batch_size=2, num_workers=0,
+               train_data=str(tmp_path / "train_list.txt"), val_data=str(tmp_path / "val_list.txt"))
+    cfg["model_params"]["sequence_model"].update(hidden_size=64, num_layers=2)
+    cfg_path = tmp_path / "config.yml"
+    cfg_path.write_text(yaml.safe_dump(cfg))
+    res = subprocess.run([sys.executable, str(ROOT / "train.py"), "-p", str(cfg_path)], cwd=str(ROOT),
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    log = (tmp_path / "ckpt" / "train.log").read_text()
+    assert "--- epoch 2 ---" in log and "train/loss" in log and "eval/loss" in log
+    ck = torch.load(tmp_path / "ckpt" / "epoch_00002.pth", map_location="cpu", weights_only=True)
+    assert set(ck) == {"optimizer", "scheduler", "steps", "epochs", "model"} and ck["epochs"] == 2
+    assert "sequence_classifier.model.weight_hh_l1_reverse" in ck["model"]
+    assert all(torch.isfinite(v).all() for v in ck["model"].values() if v.dtype.is_floating_point)
