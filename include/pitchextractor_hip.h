@@ -195,6 +195,13 @@ int pe_lstm_fwd_persistent_x3(int ncells, const float* const* whh, float* const*
 int pe_lstm_bwd_persistent_x3(int ncells, const float* const* whh_t, float* const* gates,
                            const float* const* cbuf, const float* const* dy, const int* reverse, long lddy,
                            int B, int T, int H, unsigned* sync, void* stream);
+/* mixed precision: W_hh and the h / dgates rows rounded to bf16, fp32 accumulate and cell state */
+int pe_lstm_fwd_persistent_bf16(int ncells, const float* const* whh, float* const* gates, float* const* y,
+                           float* const* cbuf, const int* reverse, long ldy, int B, int T, int H,
+                           unsigned* sync, void* stream);
+int pe_lstm_bwd_persistent_bf16(int ncells, const float* const* whh_t, float* const* gates,
+                           const float* const* cbuf, const float* const* dy, const int* reverse, long lddy,
+                           int B, int T, int H, unsigned* sync, void* stream);
 size_t pe_lstm_whh_grad_workspace_bytes(int B, int T, int H);
 int pe_lstm_whh_grad(const float* dgates, const float* y, long ldy, float* dwhh, int B, int T, int H,
                      int reverse, float* workspace, size_t workspace_bytes, void* stream);

@@ -76,6 +76,8 @@ PROTOTYPES = {
     "pe_lstm_bwd_persistent": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _p, _p]),
     "pe_lstm_fwd_persistent_x3": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _p, _p]),
     "pe_lstm_bwd_persistent_x3": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _p, _p]),
+    "pe_lstm_fwd_persistent_bf16": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _p, _p]),
+    "pe_lstm_bwd_persistent_bf16": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _p, _p]),
     "pe_lstm_whh_grad_workspace_bytes": (_z, [_i, _i, _i]),
     "pe_lstm_whh_grad": (_i, [_p, _p, _l, _p, _i, _i, _i, _i, _p, _z, _p]),
     "pe_lstm_whh_grad_x3": (_i, [_p, _p, _l, _p, _i, _i, _i, _i, _p, _z, _p]),

@@ -98,6 +98,13 @@ __device__ __forceinline__ void split8(const float4& p, const float4& q, bf16x8 
 }
 // (a term, b term) of the six products.  a_hi x W_lo goes last: W_lo may come from LDS, and its read then
 // completes under the five products that do not need it.
+// mixed precision: 8 consecutive k rounded to bf16 (RNE)
+__device__ __forceinline__ bf16x8 round8(const float4& p, const float4& q) {
+  bf16x8 o;
+  o[0] = (__bf16)p.x; o[1] = (__bf16)p.y; o[2] = (__bf16)p.z; o[3] = (__bf16)p.w;
+  o[4] = (__bf16)q.x; o[5] = (__bf16)q.y; o[6] = (__bf16)q.z; o[7] = (__bf16)q.w;
+  return o;
+}
 constexpr int kTa[6] = {2, 1, 1, 0, 0, 0}, kTb[6] = {0, 1, 0, 1, 0, 2};
 // blocks whose W lo term stays in registers; the rest (at most 32 KB per workgroup) goes to LDS
 template <int H> constexpr int fwd_lo_reg_blocks() { return (H / 64) <= 1 ? (H / 64) : 1; }
@@ -161,9 +168,11 @@ __device__ __forceinline__ void group_of_block(int NJ, int& jt, int& gidx) {
 }
 
 // --------------------------------------------------------------------------------------- forward
-template <int H, bool X3>
+// TERMS: 0 = native fp32 MFMA, 3 = exact three-term split, 1 = operands rounded to bf16 (mixed precision)
+template <int H, int TERMS>
 __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_kernel(const PFwdCells cells, int B, int T, long ldy,
                                                                      unsigned y_bytes, unsigned* sync) {
+  constexpr bool X3 = TERMS != 0;                   // bf16-term pipeline (3 or 1 terms)
   constexpr int KQ = H / 4, KH = KQ / 2, NV = KH / 4, NJ = H / 32;
   constexpr int ASTR = H + 4;                       // LDS row stride of the staged h rows
   constexpr int ROW4 = H / 4;                       // float4 per row
@@ -190,7 +199,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_kernel(const PFwdC
 
   // W_hh slice of this wave / lane: rows {g*H + j0 + r}, k = wv*KQ + hh*KH + s
   constexpr int NB = X3 ? KH / 8 : 1;               // 8-k blocks per lane (X3)
-  constexpr int NBR = X3 ? fwd_lo_reg_blocks<H>() : 1;
+  constexpr int NBR = TERMS == 3 ? fwd_lo_reg_blocks<H>() : NB;   // one term: no lo terms at all
   static_assert(!X3 || KH % 8 == 0, "X3 needs H % 64 == 0");
   float bw[X3 ? 1 : 4][X3 ? 1 : KH];
   bf16x8 bwhm[X3 ? 4 : 1][NB][2], bwlo[X3 ? 4 : 1][NBR];
@@ -201,12 +210,18 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_kernel(const PFwdC
     if constexpr (X3) {
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
-        bf16x8 t3[3];
-        split8(*reinterpret_cast<const float4*>(src + 8 * b), *reinterpret_cast<const float4*>(src + 8 * b + 4), t3);
-        bwhm[g][b][0] = t3[0];
-        bwhm[g][b][1] = t3[1];
-        if (b < NBR) bwlo[g][b < NBR ? b : 0] = t3[2];
-        else wlo_lds[(g * (NB - NBR) + (b - NBR)) * 256 + tid] = __builtin_bit_cast(uint4, t3[2]);
+        const float4 w0 = *reinterpret_cast<const float4*>(src + 8 * b);
+        const float4 w1 = *reinterpret_cast<const float4*>(src + 8 * b + 4);
+        if constexpr (TERMS == 3) {
+          bf16x8 t3[3];
+          split8(w0, w1, t3);
+          bwhm[g][b][0] = t3[0];
+          bwhm[g][b][1] = t3[1];
+          if (b < NBR) bwlo[g][b < NBR ? b : 0] = t3[2];
+          else wlo_lds[(g * (NB - NBR) + (b - NBR)) * 256 + tid] = __builtin_bit_cast(uint4, t3[2]);
+        } else {
+          bwhm[g][b][0] = round8(w0, w1);
+        }
       }
     } else {
 #pragma unroll
@@ -277,19 +292,26 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_kernel(const PFwdC
           const float* asrc = As + r * ASTR + wv * KQ + hh * KH;
 #pragma unroll
           for (int b = 0; b < NB; ++b) {
-            bf16x8 fa[3];                             // 36 VALU per 24 MFMAs: cheap enough not to pipeline
-            split8(*reinterpret_cast<const float4*>(asrc + 8 * b), *reinterpret_cast<const float4*>(asrc + 8 * b + 4),
-                   fa);
-            bf16x8 wl[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-              wl[g] = b < NBR ? bwlo[g][b < NBR ? b : 0]
-                              : __builtin_bit_cast(bf16x8, wlo_lds[(g * (NB - NBR) + (b - NBR)) * 256 + tid]);
-#pragma unroll
-            for (int t6 = 0; t6 < 6; ++t6)
+            const float4 a0 = *reinterpret_cast<const float4*>(asrc + 8 * b);
+            const float4 a1 = *reinterpret_cast<const float4*>(asrc + 8 * b + 4);
+            if constexpr (TERMS == 3) {
+              bf16x8 fa[3];                           // 36 VALU per 24 MFMAs: cheap enough not to pipeline
+              split8(a0, a1, fa);
+              bf16x8 wl[4];
 #pragma unroll
               for (int g = 0; g < 4; ++g)
-                acc[g] = mfma_bf16(kTb[t6] == 2 ? wl[g] : bwhm[g][b][kTb[t6]], fa[kTa[t6]], acc[g]);
+                wl[g] = b < NBR ? bwlo[g][b < NBR ? b : 0]
+                                : __builtin_bit_cast(bf16x8, wlo_lds[(g * (NB - NBR) + (b - NBR)) * 256 + tid]);
+#pragma unroll
+              for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                  acc[g] = mfma_bf16(kTb[t6] == 2 ? wl[g] : bwhm[g][b][kTb[t6]], fa[kTa[t6]], acc[g]);
+            } else {
+              const bf16x8 fa = round8(a0, a1);
+#pragma unroll
+              for (int g = 0; g < 4; ++g) acc[g] = mfma_bf16(bwhm[g][b][0], fa, acc[g]);
+            }
           }
         }
       }
@@ -368,9 +390,10 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_kernel(const PFwdC
 // --------------------------------------------------------------------------------------- backward
 // dh_t = dY_t + dgates_{t+1} . W_hh  (K = 4H: wave w owns gate block w; each lane half takes H/2
 // contiguous k, streamed through LDS in chunks of CH per lane).  W_hh^T rows j0 + r stay in registers.
-template <int H, bool X3>
+template <int H, int TERMS>
 __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_kernel(const PBwdCells cells, int B, int T, long lddy,
                                                                      unsigned g_bytes, unsigned* sync) {
+  constexpr bool X3 = TERMS != 0;                   // bf16-term pipeline (3 or 1 terms)
   constexpr int KH = H / 2, NJ = H / 32, K = 4 * H;
   constexpr int CH = (KH % 48 == 0) ? 48 : 16;      // k per lane per chunk
   constexpr int NCH = KH / CH;
@@ -398,7 +421,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_kernel(const PBwdC
   const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(gates, 0, g_bytes, 0x00020000);
 
   constexpr int NBK = X3 ? KH / 8 : 1;              // 8-k blocks per lane (X3)
-  constexpr int NBR = X3 ? bwd_lo_reg_blocks<H>() : 1;
+  constexpr int NBR = TERMS == 3 ? bwd_lo_reg_blocks<H>() : NBK;
   static_assert(!X3 || (KH % 8 == 0 && CH % 8 == 0), "X3 needs H % 16 == 0");
   float bw[X3 ? 1 : KH];
   bf16x8 bwhm[NBK][2], bwlo[NBR];
@@ -408,12 +431,18 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_kernel(const PBwdC
     if constexpr (X3) {
 #pragma unroll
       for (int b = 0; b < NBK; ++b) {
-        bf16x8 t3[3];
-        split8(*reinterpret_cast<const float4*>(src + 8 * b), *reinterpret_cast<const float4*>(src + 8 * b + 4), t3);
-        bwhm[b][0] = t3[0];
-        bwhm[b][1] = t3[1];
-        if (b < NBR) bwlo[b < NBR ? b : 0] = t3[2];
-        else wlo_lds[(b - NBR) * 256 + tid] = __builtin_bit_cast(uint4, t3[2]);
+        const float4 w0 = *reinterpret_cast<const float4*>(src + 8 * b);
+        const float4 w1 = *reinterpret_cast<const float4*>(src + 8 * b + 4);
+        if constexpr (TERMS == 3) {
+          bf16x8 t3[3];
+          split8(w0, w1, t3);
+          bwhm[b][0] = t3[0];
+          bwhm[b][1] = t3[1];
+          if (b < NBR) bwlo[b < NBR ? b : 0] = t3[2];
+          else wlo_lds[(b - NBR) * 256 + tid] = __builtin_bit_cast(uint4, t3[2]);
+        } else {
+          bwhm[b][0] = round8(w0, w1);
+        }
       }
     } else {
 #pragma unroll
@@ -506,24 +535,35 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_kernel(const PBwdC
           const float* asrc = cur + r * ASTR + (wv * 2 + hh) * CH;
           if constexpr (X3) {
             // two accumulators (even / odd blocks); the next block's operand is split under this block's MFMAs
-            bf16x8 fa[3];
-            split8(*reinterpret_cast<const float4*>(asrc), *reinterpret_cast<const float4*>(asrc + 4), fa);
+            if constexpr (TERMS == 3) {
+              bf16x8 fa[3];
+              split8(*reinterpret_cast<const float4*>(asrc), *reinterpret_cast<const float4*>(asrc + 4), fa);
 #pragma unroll
-            for (int b = 0; b < CH / 8; ++b) {
-              const int gb = c * (CH / 8) + b;                          // block index within this lane's k range
-              bf16x8 fn[3];
-              if (b + 1 < CH / 8)
-                split8(*reinterpret_cast<const float4*>(asrc + 8 * (b + 1)),
-                       *reinterpret_cast<const float4*>(asrc + 8 * (b + 1) + 4), fn);
-              const bf16x8 wl = gb < NBR ? bwlo[gb < NBR ? gb : 0]
-                                         : __builtin_bit_cast(bf16x8, wlo_lds[(gb - NBR) * 256 + tid]);
+              for (int b = 0; b < CH / 8; ++b) {
+                const int gb = c * (CH / 8) + b;                        // block index within this lane's k range
+                bf16x8 fn[3];
+                if (b + 1 < CH / 8)
+                  split8(*reinterpret_cast<const float4*>(asrc + 8 * (b + 1)),
+                         *reinterpret_cast<const float4*>(asrc + 8 * (b + 1) + 4), fn);
+                const bf16x8 wl = gb < NBR ? bwlo[gb < NBR ? gb : 0]
+                                           : __builtin_bit_cast(bf16x8, wlo_lds[(gb - NBR) * 256 + tid]);
 #pragma unroll
-              for (int t6 = 0; t6 < 6; ++t6) {
-                const bf16x8 wt = kTb[t6] == 2 ? wl : bwhm[gb][kTb[t6]];
-                if (b & 1) acc2 = mfma_bf16(fa[kTa[t6]], wt, acc2);
-                else acc = mfma_bf16(fa[kTa[t6]], wt, acc);
+                for (int t6 = 0; t6 < 6; ++t6) {
+                  const bf16x8 wt = kTb[t6] == 2 ? wl : bwhm[gb][kTb[t6]];
+                  if (b & 1) acc2 = mfma_bf16(fa[kTa[t6]], wt, acc2);
+                  else acc = mfma_bf16(fa[kTa[t6]], wt, acc);
+                }
+                if (b + 1 < CH / 8) { fa[0] = fn[0]; fa[1] = fn[1]; fa[2] = fn[2]; }
               }
-              if (b + 1 < CH / 8) { fa[0] = fn[0]; fa[1] = fn[1]; fa[2] = fn[2]; }
+            } else {
+#pragma unroll
+              for (int b = 0; b < CH / 8; ++b) {
+                const int gb = c * (CH / 8) + b;
+                const bf16x8 fa = round8(*reinterpret_cast<const float4*>(asrc + 8 * b),
+                                         *reinterpret_cast<const float4*>(asrc + 8 * b + 4));
+                if (b & 1) acc2 = mfma_bf16(fa, bwhm[gb][0], acc2);
+                else acc = mfma_bf16(fa, bwhm[gb][0], acc);
+              }
             }
           } else {
 #pragma unroll
@@ -598,22 +638,24 @@ int device_cus() {
   return cus;
 }
 
-template <int H, bool X3>
+template <int H, int TERMS>
 constexpr size_t fwd_lds() {
-  constexpr int NB = H / 64, NBR = X3 ? fwd_lo_reg_blocks<H>() : NB;
+  constexpr bool X3 = TERMS != 0;
+  constexpr int NB = H / 64, NBR = TERMS == 3 ? fwd_lo_reg_blocks<H>() : NB;
   constexpr size_t as = 32 * (H + 4), rd = 4 * 32 * kRs;
   return X3 ? (as > rd ? as : rd) * sizeof(float) + (size_t)4 * (NB - NBR) * 256 * 16 : (as + rd) * sizeof(float);
 }
 
-template <int H, bool X3>
+template <int H, int TERMS>
 constexpr size_t bwd_lds() {
+  constexpr bool X3 = TERMS == 3;
   constexpr int KH = H / 2;
   constexpr int CH = (KH % 48 == 0) ? 48 : 16;
-  constexpr int NBK = KH / 8, NBR = X3 ? bwd_lo_reg_blocks<H>() : NBK;
+  constexpr int NBK = KH / 8, NBR = TERMS == 3 ? bwd_lo_reg_blocks<H>() : NBK;
   return (size_t)(2 * 32 * (8 * CH + 4) + 4 * 32 * kRb) * sizeof(float) + (X3 ? (size_t)(NBK - NBR) * 256 * 16 : 0);
 }
 
-template <int H, bool X3>
+template <int H, int X3>
 int launch_fwd(const PFwdCells& cells, int grid, int B, int T, long ldy, unsigned* sync, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
@@ -628,7 +670,7 @@ int launch_fwd(const PFwdCells& cells, int grid, int B, int T, long ldy, unsigne
   return PE_OK;
 }
 
-template <int H, bool X3>
+template <int H, int X3>
 int launch_bwd(const PBwdCells& cells, int grid, int B, int T, long lddy, unsigned* sync, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
@@ -660,7 +702,7 @@ extern "C" int pe_lstm_persistent_supported(int ncells, int B, int H) {
   return grid <= device_cus() ? 1 : 0;
 }
 
-static int lstm_fwd_persistent_impl(bool x3, int ncells, const float* const* whh, float* const* gates,
+static int lstm_fwd_persistent_impl(int terms, int ncells, const float* const* whh, float* const* gates,
                                     float* const* y, float* const* cbuf, const int* reverse, long ldy, int B, int T,
                                     int H, unsigned* sync, void* stream) {
   if (!whh || !gates || !y || !cbuf || !reverse || !sync || T <= 0) return PE_E_ARG;
@@ -677,12 +719,14 @@ static int lstm_fwd_persistent_impl(bool x3, int ncells, const float* const* whh
   PE_CHECK_HIP(hipMemsetAsync(sync + kCtrStride, 0, pe_lstm_persistent_sync_bytes(ncells, B) - kCtrStride * 4, st));
   const int grid = ncells * ((B + 63) / 64) * (H / 32);
   switch (H) {                                   // the split form needs H % 64 == 0; other sizes stay native
-    case 32: return launch_fwd<32, false>(cells, grid, B, T, ldy, sync, st);
-    case 64: return x3 ? launch_fwd<64, true>(cells, grid, B, T, ldy, sync, st)
-                       : launch_fwd<64, false>(cells, grid, B, T, ldy, sync, st);
-    case 96: return launch_fwd<96, false>(cells, grid, B, T, ldy, sync, st);
-    case 384: return x3 ? launch_fwd<384, true>(cells, grid, B, T, ldy, sync, st)
-                        : launch_fwd<384, false>(cells, grid, B, T, ldy, sync, st);
+    case 32: return launch_fwd<32, 0>(cells, grid, B, T, ldy, sync, st);
+    case 64: return terms == 3 ? launch_fwd<64, 3>(cells, grid, B, T, ldy, sync, st)
+                  : terms == 1 ? launch_fwd<64, 1>(cells, grid, B, T, ldy, sync, st)
+                               : launch_fwd<64, 0>(cells, grid, B, T, ldy, sync, st);
+    case 96: return launch_fwd<96, 0>(cells, grid, B, T, ldy, sync, st);
+    case 384: return terms == 3 ? launch_fwd<384, 3>(cells, grid, B, T, ldy, sync, st)
+                   : terms == 1 ? launch_fwd<384, 1>(cells, grid, B, T, ldy, sync, st)
+                                : launch_fwd<384, 0>(cells, grid, B, T, ldy, sync, st);
   }
   return PE_E_UNSUPPORTED;
 }
@@ -690,16 +734,16 @@ static int lstm_fwd_persistent_impl(bool x3, int ncells, const float* const* whh
 extern "C" int pe_lstm_fwd_persistent(int ncells, const float* const* whh, float* const* gates, float* const* y,
                                       float* const* cbuf, const int* reverse, long ldy, int B, int T, int H,
                                       unsigned* sync, void* stream) {
-  return lstm_fwd_persistent_impl(false, ncells, whh, gates, y, cbuf, reverse, ldy, B, T, H, sync, stream);
+  return lstm_fwd_persistent_impl(0, ncells, whh, gates, y, cbuf, reverse, ldy, B, T, H, sync, stream);
 }
 
 extern "C" int pe_lstm_fwd_persistent_x3(int ncells, const float* const* whh, float* const* gates, float* const* y,
                                          float* const* cbuf, const int* reverse, long ldy, int B, int T, int H,
                                          unsigned* sync, void* stream) {
-  return lstm_fwd_persistent_impl(true, ncells, whh, gates, y, cbuf, reverse, ldy, B, T, H, sync, stream);
+  return lstm_fwd_persistent_impl(3, ncells, whh, gates, y, cbuf, reverse, ldy, B, T, H, sync, stream);
 }
 
-static int lstm_bwd_persistent_impl(bool x3, int ncells, const float* const* whh_t, float* const* gates,
+static int lstm_bwd_persistent_impl(int terms, int ncells, const float* const* whh_t, float* const* gates,
                                     const float* const* cbuf, const float* const* dy, const int* reverse, long lddy,
                                     int B, int T, int H, unsigned* sync, void* stream) {
   if (!whh_t || !gates || !cbuf || !dy || !reverse || !sync || T <= 0) return PE_E_ARG;
@@ -715,12 +759,14 @@ static int lstm_bwd_persistent_impl(bool x3, int ncells, const float* const* whh
   PE_CHECK_HIP(hipMemsetAsync(sync + kCtrStride, 0, pe_lstm_persistent_sync_bytes(ncells, B) - kCtrStride * 4, st));
   const int grid = ncells * ((B + 63) / 64) * (H / 32);
   switch (H) {
-    case 32: return launch_bwd<32, false>(cells, grid, B, T, lddy, sync, st);
-    case 64: return x3 ? launch_bwd<64, true>(cells, grid, B, T, lddy, sync, st)
-                       : launch_bwd<64, false>(cells, grid, B, T, lddy, sync, st);
-    case 96: return launch_bwd<96, false>(cells, grid, B, T, lddy, sync, st);
-    case 384: return x3 ? launch_bwd<384, true>(cells, grid, B, T, lddy, sync, st)
-                        : launch_bwd<384, false>(cells, grid, B, T, lddy, sync, st);
+    case 32: return launch_bwd<32, 0>(cells, grid, B, T, lddy, sync, st);
+    case 64: return terms == 3 ? launch_bwd<64, 3>(cells, grid, B, T, lddy, sync, st)
+                  : terms == 1 ? launch_bwd<64, 1>(cells, grid, B, T, lddy, sync, st)
+                               : launch_bwd<64, 0>(cells, grid, B, T, lddy, sync, st);
+    case 96: return launch_bwd<96, 0>(cells, grid, B, T, lddy, sync, st);
+    case 384: return terms == 3 ? launch_bwd<384, 3>(cells, grid, B, T, lddy, sync, st)
+                   : terms == 1 ? launch_bwd<384, 1>(cells, grid, B, T, lddy, sync, st)
+                                : launch_bwd<384, 0>(cells, grid, B, T, lddy, sync, st);
   }
   return PE_E_UNSUPPORTED;
 }
@@ -728,11 +774,23 @@ static int lstm_bwd_persistent_impl(bool x3, int ncells, const float* const* whh
 extern "C" int pe_lstm_bwd_persistent(int ncells, const float* const* whh_t, float* const* gates,
                                       const float* const* cbuf, const float* const* dy, const int* reverse,
                                       long lddy, int B, int T, int H, unsigned* sync, void* stream) {
-  return lstm_bwd_persistent_impl(false, ncells, whh_t, gates, cbuf, dy, reverse, lddy, B, T, H, sync, stream);
+  return lstm_bwd_persistent_impl(0, ncells, whh_t, gates, cbuf, dy, reverse, lddy, B, T, H, sync, stream);
 }
 
 extern "C" int pe_lstm_bwd_persistent_x3(int ncells, const float* const* whh_t, float* const* gates,
                                          const float* const* cbuf, const float* const* dy, const int* reverse,
                                          long lddy, int B, int T, int H, unsigned* sync, void* stream) {
-  return lstm_bwd_persistent_impl(true, ncells, whh_t, gates, cbuf, dy, reverse, lddy, B, T, H, sync, stream);
+  return lstm_bwd_persistent_impl(3, ncells, whh_t, gates, cbuf, dy, reverse, lddy, B, T, H, sync, stream);
+}
+
+extern "C" int pe_lstm_fwd_persistent_bf16(int ncells, const float* const* whh, float* const* gates, float* const* y,
+                                           float* const* cbuf, const int* reverse, long ldy, int B, int T, int H,
+                                           unsigned* sync, void* stream) {
+  return lstm_fwd_persistent_impl(1, ncells, whh, gates, y, cbuf, reverse, ldy, B, T, H, sync, stream);
+}
+
+extern "C" int pe_lstm_bwd_persistent_bf16(int ncells, const float* const* whh_t, float* const* gates,
+                                           const float* const* cbuf, const float* const* dy, const int* reverse,
+                                           long lddy, int B, int T, int H, unsigned* sync, void* stream) {
+  return lstm_bwd_persistent_impl(1, ncells, whh_t, gates, cbuf, dy, reverse, lddy, B, T, H, sync, stream);
 }

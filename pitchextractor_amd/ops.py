@@ -96,7 +96,8 @@ def _s():
 
 # Opt-in mixed precision (reference trainer.py:103 autocast; config training.mixed_precision): when True the
 # conv / linear products and their weight gradients round their operands to bf16 on the way into LDS and
-# accumulate in fp32 (the LSTM recurrence, attention and everything in HBM stay fp32); False is the parity mode.
+# accumulate in fp32; the persistent LSTM recurrences round W_hh and h to bf16 as well (cell state fp32);
+# attention and everything in HBM stay fp32.  False is the parity mode.
 MATMUL_BF16 = False
 # How fp32 products run (always, for the weight-gradient products; when MATMUL_BF16 is off for the rest):
 #   "x3"     every fp32 operand is split exactly into three bf16 terms and six cross products are
@@ -120,6 +121,8 @@ LSTM_X3 = {"fwd": os.environ.get("PE_LSTM_X3_FWD", "1") == "1", "bwd": os.enviro
 
 
 def _lstm_suffix(which):
+    if MATMUL_BF16:
+        return "_bf16"                 # mixed precision: bf16 recurrent products (as autocast runs nn.LSTM)
     return "_x3" if (FP32_MATMUL == "x3" and LSTM_X3[which]) else ""
 
 

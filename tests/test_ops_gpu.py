@@ -335,6 +335,34 @@ def test_lstm_layer_bidirectional(hip_device, B, T, In, H, persistent, monkeypat
     assert not ops.persistent_lstm_error(dev)
 
 
+@pytest.mark.parametrize("B,T,H", [(130, 9, 384), (5, 7, 64)])
+def test_lstm_recurrence_mixed_precision(hip_device, B, T, H):
+    """training.mixed_precision also rounds W_hh and the h / dgates rows of the persistent recurrences to bf16
+    (fp32 accumulate and cell state): forward output and the recurrent data gradient stay within bf16-level
+    error of the fp64 layer."""
+    In = 64
+    torch.manual_seed(0)
+    ref = torch.nn.LSTM(In, H, num_layers=1, batch_first=True, bidirectional=False).double()
+    x = rnd(B, T, In, seed=1).double().requires_grad_(True)
+    y, _ = ref(x)
+    dy = rnd(B, T, H, seed=2).double()
+    y.backward(dy)
+    dev = hip_device
+    P = {n: p.detach().float().to(dev) for n, p in ref.named_parameters()}
+    g = ops.gemm_nt(x.detach().float().to(dev).view(-1, In), P["weight_ih_l0"], bias0=P["bias_ih_l0"],
+                    bias1=P["bias_hh_l0"]).view(B, T, 4 * H)
+    yd, cb = torch.empty(B, T, H, device=dev), torch.empty(B, T, H, device=dev)
+    with ops.matmul_bf16(True):
+        ops.lstm_fwd([P["weight_hh_l0"]], [g], [yd], [cb], [0], B, T, H)
+        close(yd, y, 2e-2)
+        assert (yd.cpu().double() - y.detach()).abs().max() > 1e-6          # the bf16 path really ran
+        dcar = [torch.empty(B, H, device=dev)]
+        ops.lstm_bwd([ops.transpose2d(P["weight_hh_l0"])], [g], [cb], [dy.float().to(dev)], dcar, [0], B, T, H)
+    dx = ops.gemm_nt(g.view(-1, 4 * H), ops.transpose2d(P["weight_ih_l0"]))
+    close(dx.view(B, T, In), x.grad, 3e-2)
+    assert not ops.persistent_lstm_error(dev)
+
+
 # ------------------------------------------------------------------ heads / loss / AdamW
 def test_heads(hip_device):
     R, D = 777, 768
