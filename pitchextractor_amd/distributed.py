@@ -44,6 +44,59 @@ def shard_range(n_items: int, rank: int, world: int):
     return rank * per, (rank + 1) * per
 
 
+class EpochShardSampler(torch.utils.data.Sampler):
+    """``DistributedSampler``-equivalent index source: every epoch ONE seeded permutation of the
+    whole list (identical on all ranks: ``seed + epoch``), truncated to a multiple of ``world * batch`` and cut
+    into ``world`` equal CONTIGUOUS shards -- so every rank runs exactly the same number of optimizer steps
+    (a rank with one batch more would wait forever in its last all-reduce) and the union of the shards is a
+    different subset-free reshuffle each epoch.  ``shuffle=False`` (validation) keeps the list order.
+    ``len(sampler) // batch`` is the per-rank steps per epoch that OneCycleLR must be built with (0 when the
+    list cannot fill one batch on every rank: the caller must refuse to train)."""
+
+    def __init__(self, n_items: int, batch: int, rank: int, world: int, seed: int = 0, shuffle: bool = True,
+                 drop_last: bool = True):
+        if not (0 <= rank < world) or batch < 1:
+            raise ValueError("EpochShardSampler: need 0 <= rank < world and batch >= 1")
+        self.n_items, self.batch, self.rank, self.world = int(n_items), int(batch), int(rank), int(world)
+        self.seed, self.shuffle, self.epoch = int(seed), bool(shuffle), 0
+        if drop_last:                    # training: equal shards of whole batches
+            self.per_rank = (self.n_items // (self.world * self.batch)) * self.batch
+            self.lo = self.rank * self.per_rank
+        else:                            # validation (no collective inside the epoch): cover every item once
+            base, extra = divmod(self.n_items, self.world)
+            self.per_rank = base + (1 if self.rank < extra else 0)
+            self.lo = self.rank * base + min(self.rank, extra)
+
+    def set_epoch(self, epoch: int):
+        self.epoch = int(epoch)
+
+    def indices(self):
+        if self.shuffle:
+            g = torch.Generator()
+            g.manual_seed(self.seed + self.epoch)
+            order = torch.randperm(self.n_items, generator=g).tolist()
+        else:
+            order = list(range(self.n_items))
+        return order[self.lo:self.lo + self.per_rank]
+
+    def __iter__(self):
+        return iter(self.indices())
+
+    def __len__(self):
+        return self.per_rank
+
+
+def mean_over_ranks(values: dict, weight: float, device=None, group=None) -> dict:
+    """Weighted mean of per-rank scalar dicts (same keys everywhere); logging only."""
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return dict(values)
+    keys = sorted(values)
+    t = torch.tensor([float(values[k]) * weight for k in keys] + [float(weight)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    tot = float(t[-1].item())
+    return {k: (float(t[i].item()) / tot if tot > 0 else float("nan")) for i, k in enumerate(keys)}
+
+
 class GradientAllReduce:
     """Sum-all-reduce of a flat gradient buffer, in buckets, on a side stream.
 
@@ -87,6 +140,14 @@ class GradientAllReduce:
                                                          async_op=True))
             else:
                 self._pending.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def any_rank(self, flag: bool) -> bool:
+        """Logical OR of a per-rank status over the group (fault flags must be acted on by every rank)."""
+        if self.world == 1:
+            return bool(flag)
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=self.flat_grad.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return bool(int(t.item()))
 
     def finish(self):
         """Reduce whatever has not been issued yet and make the compute stream wait for all of it."""

@@ -15,6 +15,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
+from . import ops
 from .mel import DEFAULT_MEL_PARAMS, LOG_EPS, MEL_MEAN, MEL_STD, MelSpectrogram
 from .model import JDCNet
 
@@ -85,6 +86,10 @@ def predict_f0(model: JDCNet, audio, chunk_size: int = 192, overlap: int = 48,
     was_training = model.training
     model.eval()
     f0, _ = model(batch.transpose(-1, -2))
+    if ops.persistent_lstm_error(device):          # a timed-out group barrier voids the outputs: redo on the safe kernels
+        ops.clear_persistent_lstm_error(device)
+        ops.USE_PERSISTENT_LSTM = False
+        f0, _ = model(batch.transpose(-1, -2))
     if was_training:
         model.train()
     f0 = f0[..., 0].cpu().numpy() if f0.shape[-1] == 1 else f0.cpu().numpy()

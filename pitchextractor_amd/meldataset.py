@@ -14,19 +14,25 @@ alignment (f0_backends.py:788-806), crop offsets -- is reproduced exactly and ru
 
 Out of scope here: the F0 tracker backends and the WORLD / pitch-shift
 augmentation need packages that are not installable offline.  F0 labels therefore come from the
-reference's cache files (``<wav>_f0*.npy``; the legacy ``<wav>_f0.npy`` too) or from an
-``f0_provider`` callable; an item with neither fails loudly, as the reference does when no
-backend is usable (meldataset.py:80-88).  Files at another sample rate are resampled on the GPU
+reference's cache files under the reference's own contract (meldataset.py:519-604):
+``<wav>_f0<cache_identifier>.npy`` validated by its sibling ``.json`` (cache_identifier, sample_rate,
+hop_length), then the legacy ``<wav>_f0.npy``; or from an ``f0_provider`` callable.  A cache whose
+metadata does not match is skipped with a warning and left on disk (the reference deletes and
+recomputes it; this build cannot recompute).  An item with no usable label source fails loudly, as the
+reference does when no backend is usable (meldataset.py:80-88).  ``<wav>_mel.npy`` caches
+(meldataset.py:679-788) are neither read nor written: the mel is recomputed on the device, one launch
+per batch.  Files at another sample rate are resampled on the GPU
 (meldataset.py:621-627 -> ``pitchextractor_amd.resample.Resampler``) right before the mel launch; one
 batch must come from one source rate.
 """
 from __future__ import annotations
 
-import glob
+import json
 import logging
 import math
 import os
 import random
+import re
 import struct
 
 import numpy as np
@@ -157,6 +163,73 @@ def wav_info(path):
                 fh.seek(size + (size & 1), 1)
 
 
+# --------------------------------------------------------------------------- F0 cache naming
+_BACKEND_TYPES = ("pyworld", "crepe", "swiftf0", "praat", "parselmouth")            # f0_backends.py:587-593
+_DEFAULT_BACKENDS = [{"name": "pyworld_harvest", "type": "pyworld"}, {"name": "pyworld_dio", "type": "pyworld"}]
+
+
+def _norm_backend(name) -> str:
+    return re.sub(r"[^a-z0-9]+", "_", str(name).lower()).strip("_")               # f0_backends.py:596-597
+
+
+def _enabled(value) -> bool:
+    if isinstance(value, str):                                                      # f0_backends.py:619-631
+        v = value.strip().lower()
+        if not v or v in {"0", "false", "no", "off"}:
+            return False
+        if v in {"1", "true", "yes", "on"}:
+            return True
+    return bool(value)
+
+
+def f0_cache_identifier(f0_params: dict | None) -> str:
+    """The reference's ``F0Extractor.cache_identifier`` (f0_backends.py:661-757) for an ``f0_params``
+    block: "-" + the cache keys of the enabled backends in chain order, joined by "_" (the shipped
+    config.yml -> "-swiftf0").  The reference drops backends whose package is missing on the machine that
+    computed the cache; set ``f0_params['cache_identifier']`` to name such a cache explicitly."""
+    cfg = f0_params or {}
+    if cfg.get("cache_identifier") is not None:
+        return str(cfg["cache_identifier"])
+    backends = cfg.get("backends") or {}
+    if cfg.get("backend_order"):
+        sequence = list(cfg["backend_order"])
+    elif backends:
+        sequence = list(backends.keys())
+    else:
+        sequence = [e["name"] for e in _DEFAULT_BACKENDS]
+    defaults = {e["name"]: e for e in _DEFAULT_BACKENDS}
+    keys = []
+    for raw in sequence:
+        if isinstance(raw, dict):
+            entry = dict(raw)
+        else:
+            name = str(raw)
+            bcfg, bkey = None, name
+            if backends:
+                if name in backends:
+                    bcfg = backends[name]
+                else:
+                    for k, v in backends.items():
+                        if _norm_backend(k) == _norm_backend(name):
+                            bcfg, bkey = v, k
+                            break
+                if bcfg is None:
+                    continue                                   # declared order names an unconfigured backend
+            entry = {**defaults.get(bkey, defaults.get(name, {"name": name, "type": name})), **(bcfg or {})}
+            entry.setdefault("name", bkey or name)
+            entry.setdefault("type", entry.get("backend", entry.get("type", name)))
+        if not _enabled(entry.get("enabled", True)):
+            continue
+        if str(entry.get("type") or entry.get("backend") or "pyworld").lower() not in _BACKEND_TYPES:
+            continue
+        name = _norm_backend(entry.get("name") or entry.get("type") or "backend")
+        bconf = entry.get("config") or {k: v for k, v in entry.items()
+                                        if k not in {"name", "type", "backend", "enabled"}}
+        suffix = bconf.get("cache_key_suffix") if isinstance(bconf, dict) else None
+        keys.append(_norm_backend(f"{name}-{suffix}" if suffix else name))
+    return ("-" + "_".join(keys)) if keys else ""
+
+
 # --------------------------------------------------------------------------- dataset
 class MelDataset(torch.utils.data.Dataset):
     def __init__(self, data_list, sr=DEFAULT_MEL_PARAMS["sample_rate"], mel_params=None, f0_params=None,
@@ -178,7 +251,9 @@ class MelDataset(torch.utils.data.Dataset):
 
         self.f0_params = f0_params or {}
         self.f0_provider = f0_provider
-        self.f0_cache_glob = "_f0*.npy"
+        self.f0_cache_identifier = f0_cache_identifier(self.f0_params)
+        self.f0_cache_suffix = f"_f0{self.f0_cache_identifier}.npy"               # meldataset.py:91-92
+        self.f0_meta_suffix = self.f0_cache_suffix.replace(".npy", ".json")
         self.mean, self.std = MEL_MEAN, MEL_STD
         self.data_augmentation = data_augmentation and (not validation)
         self.max_mel_length = MAX_MEL_LENGTH
@@ -196,13 +271,37 @@ class MelDataset(torch.utils.data.Dataset):
         return len(self.data_list)
 
     # ---- labels ---------------------------------------------------------------------------
+    def _f0_cache_paths(self, path):
+        return path + self.f0_cache_suffix, path + self.f0_meta_suffix, path + "_f0.npy"
+
     def _load_cached_f0(self, path):
-        cands = sorted(glob.glob(glob.escape(path) + self.f0_cache_glob))
-        for c in cands:
+        """meldataset.py:566-604: the identifier-named cache if its .json agrees on (cache_identifier,
+        sample_rate, hop_length); else the legacy ``_f0.npy``; else None.  Nothing is deleted."""
+        data_path, meta_path, legacy_path = self._f0_cache_paths(path)
+        if os.path.isfile(data_path) and data_path != legacy_path:
+            metadata = None
+            if os.path.isfile(meta_path):
+                try:
+                    with open(meta_path, "r", encoding="utf-8") as fh:
+                        metadata = json.load(fh)
+                except (OSError, json.JSONDecodeError):
+                    metadata = None
+            expected = {"cache_identifier": self.f0_cache_identifier, "sample_rate": int(self.sr),
+                        "hop_length": int(self.mel_params["hop_length"])}
+            if metadata and all(metadata.get(k) == v for k, v in expected.items()):
+                try:
+                    return np.load(data_path).astype(np.float32)
+                except (OSError, ValueError):
+                    logger.warning("[MelDataset] unreadable F0 cache %s: skipped", data_path)
+            else:
+                logger.warning("[MelDataset] F0 cache %s %s: skipped (the reference would recompute it)", data_path,
+                               "has no readable metadata" if not metadata else
+                               f"was computed for {({k: metadata.get(k) for k in expected})}, expected {expected}")
+        if os.path.isfile(legacy_path):
             try:
-                return np.load(c).astype(np.float32)
+                return np.load(legacy_path).astype(np.float32)
             except (OSError, ValueError):
-                continue
+                logger.warning("[MelDataset] unreadable legacy F0 cache %s: skipped", legacy_path)
         return None
 
     def _f0_for(self, path, waveform, start_sample, expected_frames):
@@ -217,8 +316,9 @@ class MelDataset(torch.utils.data.Dataset):
             return cached[lo:min(cached.shape[0], lo + int(expected_frames) + 4)]
         if self.f0_provider is not None:
             return np.asarray(self.f0_provider(path, waveform, self.sr), dtype=np.float32)
-        raise RuntimeError(f"no F0 labels for {path}: neither a '<wav>_f0*.npy' cache nor an f0_provider "
-                           "(the reference's tracker backends are outside this build)")
+        raise RuntimeError(f"no F0 labels for {path}: no valid '{os.path.basename(path)}{self.f0_cache_suffix}' "
+                           "(+ .json) cache, no legacy '_f0.npy' and no f0_provider (the reference's tracker "
+                           "backends are outside this build)")
 
     # ---- one item -------------------------------------------------------------------------
     def _metadata(self, path):
@@ -347,6 +447,12 @@ class DeviceMelLoader:
     def __len__(self):
         return len(self.loader)
 
+    def set_epoch(self, epoch: int):
+        """Data-parallel runs: re-seed the cross-rank permutation (distributed.EpochShardSampler)."""
+        sampler = getattr(self.loader, "sampler", None)
+        if hasattr(sampler, "set_epoch"):
+            sampler.set_epoch(epoch)
+
     def __iter__(self):
         for waves, lengths, crops, f0s, sils, src_sr in self.loader:
             waves = waves.to(self.device, non_blocking=True)
@@ -361,7 +467,10 @@ class DeviceMelLoader:
 
 
 def build_dataloader(path_list, validation=False, batch_size=4, num_workers=1, device="cpu", collate_config=None,
-                     dataset_config=None):
+                     dataset_config=None, shard=None):
+    """Reference signature (meldataset.py:829-875) plus ``shard=(rank, world, seed)`` for data-parallel runs:
+    the loader then draws its indices from ``distributed.EpochShardSampler`` (equal contiguous per-rank shards
+    of a per-epoch permutation) instead of the single-process shuffle."""
     dataset_config = dict(dataset_config or {})
     dataloader_options = dataset_config.pop("dataloader", {}) or {}
     if torch.device(device).type != "cuda":
@@ -371,6 +480,12 @@ def build_dataloader(path_list, validation=False, batch_size=4, num_workers=1, d
     collate_fn = Collater(**(collate_config or {}))
     kwargs = dict(batch_size=batch_size, shuffle=(not validation), num_workers=num_workers,
                   drop_last=(not validation), collate_fn=collate_fn, pin_memory=True)
+    if shard is not None:
+        from .distributed import EpochShardSampler
+        rank, world, seed = shard
+        kwargs["sampler"] = EpochShardSampler(len(dataset), batch_size, rank, world, seed=seed,
+                                              shuffle=(not validation), drop_last=(not validation))
+        kwargs["shuffle"] = False
     start_method = dataloader_options.get("start_method")
     if start_method and num_workers > 0:
         kwargs["multiprocessing_context"] = torch.multiprocessing.get_context(start_method)

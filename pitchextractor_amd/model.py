@@ -6,9 +6,12 @@ checkpoints move both ways.  What differs is everything underneath:
 
 * all parameters live in ONE flat fp32 buffer (fused AdamW, one gradient buffer for the
   data-parallel all-reduce); the ``nn.Parameter`` objects are views into it;
-* activations are channels-last ``[B, T, F, C]``; the 3x3 convolutions are implicit GEMMs on
-  fp32 MFMA, BatchNorm statistics / LeakyReLU / max-pool / dropout are fused HBM passes, the
-  BiLSTM recurrence runs one launch per time step for all 4 (direction x branch) cells;
+* activations are channels-last ``[B, T, F, C]``; the 3x3 convolutions are halo-staged implicit GEMMs
+  whose fp32 products run as an exact three-term bf16 split on the bf16 MFMA pipe (``ops.FP32_MATMUL``:
+  "x3", default) or on ``v_mfma_f32_32x32x2_f32`` ("native"); BatchNorm statistics / LeakyReLU /
+  max-pool / dropout are fused HBM passes; the BiLSTM recurrence is ONE persistent launch per layer for
+  all 4 (direction x branch) cells with W_hh resident on chip (one launch per time step only as the
+  fallback for shapes / devices the persistent kernels do not cover);
 * the whole network is a single ``autograd.Function`` with a hand-written backward that
   writes parameter gradients straight into the flat gradient buffer.
 
@@ -425,17 +428,44 @@ def _tf_backward(sm, saved, dy, g):
 class _JDCFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, x, _anchor, need_grad):
+        ctx.net, ctx.recompute = net, None
+        if need_grad and net.checkpoint_forward:
+            # Whole-model gradient checkpointing, the reference's granularity (trainer.py:226-233 wraps the
+            # entire model in ONE checkpoint segment): this pass keeps nothing but the input and the dropout
+            # stream position; backward re-runs the forward with bookkeeping, then differentiates it.
+            drop = net.dropout_cfg
+            if drop.inject is not None:
+                raise NotImplementedError("gradient checkpointing cannot replay injected dropout masks")
+            ctx.recompute = (x, drop.seed, drop.offset, net.training)
+            out_cls, out_det, _ = net._forward_impl(x, False)
+            ctx.saved = None
+            return out_cls, out_det
         out_cls, out_det, saved = net._forward_impl(x, need_grad)
-        ctx.net, ctx.saved = net, saved
+        ctx.saved = saved
         if net.keep_last_context:
             net.last_context = saved
         return out_cls, out_det
 
     @staticmethod
     def backward(ctx, d_cls, d_det):
+        net = ctx.net
+        if ctx.recompute is not None:
+            x, seed, offset, training = ctx.recompute
+            drop = net.dropout_cfg
+            now = (drop.seed, drop.offset, net.training)
+            drop.seed, drop.offset = seed, offset           # same Philox stream => same masks as the first pass
+            net.train(training)
+            try:
+                # like torch.utils.checkpoint under the reference, the second forward runs in train mode again:
+                # BatchNorm running statistics take a second momentum update with the same batch statistics
+                _, _, ctx.saved = net._forward_impl(x, True)
+            finally:
+                drop.seed, drop.offset = now[0], max(now[1], drop.offset)
+                net.train(now[2])
+            ctx.recompute = None
         if ctx.saved is None:
             raise RuntimeError("JDCNet backward called on a forward that ran without gradient bookkeeping")
-        ctx.net._backward_impl(ctx.saved, d_cls, d_det)
+        net._backward_impl(ctx.saved, d_cls, d_det)
         ctx.saved = None
         return None, None, None, None
 
@@ -467,6 +497,7 @@ class JDCNet(nn.Module):
         self.training_graph_wanted = True
         self._dp = None
         self.keep_last_context = False      # tests: expose the saved tensors (dropout masks) of the last forward
+        self.checkpoint_forward = False     # Trainer(gradient_checkpointing=True): recompute the forward in backward
         self.last_context = None
         self._init_weights()
         self._flat = None
@@ -516,10 +547,6 @@ class JDCNet(nn.Module):
         out = super()._apply(fn, recurse)
         self._flatten()                    # .to(device) / .float() re-materialise parameters: re-pack them
         return out
-
-    def load_state_dict(self, state_dict, strict=True, assign=False):
-        res = super().load_state_dict(state_dict, strict=strict, assign=False)
-        return res
 
     def attach_data_parallel(self, dp):
         """``dp``: pitchextractor_amd.distributed.GradientAllReduce over ``flat_gradients()``.  Backward then

@@ -449,6 +449,13 @@ def persistent_lstm_error(device) -> bool:
     return bool(buf is not None and int(buf[0].item()) != 0)
 
 
+def clear_persistent_lstm_error(device) -> None:
+    """Reset the sticky barrier-timeout word (the persistent kernels skip their waits while it is set)."""
+    buf = _SYNC.get(torch.device(device))
+    if buf is not None:
+        buf[0:1].zero_()
+
+
 def _persistent_ok(ncells, B, H, device):
     if not USE_PERSISTENT_LSTM:
         return False

@@ -84,6 +84,12 @@ class FusedAdamW(Optimizer):
         plan["flat_g"] = torch.as_strided(g0, (n,), (1,), glo)
         return plan
 
+    def load_state_dict(self, state_dict):
+        """torch semantics, then drop the cached flat moment buffers: the next ``step`` re-adopts the loaded
+        ``exp_avg`` / ``exp_avg_sq`` instead of continuing with the moments of the run so far."""
+        super().load_state_dict(state_dict)
+        self._flat_plans = {}
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None

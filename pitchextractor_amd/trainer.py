@@ -50,19 +50,22 @@ class Trainer(object):
         self.finish_train = False
         self.mel_transform = mel_transform
         self.data_parallel = data_parallel
-        # The reference honours both flags only on an accelerator (trainer.py:63-64,103).  mixed_precision
-        # switches the k-contiguous MFMA products (conv forward / data gradient, Linear / LSTM input
-        # projections) to bf16 operands with fp32 accumulation -- the autocast op set minus the weight
-        # gradients and the recurrence, which stay fp32; no GradScaler is needed (bf16 keeps the fp32
-        # exponent).  288 GB of HBM holds every activation of a batch-256 step (~20 GB), so
-        # gradient_checkpointing is accepted and recomputes nothing.
+        # The reference honours both flags only on an accelerator (trainer.py:63-64,103).
+        # mixed_precision: inside a per-step scope every MFMA product -- conv forward / data gradient / weight
+        # gradient, Linear and LSTM input projections and their weight gradients, and the persistent LSTM
+        # recurrences (W_hh and the h / dgates rows) -- takes bf16-rounded operands and accumulates in fp32;
+        # attention scores, normalisations, losses, the LSTM cell state and every tensor in HBM stay fp32.
+        # bf16 keeps the fp32 exponent, so no GradScaler is needed; ``amp_dtype="fp16"`` selects the
+        # reference's literal autocast default (fp16 operands + dynamic loss scaling, trainer.py:64-102,241-244).
+        # gradient_checkpointing: the reference's single whole-model segment (trainer.py:226-233) -- the forward
+        # keeps no activations and backward recomputes it (JDCNet.checkpoint_forward).
         self.use_amp = bool(use_mixed_precision)
         self.gradient_checkpointing = bool(gradient_checkpointing)
         self.gradient_checkpoint_use_reentrant = checkpoint_use_reentrant
         if self.use_amp:
-            logger.info("mixed_precision: bf16 MFMA operands for conv / linear products, fp32 accumulate and state")
+            logger.info("mixed_precision: bf16 MFMA operands for every matmul-shaped product, fp32 accumulate and state")
         if self.gradient_checkpointing:
-            logger.info("gradient_checkpointing requested: nothing is recomputed on this part (flag accepted, no-op)")
+            logger.info("gradient_checkpointing: whole-model segment, forward recomputed in backward")
 
     @staticmethod
     def _check_criterion(criterion):
@@ -154,21 +157,43 @@ class Trainer(object):
         return ops.f0_sil_loss(f0_pred.detach().reshape(-1), f0.reshape(-1), sil_pred.detach().reshape(-1),
                                sil.reshape(-1), lam, 1.0, want_grads)
 
+    def _forward_backward(self, x, f0, sil):
+        with ops.matmul_bf16(self.use_amp):
+            self.model.checkpoint_forward = self.gradient_checkpointing
+            try:
+                f0_pred, sil_pred = self.model(x.transpose(-1, -2))
+                out3, d_f0, d_sil = self._loss(f0_pred, sil_pred, f0, sil, True)
+                torch.autograd.backward([f0_pred, sil_pred], [d_f0.view_as(f0_pred), d_sil.view_as(sil_pred)])
+            finally:
+                self.model.checkpoint_forward = False
+        if self.data_parallel is not None:
+            self.data_parallel.finish()
+        return out3
+
+    def _lstm_fault(self, device) -> bool:
+        """True when a persistent-LSTM group barrier timed out in this step on ANY rank (then every rank's
+        results are suspect or its peers would deadlock in the next all-reduce).  Clears the sticky word and
+        switches this process to the one-launch-per-time-step kernels."""
+        bad = ops.persistent_lstm_error(device)
+        if self.data_parallel is not None and self.data_parallel.world > 1:
+            bad = self.data_parallel.any_rank(bad)
+        if bad:
+            ops.clear_persistent_lstm_error(device)
+            ops.USE_PERSISTENT_LSTM = False
+            self.logger.warning("persistent LSTM kernel: a group barrier timed out (workgroups not co-resident?); "
+                                "falling back to the per-time-step kernels for the rest of this run")
+        return bad
+
     def run(self, batch):
         self.optimizer.zero_grad(set_to_none=True)
         x, f0, sil = self._inputs(batch)
-        with ops.matmul_bf16(self.use_amp):
-            f0_pred, sil_pred = self.model(x.transpose(-1, -2))
-            out3, d_f0, d_sil = self._loss(f0_pred, sil_pred, f0, sil, True)
-            torch.autograd.backward([f0_pred, sil_pred], [d_f0.view_as(f0_pred), d_sil.view_as(sil_pred)])
-        if self.data_parallel is not None:
-            self.data_parallel.finish()
+        out3 = self._forward_backward(x, f0, sil)
+        if self._lstm_fault(x.device):                     # before the update: redo the step on the safe kernels
+            self.optimizer.zero_grad(set_to_none=True)
+            out3 = self._forward_backward(x, f0, sil)
         self.optimizer.step()
         self.scheduler.step()
         loss, loss_f0, loss_sil = out3.tolist()            # one device->host copy for all three scalars
-        if ops.persistent_lstm_error(x.device):
-            raise RuntimeError("persistent LSTM kernel: a group barrier timed out (workgroups not co-resident?); "
-                               "set pitchextractor_amd.ops.USE_PERSISTENT_LSTM = False")
         return {"loss": loss, "f0": loss_f0, "sil": loss_sil}
 
     def _epoch(self, loader, tag, step_fn):
@@ -182,6 +207,8 @@ class Trainer(object):
         """One pass over ``train_dataloader`` -> {'train/loss','train/f0','train/sil','train/learning_rate'}."""
         self.epochs += 1
         self.model.train()
+        if hasattr(self.train_dataloader, "set_epoch"):
+            self.train_dataloader.set_epoch(self.epochs)
         out = self._epoch(self.train_dataloader, "train", self.run)
         out["train/learning_rate"] = self._get_lr()
         return out
@@ -191,6 +218,9 @@ class Trainer(object):
         x, f0, sil = self._inputs(batch)
         with ops.matmul_bf16(self.use_amp):
             f0_pred, sil_pred = self.model(x.transpose(-1, -2))
+        if self._lstm_fault(x.device):
+            with ops.matmul_bf16(self.use_amp):
+                f0_pred, sil_pred = self.model(x.transpose(-1, -2))
         out3, _, _ = self._loss(f0_pred, sil_pred, f0, sil, False)
         loss, loss_f0, loss_sil = out3.tolist()
         return {"loss": loss, "f0": loss_f0, "sil": loss_sil}

@@ -233,6 +233,42 @@ def make_data_golden(ref_f0_mod, ref_tools_mod):
     print("data_golden.npz")
 
 
+CACHE_ID_CASES = {
+    "default": {},
+    "shipped_yaml": "Configs/config.yml",           # dataset_params.f0_params of the reference's own config
+    "order_subset": {"backend_order": ["CREPE", "praat", "swiftf0"],
+                     "backends": {"crepe": {"type": "crepe", "enabled": "yes", "config": {"cache_key_suffix": "Full v2"}},
+                                  "swiftf0": {"type": "swiftf0", "enabled": True},
+                                  "Praat": {"type": "praat", "enabled": "off"}}},
+    "dict_entries": {"backend_order": [{"name": "My Harvest", "type": "pyworld", "cache_key_suffix": "a"},
+                                       {"name": "x", "type": "nonexistent"},
+                                       {"name": "dio", "type": "pyworld", "enabled": 0}]},
+    "no_order": {"backends": {"parselmouth": {"type": "parselmouth"}, "pyworld_dio": {"enabled": False},
+                              "pyworld_harvest": {"config": {"algorithm": "harvest"}}}},
+}
+
+
+def make_cache_id_golden(ref_f0_mod):
+    """``F0Extractor.cache_identifier`` (f0_backends.py:661-757) for a few ``f0_params`` blocks.  None of the
+    tracker packages is installed, so the registry's classes are swapped for a do-nothing subclass of the
+    reference's own ``BaseF0Backend``: only the reference's config-merging / naming code runs."""
+    import json
+    import yaml
+
+    class _NoTracker(ref_f0_mod.BaseF0Backend):
+        backend_type = "none"
+
+    for key in list(ref_f0_mod.BACKEND_REGISTRY):
+        ref_f0_mod.BACKEND_REGISTRY[key] = _NoTracker
+    out = {}
+    for tag, cfg in CACHE_ID_CASES.items():
+        if isinstance(cfg, str):
+            cfg = yaml.safe_load(open(REF / cfg))["dataset_params"]["f0_params"]
+        out[tag] = {"f0_params": cfg, "cache_identifier": ref_f0_mod.F0Extractor(24000, 300, cfg).cache_identifier}
+    (HERE / "cache_id_golden.json").write_text(json.dumps(out, indent=1, sort_keys=True))
+    print("cache_id_golden.json", {k: v["cache_identifier"] for k, v in out.items()})
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     sys.path.insert(0, str(REF))
@@ -241,7 +277,7 @@ if __name__ == "__main__":
     ref_trainer = ref_module("ref_trainer", "trainer.py")
     ref_f0 = ref_module("ref_f0_backends", "f0_backends.py")
     ref_tools = ref_module("ref_dynamic_pitch_tools", "Utils/dynamic_pitch_tools.py")
-    what = sys.argv[1:] or ["model", "optimizer", "data", "step"]
+    what = sys.argv[1:] or ["model", "optimizer", "data", "step", "cache_id"]
     if "model" in what:
         make_model_goldens(ref_model)
     if "optimizer" in what:
@@ -250,3 +286,5 @@ if __name__ == "__main__":
         make_data_golden(ref_f0, ref_tools)
     if "step" in what:
         make_step_golden(ref_model, ref_opt, ref_trainer)
+    if "cache_id" in what:
+        make_cache_id_golden(ref_f0)

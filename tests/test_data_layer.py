@@ -1,4 +1,5 @@
 """Host-side data-layer arithmetic (bit-exact: indices, interpolation, padding) -- no GPU needed."""
+import os
 import random
 import struct
 
@@ -76,14 +77,7 @@ def test_dataset_item_and_collater(tmp_path):
         write_wav(p, wave, 24000, "float32")
         np.save(str(p) + "_f0.npy", f0[: len(f0) - (i % 2)])          # legacy cache name, one frame short
         lines.append(f"{p}|0\n")
-    ds = md.MelDataset.__new__(md.MelDataset)
-    # construct without the HIP transform (CPU test): exercise everything except to_melspec
-    ds.verbose = False
-    ds.data_list = [l[:-1].split("|")[0] for l in lines]
-    ds.mel_params = dict(md.DEFAULT_MEL_PARAMS); ds.sr = 24000
-    ds.f0_params = {}; ds.f0_provider = None; ds.f0_cache_glob = "_f0*.npy"
-    ds.data_augmentation = False; ds.max_mel_length = 192; ds.zero_value = 0.0
-    ds._audio_metadata_cache = {}; ds._invalid_paths = set()
+    ds = md.MelDataset(lines, verbose=False)     # the HIP transform is built lazily: everything but to_melspec runs here
     items = [ds[i] for i in range(3)]
     w0, f0_0, s0, c0, sr0 = items[0]
     assert sr0 == 24000
@@ -111,10 +105,56 @@ def test_missing_labels_fail_loudly(tmp_path):
     wave, _, _ = synthetic.utterance(0, duration=1.0)
     p = tmp_path / "x.wav"
     write_wav(p, wave, 24000)
-    ds = md.MelDataset.__new__(md.MelDataset)
-    ds.f0_cache_glob = "_f0*.npy"; ds.f0_provider = None; ds.mel_params = dict(md.DEFAULT_MEL_PARAMS); ds.sr = 24000
+    ds = md.MelDataset([f"{p}|0\n"], verbose=False)
     with pytest.raises(RuntimeError):
         ds._f0_for(str(p), wave, 0, None)
+
+
+def test_cache_identifier_matches_reference_golden(golden_dir):
+    """``F0Extractor.cache_identifier`` as the imported reference computes it (tests/golden/make_golden.py
+    cache_id): the shipped config.yml names its caches ``<wav>_f0-swiftf0.npy``."""
+    import json
+    cases = json.loads((golden_dir / "cache_id_golden.json").read_text())
+    assert cases["shipped_yaml"]["cache_identifier"] == "-swiftf0"
+    for tag, case in cases.items():
+        assert md.f0_cache_identifier(case["f0_params"]) == case["cache_identifier"], tag
+    assert md.f0_cache_identifier({"cache_identifier": "-custom"}) == "-custom"
+
+
+def test_f0_cache_contract(tmp_path):
+    """meldataset.py:566-604: identifier-named cache + matching .json first, legacy ``_f0.npy`` second; a cache
+    computed for another hop / rate / backend chain is not used (and, unlike the reference, not deleted)."""
+    import json
+    wave, f0, _ = synthetic.utterance(0, duration=1.0)
+    p = str(tmp_path / "x.wav")
+    write_wav(p, wave, 24000)
+    params = {"backends": {"swiftf0": {"type": "swiftf0", "enabled": True}}}
+    ds = md.MelDataset([f"{p}|0\n"], f0_params=params, verbose=False)
+    assert ds.f0_cache_suffix == "_f0-swiftf0.npy" and ds.f0_meta_suffix == "_f0-swiftf0.json"
+    meta = {"cache_identifier": "-swiftf0", "backend": "swiftf0", "sample_rate": 24000, "hop_length": 300}
+    legacy, named = f0 + 1.0, f0 + 2.0
+    np.save(p + "_f0.npy", legacy)
+    np.save(p + "_f0-swiftf0.npy", named)
+    # (1) no metadata next to the named cache -> not trusted; the legacy file is the label source
+    np.testing.assert_array_equal(ds._load_cached_f0(p), legacy)
+    # (2) matching metadata -> the named cache wins over the legacy file (which sorts first in a glob)
+    json.dump(meta, open(p + "_f0-swiftf0.json", "w"))
+    np.testing.assert_array_equal(ds._load_cached_f0(p), named)
+    # (3) metadata from another hop length / sample rate / backend chain -> skipped, files stay on disk
+    for key, val in (("hop_length", 256), ("sample_rate", 22050), ("cache_identifier", "-crepe")):
+        json.dump(dict(meta, **{key: val}), open(p + "_f0-swiftf0.json", "w"))
+        np.testing.assert_array_equal(ds._load_cached_f0(p), legacy)
+        assert os.path.isfile(p + "_f0-swiftf0.npy") and os.path.isfile(p + "_f0-swiftf0.json")
+    # (4) a cache of some other backend chain is never picked up by accident
+    os.remove(p + "_f0.npy"); os.remove(p + "_f0-swiftf0.npy"); os.remove(p + "_f0-swiftf0.json")
+    np.save(p + "_f0-crepe.npy", f0)
+    assert ds._load_cached_f0(p) is None
+    with pytest.raises(RuntimeError):
+        ds._f0_for(p, wave, 0, None)
+    # (5) unreadable metadata -> named cache skipped
+    np.save(p + "_f0-swiftf0.npy", named)
+    open(p + "_f0-swiftf0.json", "w").write("{not json")
+    assert ds._load_cached_f0(p) is None
 
 
 def test_resampler_oracle_properties():

@@ -58,6 +58,51 @@ def test_two_rank_gradient_all_reduce(tmp_path):
     assert (tmp_path / "ok0.npy").exists() and (tmp_path / "ok1.npy").exists()
 
 
+def _epoch_worker(rank, world, port, out_dir):
+    """What train.py does per epoch, minus the HIP step: sampler-driven DataLoader + one all-reduce per batch."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    pdist.init_from_env("gloo")
+    n_files, batch = 11, 2                                  # 11 % (2 ranks * 2) != 0: the advisor's hang case
+    sampler = pdist.EpochShardSampler(n_files, batch, rank, world, seed=5)
+    loader = torch.utils.data.DataLoader(list(range(n_files)), batch_size=batch, sampler=sampler, drop_last=True)
+    assert len(loader) == 2                                 # same steps_per_epoch on every rank
+    seen = []
+    for epoch in (1, 2):
+        sampler.set_epoch(epoch)
+        mine = []
+        for b in loader:
+            t = torch.ones(1)
+            dist.all_reduce(t)                              # the step's gradient all-reduce: must pair up
+            assert t.item() == world
+            mine += b.tolist()
+        seen.append(mine)
+    stats = pdist.mean_over_ranks({"eval/loss": float(rank + 1)}, weight=float(rank + 1))
+    assert abs(stats["eval/loss"] - (1 * 1 + 2 * 2) / 3.0) < 1e-12
+    assert pdist.GradientAllReduce(torch.zeros(4), None).any_rank(rank == 1) is True
+    np.save(os.path.join(out_dir, f"seen{rank}.npy"), np.array(seen))
+    dist.destroy_process_group()
+
+
+def test_two_rank_epoch_with_indivisible_file_count_terminates(tmp_path):
+    port = _free_port()
+    mp.spawn(_epoch_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "seen0.npy"), np.load(tmp_path / "seen1.npy")
+    assert a.shape == b.shape == (2, 4)
+    for e in range(2):
+        assert not set(a[e]) & set(b[e])                    # disjoint rank shards of one permutation
+    assert a[0].tolist() != a[1].tolist()                   # reshuffled across ranks between epochs
+    g = torch.Generator(); g.manual_seed(5 + 1)
+    perm = torch.randperm(11, generator=g).tolist()
+    assert a[0].tolist() == perm[0:4] and b[0].tolist() == perm[4:8]       # contiguous cuts, common length
+
+
+def test_shard_sampler_validation_covers_every_item_once():
+    parts = [list(pdist.EpochShardSampler(11, 4, r, 3, shuffle=False, drop_last=False)) for r in range(3)]
+    assert sorted(sum(parts, [])) == list(range(11)) and [len(p) for p in parts] == [4, 4, 3]
+    assert len(pdist.EpochShardSampler(3, 2, 0, 2)) == 0     # cannot fill a batch per rank: train.py refuses
+
+
 def test_single_process_is_a_no_op():
     g = torch.ones(8)
     opt = _Opt()

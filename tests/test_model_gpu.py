@@ -228,6 +228,68 @@ def test_full_batch_is_sample_independent_and_deterministic(hip_device):
     assert torch.equal(cb[:8], c8) and torch.equal(cb[248:], c8) and torch.equal(db[96:104], d8)
 
 
+def _f64_oracle_grads(state, cfg, x, f0, sil):
+    """float64 CPU oracle: forward + backward of the reference-equivalent step (train mode, dropout off)."""
+    st64 = {k: (v.double().requires_grad_(not k.endswith(("running_mean", "running_var")))
+                if v.dtype.is_floating_point else v) for k, v in state.items()}
+    cls, det = model_ref.jdcnet_forward(st64, x.double(), cfg, train=True)
+    loss, _, _ = model_ref.jdc_loss(cls, det, f0.double(), sil.double(), 0.1)
+    loss.backward()
+    return cls.detach(), det.detach(), loss.item(), {k: v.grad for k, v in st64.items()
+                                                      if torch.is_tensor(v) and v.dtype.is_floating_point
+                                                      and v.grad is not None}
+
+
+@pytest.fixture(scope="module")
+def oracle_b8():
+    torch.set_num_threads(16)
+    state = model_ref.seeded_state(11)
+    x8 = golden_input(9, B=8)
+    f0, sil = golden_targets(9, B=8)
+    return state, x8, f0, sil, _f64_oracle_grads(state, dict(SEQ_CFG), x8, f0, sil)
+
+
+@pytest.mark.parametrize("fp32_mode", ["x3", "native"])
+def test_full_size_training_step_matches_oracle_by_tiling(hip_device, oracle_b8, fp32_mode, monkeypatch):
+    """BASELINE config[1] size (B = 256, train mode, default BiLSTM) against the float64 oracle.
+
+    Eight samples tiled x32: BatchNorm batch statistics, the mean loss and every parameter gradient of
+    the tiled batch equal those of the eight-sample batch exactly in real arithmetic, so the float64
+    oracle at B = 8 is the oracle for B = 256 too.  This is where the split-K planner, the XCD remap, the
+    9-tap weight-gradient slab reduction over 3.9 M pixels and the full persistent-LSTM grid run at their
+    bench shapes.  Tolerances are the golden test's (logits 1e-4 of scale, loss 1e-5, gradient norms 2e-3)
+    plus an element-wise bound of 2e-3 of each gradient tensor's largest element (fp32 summation over
+    32x more terms than the B = 8 run)."""
+    monkeypatch.setattr(ops, "FP32_MATMUL", fp32_mode)
+    state, x8, f0, sil, (ref_cls, ref_det, ref_loss, ref_g) = oracle_b8
+    net = build(state, 1, 384, hip_device).train()
+    net.block_dropout = 0.0
+    reps = 32
+    x = x8.repeat(reps, 1, 1, 1).to(hip_device)
+    f0b, silb = f0.repeat(reps, 1).to(hip_device), sil.repeat(reps, 1).to(hip_device)
+    cls, det = net(x)
+    out3, d_f0, d_sil = ops.f0_sil_loss(cls.detach().reshape(-1), f0b.reshape(-1), det.detach().reshape(-1),
+                                        silb.reshape(-1), 0.1)
+    torch.autograd.backward([cls, det], [d_f0.view_as(cls), d_sil.view_as(det)])
+    assert not ops.persistent_lstm_error(hip_device)
+    assert cls.shape == (256, 192, 1)
+    for r in (0, 13, 31):                                           # every replica of the tile, same numbers
+        close(cls[8 * r:8 * r + 8], ref_cls.numpy(), 1e-4)
+        close(det[8 * r:8 * r + 8], ref_det.numpy(), 1e-4)
+    assert abs(out3[0].item() - ref_loss) <= 1e-5 * abs(ref_loss)
+    bad = []
+    for n, p in net.named_parameters():
+        ref = ref_g[n]
+        got = p.grad.detach().cpu().double()
+        rn = ref.norm().item()
+        if abs(got.norm().item() - rn) > 2e-3 * rn + 1e-9:
+            bad.append((n, "norm", got.norm().item(), rn))
+        err = (got - ref).abs().max().item()
+        if err > 2e-3 * ref.abs().max().item() + 1e-9:
+            bad.append((n, "elem", err, ref.abs().max().item()))
+    assert not bad, bad
+
+
 def test_cpu_input_fails_loudly():
     net = JDCNet(num_class=1, sequence_model_config=dict(SEQ_CFG))
     with pytest.raises(RuntimeError):
@@ -292,6 +354,36 @@ def test_checkpoint_roundtrip_and_partial_load(tmp_path, hip_device):
     tr2.load_checkpoint(str(tmp_path / "big.pth"), load_only_params=True)
     assert torch.equal(net2.classifier.weight.cpu(), big["classifier.weight"][:1])
     assert torch.equal(net2.conv_block[0].weight.cpu(), big["conv_block.0.weight"])
+
+
+def test_optimizer_state_loaded_after_a_step_is_adopted(tmp_path, hip_device):
+    """Loading a checkpoint into a trainer that has ALREADY stepped must continue from the loaded AdamW moments
+    (the fused optimizer caches flat moment buffers; ``load_state_dict`` has to drop them)."""
+    crit = {"l1": torch.nn.SmoothL1Loss(), "ce": torch.nn.BCEWithLogitsLoss()}
+    sp = {"max_lr": 3e-4, "pct_start": 0.0, "epochs": 2, "steps_per_epoch": 8}
+    batches = list(training_batches(3))
+
+    def fresh(seed):
+        net = build(model_ref.seeded_state(seed, hidden_size=64), 1, 64, hip_device).train()
+        net.block_dropout = 0.0
+        opt, sched = build_optimizer({"params": net.parameters(), "optimizer_params": {}, "scheduler_params": dict(sp)})
+        return net, Trainer(model=net, criterion=crit, optimizer=opt, scheduler=sched, device="cuda:0",
+                            loss_config={"lambda_f0": 0.1}, logger=logging.getLogger("t"))
+    net_a, tr_a = fresh(11)
+    tr_a.run(batches[0]); tr_a.run(batches[1])
+    path = tmp_path / "two_steps.pth"
+    tr_a.save_checkpoint(str(path))
+    ref = tr_a.run(batches[2])                                   # the continuation every resume must reproduce
+    net_b, tr_b = fresh(12)                                      # other weights, and it has its own history:
+    tr_b.run(batches[2]); tr_b.run(batches[0])
+    tr_b.load_checkpoint(str(path), load_only_params=False)
+    got = tr_b.run(batches[2])
+    assert abs(got["loss"] - ref["loss"]) <= 1e-6 * abs(ref["loss"])
+    assert torch.equal(net_a.flat_parameters, net_b.flat_parameters)
+    sd = tr_b.optimizer.state_dict()["state"]
+    assert float(sd[0]["step"]) == 3.0
+    m = tr_b.optimizer._flat_plans and next(iter(tr_b.optimizer._flat_plans.values()))["m"]
+    assert sd[0]["exp_avg"].data_ptr() == m.data_ptr()            # the saved tensors are the ones being updated
 
 
 def test_notebook_inference_recipe(tmp_path, hip_device):

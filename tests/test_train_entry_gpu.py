@@ -48,16 +48,16 @@ def test_train_py_two_ranks(tmp_path, hip_device):
     two ranks rehearsed on one GPU over gloo (the production backend is RCCL, one process per GPU)."""
     import os
     lines = []
-    for i in range(8):
+    for i in range(11):          # 11 files, 2 ranks x batch 2: not divisible -- ranks must still run equal step counts
         wave, f0, _ = synthetic.utterance(i, duration=2.0)
         p = tmp_path / f"u{i}.wav"
         write_wav(p, wave, 24000, "float32")
         np.save(str(p) + "_f0.npy", f0)
         lines.append(f"{p}|0\n")
     (tmp_path / "train_list.txt").write_text("".join(lines))
-    (tmp_path / "val_list.txt").write_text("".join(lines[:4]))
+    (tmp_path / "val_list.txt").write_text("".join(lines[:3]))
     cfg = yaml.safe_load((ROOT / "Configs" / "config.yml").read_text())
-    cfg.update(log_dir=str(tmp_path / "ckpt"), save_freq=1, epochs=1, batch_size=4, num_workers=0,
+    cfg.update(log_dir=str(tmp_path / "ckpt"), save_freq=1, epochs=2, batch_size=4, num_workers=0,
                train_data=str(tmp_path / "train_list.txt"), val_data=str(tmp_path / "val_list.txt"))
     cfg["model_params"]["sequence_model"].update(hidden_size=64, num_layers=1)
     cfg_path = tmp_path / "config.yml"
@@ -68,5 +68,5 @@ def test_train_py_two_ranks(tmp_path, hip_device):
                           str(cfg_path)], cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-3000:]
     log = (tmp_path / "ckpt" / "train.log").read_text()
-    assert "--- epoch 1 ---" in log and "train/loss" in log
-    assert (tmp_path / "ckpt" / "epoch_00001.pth").exists()
+    assert "--- epoch 2 ---" in log and "train/loss" in log and "eval/loss" in log
+    assert (tmp_path / "ckpt" / "epoch_00002.pth").exists()

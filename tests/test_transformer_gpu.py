@@ -163,3 +163,55 @@ def test_transformer_dropout_masks_replayed_in_oracle(hip_device):
     st64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in state.items()}
     rc, rd = model_ref.jdcnet_forward(st64, x.double(), cfg, train=True, masks=iter(masks))
     assert _rel(cls, rc.detach().numpy()) <= 1e-4 and _rel(det, rd.detach().numpy()) <= 1e-4
+
+
+# ------------------------------------------------------------------ BASELINE config[2]: Transformer head + mixed precision
+# bf16 operands carry 8 significant bits (relative rounding 2^-9 = 2e-3 per operand); through ~12 conv and
+# ~26 linear products the logits drift by a few 1e-3 of their scale and gradient norms by ~1 %.  Stated
+# tolerances: logits 2e-2 of scale, loss 1e-2 relative, per-parameter gradient norms 5e-2 relative.
+BF16_LOGIT_TOL, BF16_LOSS_TOL, BF16_GRAD_TOL = 2e-2, 1e-2, 5e-2
+
+
+def test_transformer_mixed_precision_step_matches_reference_float64(G, hip_device):
+    net = build(model_ref.seeded_state(11, model_type="transformer"), hip_device).train()
+    net.block_dropout = 0.0
+    f0, sil = (t.to(hip_device) for t in golden_targets(3))
+    with ops.matmul_bf16(True):
+        cls, det = net(golden_input(3).to(hip_device))
+        out3, d_f0, d_sil = ops.f0_sil_loss(cls.detach().reshape(-1), f0.reshape(-1), det.detach().reshape(-1),
+                                            sil.reshape(-1), 0.1)
+        torch.autograd.backward([cls, det], [d_f0.view_as(cls), d_sil.view_as(det)])
+    r_cls, r_det = _rel(cls, G["tf_f64_train_cls"]), _rel(det, G["tf_f64_train_det"])
+    assert r_cls <= BF16_LOGIT_TOL and r_det <= BF16_LOGIT_TOL, (r_cls, r_det)
+    assert r_cls > 1e-6                                  # the mode really rounds operands
+    np.testing.assert_allclose(out3.cpu().numpy()[0], G["tf_f64_loss"][0], rtol=BF16_LOSS_TOL)
+    norms = dict(zip([str(n) for n in G["tf_f64_grad_names"]], G["tf_f64_grad_norms"]))
+    bad = [(n, p.grad.double().norm().item(), norms[n]) for n, p in net.named_parameters()
+           if abs(p.grad.double().norm().item() - norms[n]) > BF16_GRAD_TOL * norms[n] + 1e-9]
+    assert not bad, bad
+
+
+def test_transformer_mixed_precision_curve_tracks_cpu_oracle_trainer(hip_device):
+    """12 optimiser steps of the HIP trainer with use_mixed_precision=True (Transformer head, dropout off)
+    against the fp32 CPU oracle trainer (oracle/train_ref.CpuTrainer = reference Trainer.run restated) on
+    identical batches: loss within 2 %."""
+    import logging
+    from oracle import train_ref
+    from pitchextractor_amd.optimizers import build_optimizer
+    from pitchextractor_amd.trainer import Trainer
+    from tests.golden.make_golden import training_batches
+    state = model_ref.seeded_state(21, model_type="transformer")
+    net = build(state, hip_device).train()
+    net.block_dropout = 0.0
+    opt, sched = build_optimizer({"params": net.parameters(), "optimizer_params": {},
+                                  "scheduler_params": {"max_lr": 3e-4, "pct_start": 0.0, "epochs": 100,
+                                                       "steps_per_epoch": 8}})
+    tr = Trainer(model=net, criterion={"l1": torch.nn.SmoothL1Loss(), "ce": torch.nn.BCEWithLogitsLoss()},
+                 optimizer=opt, scheduler=sched, device="cuda:0", loss_config={"lambda_f0": 0.1},
+                 logger=logging.getLogger("t"), use_mixed_precision=True)
+    torch.set_num_threads(16)
+    cpu = train_ref.CpuTrainer(state, dict(TF_CFG), max_lr=3e-4, total_steps=800, lambda_f0=0.1)
+    for i, batch in enumerate(training_batches(12)):
+        got, ref = tr.run(batch), cpu.run(batch)
+        assert abs(got["loss"] - ref["loss"]) <= 2e-2 * abs(ref["loss"]), (i, got, ref)
+        assert abs(got["sil"] - ref["sil"]) <= 2e-2 * abs(ref["sil"]) + 2e-3, (i, got, ref)

@@ -5,8 +5,9 @@
     python train.py --config_path ./Configs/config.yml
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train.py -p cfg.yml
 
-Data-parallel runs shard every minibatch over the ranks (one process per GPU) and all-reduce
-gradients with RCCL; rank 0 logs and checkpoints.  TensorBoard is optional (absent -> scalars go to
+Data-parallel runs shard every minibatch over the ranks (one process per GPU: per-epoch seeded
+permutation cut into equal contiguous rank shards) and all-reduce gradients with RCCL; rank 0 logs
+and checkpoints.  TensorBoard is optional (absent -> scalars go to
 the log file only).
 """
 import logging
@@ -86,15 +87,20 @@ def main(config_path):
     training_config = config.get("training", {})
 
     train_list, val_list = get_data_path_list(config.get("train_data"), config.get("val_data"))
-    if world > 1:                                  # contiguous per-rank shards of the file lists
-        train_list = train_list[rank::world]
-        val_list = val_list[rank::world]
+    # Data parallel: every rank holds the whole list; each epoch one seeded permutation is cut into equal
+    # contiguous per-rank shards truncated to a common length (distributed.EpochShardSampler), so all ranks
+    # run the same number of steps and OneCycleLR sees the same steps_per_epoch everywhere.
+    seed = int(config.get("seed", 1234))
+    shard = (rank, world, seed) if world > 1 else None
     per_rank_batch = max(1, batch_size // world)
     train_dataloader = build_dataloader(train_list, batch_size=per_rank_batch, num_workers=num_workers,
-                                        dataset_config=config.get("dataset_params", {}), device=device)
+                                        dataset_config=config.get("dataset_params", {}), device=device, shard=shard)
     val_dataloader = build_dataloader(val_list, batch_size=per_rank_batch, validation=True,
                                       num_workers=num_workers // 2, device=device,
-                                      dataset_config=config.get("dataset_params", {}))
+                                      dataset_config=config.get("dataset_params", {}), shard=shard)
+    if len(train_dataloader) == 0:
+        raise SystemExit(f"train list of {len(train_list)} files cannot fill one batch of {per_rank_batch} on "
+                         f"each of {world} rank(s)")
 
     model_config = config.get("model_params", {})
     model = JDCNet(num_class=model_config.get("num_class", 1),
@@ -106,6 +112,7 @@ def main(config_path):
         "steps_per_epoch": len(train_dataloader),
     }
     model.to(device)
+    model.dropout_cfg.seed = seed + rank           # replicas draw different dropout masks
     optimizer, scheduler = build_optimizer(
         {"params": model.parameters(), "optimizer_params": {}, "scheduler_params": scheduler_params})
     criterion = {"l1": nn.SmoothL1Loss(), "ce": nn.BCEWithLogitsLoss()}
@@ -127,7 +134,14 @@ def main(config_path):
 
     for epoch in range(1, epochs + 1):
         results = trainer._train_epoch()
-        results.update(trainer._eval_epoch())
+        evals = trainer._eval_epoch()
+        if world > 1:                               # logging only: every rank's batches count
+            lr = results.pop("train/learning_rate")
+            results = pdist.mean_over_ranks(results, len(train_dataloader), device=device)
+            results["train/learning_rate"] = lr
+            evals = pdist.mean_over_ranks(evals or {"eval/loss": 0.0, "eval/f0": 0.0, "eval/sil": 0.0},
+                                          len(val_dataloader) if evals else 0, device=device)
+        results.update(evals)
         if rank == 0:
             logger.info("--- epoch %d ---" % epoch)
             for key, value in results.items():
