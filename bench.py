@@ -9,10 +9,16 @@ already resident in HBM: fused mel front end -> JDCNet forward -> SmoothL1+BCE l
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints one JSON line.  ``roofline`` prices the dominant kernel family (the 3x3 implicit-GEMM
-convolutions: forward + data-gradient launches of ``conv3x3_kernel``) by algorithmic FLOPs over
-HIP-event time measured inside the timed region; ``cpu_baseline`` times the CPU oracle trainer on a
-bounded sample (B = 4, the reference's own CPU-runnable configuration).
+Rank 0 prints one JSON line.  ``value`` is the HBM-resident rate (inputs in HBM when the timed region
+starts).  ``roofline`` prices the dominant kernel family (the 3x3 implicit-GEMM convolutions: forward +
+data-gradient launches of ``conv3x3_halo_kernel``) by algorithmic FLOPs over HIP-event time measured inside
+the timed region; ``roofline_mel`` does the same for the fused mel front end against HBM bandwidth
+(1 520 B per frame).  After the timed region (N = 1 only, never part of ``value``):
+``kernel_families`` = HIP events around every C-ABI call for a few extra steps (ms/step, share of the step,
+achieved rate and fraction of the matching peak, all computed here); ``from_host`` = the same step fed from
+pinned host memory with the next batch's H2D in flight on a side stream (SURVEY 8d's step definition);
+``fp32_native_mfma`` = the step on the native fp32 MFMA instructions; ``cpu_baseline`` = the CPU oracle
+trainer on BASELINE config[0] (B = 4, 10 steps after 2 warm-ups).
 """
 import argparse
 import json
@@ -63,7 +69,7 @@ def pmc_traffic(conv_key="pe_conv3x3_fwd"):
         return None
 
 
-def cpu_baseline(n_steps=3, batch=4):
+def cpu_baseline(n_steps=10, batch=4, n_warm=2):
     """Reference-equivalent fp32 CPU trainer (oracle port) on a bounded sample, host cores stated."""
     from oracle import mel_ref, model_ref, train_ref
     from pitchextractor_amd import synthetic
@@ -81,11 +87,13 @@ def cpu_baseline(n_steps=3, batch=4):
         mels[i, 0, :, :lm.shape[1]] = lm
     t_mel = time.perf_counter() - t_mel0
     b = (torch.from_numpy(mels), torch.from_numpy(f0), torch.from_numpy(sil))
-    t0 = time.perf_counter()
-    tr.run(b)                                   # warm-up
-    warm = time.perf_counter() - t0
-    if warm > 10.0:                             # keep the whole baseline within ~30 s of CPU work
-        n_steps = 1
+    warm = 0.0
+    for _ in range(n_warm):                     # 2 warm-up steps, then 10 timed
+        t0 = time.perf_counter()
+        tr.run(b)
+        warm = time.perf_counter() - t0
+    if warm * n_steps > 60.0:                   # keep the whole baseline bounded on a slow host
+        n_steps = max(1, int(60.0 / warm))
     times = []
     for _ in range(n_steps):
         t0 = time.perf_counter()
@@ -93,8 +101,30 @@ def cpu_baseline(n_steps=3, batch=4):
         times.append(time.perf_counter() - t0)
     step = float(np.median(times))
     return {"value": batch * FRAMES / (step + t_mel), "unit": "mel-frames/s", "cores": cores, "kind": "port",
-            "sample": f"{n_steps} steps of batch {batch} x {FRAMES} frames, default JDCNet+BiLSTM fp32, "
-                      f"incl. float64 numpy mel ({t_mel * 1e3:.0f} ms/batch); median step {step:.2f} s"}
+            "model_step_only": batch * FRAMES / step,
+            "sample": f"BASELINE config[0]: {n_steps} steps after {n_warm} warm-ups of batch {batch} x {FRAMES} frames, "
+                      f"default JDCNet+BiLSTM fp32, incl. float64 numpy mel ({t_mel * 1e3:.0f} ms/batch); "
+                      f"median step {step:.2f} s"}
+
+
+def _family_table(summ, steps, step_ms):
+    """Per C-ABI entry point: ms/step, share of the step, achieved rate and fraction of the matching peak --
+    all from HIP-event sums of this run (MFMA families: algorithmic 2*M*N*K FLOPs; mel: 1 520 B/frame)."""
+    rows = {}
+    for name, v in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"]):
+        ms = v["total_ms"] / steps
+        row = {"ms_per_step": round(ms, 4), "share_of_step": round(ms / step_ms, 4), "calls_per_step": v["calls"] / steps}
+        if v["work"]:
+            rate = v["work"] / (v["total_ms"] * 1e-3)
+            if name.startswith("pe_mel") or name.startswith("pe_resample"):
+                row.update(bound="hbm", achieved_gbps=rate / 1e9, frac_of_peak=rate / 1e9 / HBM_PEAK_GBPS)
+            else:
+                # the entry point's suffix names the pipe its products ran on
+                peak = (MFMA_BF16_PEAK_TFLOPS if name.endswith("_bf16") else
+                        MFMA_BF16_PEAK_TFLOPS / 6.0 if name.endswith("_x3") else MFMA_F32_PEAK_TFLOPS)
+                row.update(bound="mfma", achieved_tflops=rate / 1e12, peak_tflops=peak, frac_of_peak=rate / 1e12 / peak)
+        rows[name] = row
+    return rows
 
 
 def main():
@@ -115,15 +145,20 @@ def main():
     ap.add_argument("--no-native-ref", action="store_true",
                     help="skip the 7 extra steps that time the native fp32 MFMA form for the fp32_native_mfma field")
     ap.add_argument("--family-timing", action="store_true",
-                    help="HIP events around EVERY C-ABI call (kernel_families_ms_per_step); by default only the "
-                         "roofline kernel's launches are bracketed, which keeps ~1400 event records per step out "
-                         "of the timed region")
+                    help="HIP events around EVERY C-ABI call INSIDE the timed region (costs ~2 %% of the step); by "
+                         "default only the roofline kernels are bracketed there and the family table comes from "
+                         "--family-steps extra steps after it")
+    ap.add_argument("--family-steps", type=int, default=3,
+                    help="extra steps after the timed region with events around every call (0 = skip; N = 1 only)")
+    ap.add_argument("--host-steps", type=int, default=None,
+                    help="extra steps fed from pinned host memory with double-buffered H2D (default: --steps; 0 = skip)")
     args = ap.parse_args()
     bf16 = args.precision == "bf16"
 
     from pitchextractor_amd import distributed as pdist
     from pitchextractor_amd import ops, synthetic
     from pitchextractor_amd.mel import DEFAULT_MEL_PARAMS, MelSpectrogram
+    from pitchextractor_amd.meldataset import H2DPrefetcher
     from pitchextractor_amd.model import JDCNet
     from pitchextractor_amd.optimizers import build_optimizer
     from pitchextractor_amd.trainer import Trainer
@@ -158,10 +193,9 @@ def main():
     lo, _ = pdist.shard_range(args.batch * world, rank, world)
     w32, f32, s32 = synthetic.batch(lo % 32, 32)
     reps = (args.batch + 31) // 32
-    waves = torch.from_numpy(np.tile(w32, (reps, 1))[:args.batch]).to(dev)
-    f0 = torch.from_numpy(np.tile(f32, (reps, 1))[:args.batch]).to(dev)
-    sil = torch.from_numpy(np.tile(s32, (reps, 1))[:args.batch]).to(dev)
-    batch = (waves, f0, sil)
+    host = tuple(torch.from_numpy(np.tile(a, (reps, 1))[:args.batch]).pin_memory() for a in (w32, f32, s32))
+    batch = tuple(t.to(dev) for t in host)
+    real_frames = 1 + w32.shape[1] // DEFAULT_MEL_PARAMS["hop_length"]
 
     def barrier():
         if world > 1:
@@ -178,7 +212,7 @@ def main():
     barrier()
     x3 = ops.FP32_MATMUL == "x3"
     conv_key = "pe_conv3x3_fwd" + ("_bf16" if bf16 else "_x3" if x3 else "")
-    ops.TIMER = ops.KernelTimer(None if args.family_timing else {conv_key})
+    ops.TIMER = ops.KernelTimer(None if args.family_timing else {conv_key, "pe_mel_forward"})
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = tr.run(batch)
@@ -192,9 +226,46 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    ms = elapsed / args.steps * 1e3
 
-    # the same step with the fp32 products on the native fp32 MFMA instructions, for reference (N = 1 only,
-    # a few steps after the timed region; never part of `value`)
+    # ---- everything below runs AFTER the timed region and never enters `value` ----------------------
+    # (a) family table: events around every C-ABI call for a few extra steps (N = 1 only)
+    fam_summ, fam_ms = (timer.summary(), ms) if args.family_timing else (None, None)
+    if world == 1 and not args.family_timing and args.family_steps > 0:
+        ops.TIMER = ops.KernelTimer(None)
+        torch.cuda.synchronize(dev)
+        t_f = time.perf_counter()
+        for _ in range(args.family_steps):
+            tr.run(batch)
+        torch.cuda.synchronize(dev)
+        fam_ms = (time.perf_counter() - t_f) / args.family_steps * 1e3
+        fam_summ, ops.TIMER = ops.TIMER.summary(), None
+
+    # (b) SURVEY 8(d)'s step: from pinned host audio, the next batch's H2D (49 MB) in flight on a side stream
+    from_host = None
+    host_steps = args.steps if args.host_steps is None else args.host_steps
+    if host_steps > 0:
+        feeder = H2DPrefetcher(dev)
+        tr.run(feeder.acquire(feeder.submit(host)))                       # warm the side-stream allocations
+        barrier()
+        t_h = time.perf_counter()
+        ticket = feeder.submit(host)
+        for k in range(host_steps):
+            nxt = feeder.submit(host) if k + 1 < host_steps else None
+            tr.run(feeder.acquire(ticket))
+            ticket = nxt
+        barrier()
+        el_h = time.perf_counter() - t_h
+        if world > 1:
+            t = torch.tensor([el_h], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el_h = float(t.item())
+        from_host = {"value": args.batch * world * FRAMES * host_steps / el_h, "unit": "mel-frames/s",
+                     "ms_per_step": el_h / host_steps * 1e3, "steps": host_steps,
+                     "h2d_bytes_per_step": int(sum(t.numel() * t.element_size() for t in host)),
+                     "note": "step starts at pinned host audio; batch k+1's H2D overlaps step k on a side stream"}
+
+    # (c) the same step with the fp32 products on the native fp32 MFMA instructions, for reference (N = 1 only)
     native_ref = None
     if world == 1 and x3 and not bf16 and not args.no_native_ref:
         ops.FP32_MATMUL = "native"
@@ -213,7 +284,6 @@ def main():
             ops.FP32_MATMUL = "x3"
 
     if rank == 0:
-        ms = elapsed / args.steps * 1e3
         frames = args.batch * world * FRAMES * args.steps
         summ = timer.summary()
         conv = summ.get(conv_key)
@@ -224,29 +294,43 @@ def main():
                 peak, note = MFMA_BF16_PEAK_TFLOPS, "bf16 dense MFMA peak"
             elif x3:
                 peak, note = MFMA_BF16_PEAK_TFLOPS / 6.0, ("fp32 product = 6 bf16 MFMAs (exact 3-term split): "
-                                                           "bf16 dense MFMA peak / 6; the native fp32 MFMA peak "
-                                                           f"is {MFMA_F32_PEAK_TFLOPS} TFLOP/s")
+                                                           "bf16 dense MFMA peak / 6 (builder-defined ceiling); the "
+                                                           f"native fp32 MFMA peak is {MFMA_F32_PEAK_TFLOPS} TFLOP/s")
             else:
                 peak, note = MFMA_F32_PEAK_TFLOPS, "fp32 MFMA (32x32x2) peak"
             roof = {"bound": "mfma", "kernel": ("conv3x3_kernel (implicit-GEMM fwd + dgrad launches)" if not (bf16 or x3) else "conv3x3_halo_kernel (halo-staged implicit-GEMM fwd + dgrad launches)"),
                     "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak,
                     "peak_note": note, "traffic": pmc_traffic(conv_key),
                     "avg_launch_ms": conv["avg_ms"], "launches_per_step": conv["calls"] / args.steps}
-        families = {k: {"ms_per_step": v["total_ms"] / args.steps,
-                        "tflops": (v["work"] / (v["total_ms"] * 1e-3) / 1e12) if v["work"] else None}
-                    for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])[:12]}
+        mel = summ.get("pe_mel_forward")
+        roof_mel = None
+        if mel:
+            gbps = mel["work"] / (mel["total_ms"] * 1e-3) / 1e9              # 1 520 B x real frames per launch
+            roof_mel = {"bound": "hbm", "kernel": "mel_fwd_kernel (frame + Hann + rFFT + power + mel + log + pad)",
+                        "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+                        "bytes_per_launch": mel["work"] / mel["calls"], "avg_launch_ms": mel["avg_ms"],
+                        "traffic": None,
+                        "note": "62.6 MB per launch fits the 256 MiB Infinity Cache: this is the warm in-step rate; "
+                                "the cold multi-batch rate is tools/bench_mel.py (profiles/)"}
         line = {
             "metric": "mel-frames/sec training throughput (JDCNet, 24 kHz, batch=256)",
             "value": frames / elapsed, "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
             "config": {"workload": (("BASELINE config[2]: batch" if args.head == "transformer" else "BASELINE config[3] per-GPU shape: batch") if bf16 else "BASELINE config[1]: batch") + "=256/GPU, 24 kHz 2 s synthetic glides "
-                                   f"(161 real frames zero-padded to 192), JDCNet+{'BiLSTM(4x384)' if args.head == 'bilstm' else 'Transformer(4 layers, 8 heads, ff 1536)'}, " + ("mixed precision (bf16 conv/linear operands, fp32 accumulate), " if bf16 else f"fp32 (products: {ops.FP32_MATMUL}), ") +
+                                   f"({real_frames} real frames zero-padded to 192), JDCNet+{'BiLSTM(4x384)' if args.head == 'bilstm' else 'Transformer(4 layers, 8 heads, ff 1536)'}, " + ("mixed precision (bf16 conv/linear operands, fp32 accumulate), " if bf16 else f"fp32 (products: {ops.FP32_MATMUL}), ") +
                                    "raw audio resident in HBM -> mel -> fwd -> loss -> bwd -> AdamW",
                        "global_batch": args.batch * world, "frames_per_utterance": FRAMES,
-                       "real_frames_per_utterance": 161, "parallelism": f"dp{world}"},
-            "loss": last["loss"], "roofline": roof, "kernel_families_ms_per_step": families,
+                       "real_frames_per_utterance": real_frames, "parallelism": f"dp{world}"},
+            "loss": last["loss"], "roofline": roof, "roofline_mel": roof_mel,
         }
+        if from_host is not None:
+            line["from_host"] = from_host
+        if fam_summ is not None:
+            line["kernel_families"] = {"steps": args.steps if args.family_timing else args.family_steps,
+                                       "ms_per_step_with_events": fam_ms,
+                                       "rows": _family_table(fam_summ, args.steps if args.family_timing else args.family_steps,
+                                                             fam_ms)}
         if native_ref is not None:
             line["fp32_native_mfma"] = native_ref
         if world == 1 and not args.no_cpu_baseline and args.head == "bilstm" and not bf16:

@@ -435,6 +435,32 @@ class Collater(object):
         return waves, lengths, crops, f0s, sils, (rates.pop() if rates else 0)
 
 
+class H2DPrefetcher:
+    """Host->device copies on a side HIP stream so the next batch's raw audio (49 MB at B = 256) crosses PCIe
+    underneath the current step.  ``submit`` starts the copies of a tuple of (pinned) host tensors and returns a
+    ticket; ``acquire`` makes the compute stream wait for that ticket only."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+
+    def submit(self, host_items):
+        with torch.cuda.stream(self.stream):
+            dev = tuple(t.to(self.device, non_blocking=True) if torch.is_tensor(t) else t for t in host_items)
+            ready = torch.cuda.Event()
+            ready.record(self.stream)
+        return dev, ready
+
+    def acquire(self, ticket):
+        dev, ready = ticket
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(ready)
+        for t in dev:
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(cur)              # allocated on the side stream, consumed on the compute stream
+        return dev
+
+
 class DeviceMelLoader:
     """Iterates a host DataLoader of raw-audio batches and yields the reference's batch tuple
     ``(mels (B,1,80,192), f0s, is_silences)`` with the mel computed on the GPU in one launch."""
@@ -443,6 +469,7 @@ class DeviceMelLoader:
         self.loader, self.mel, self.device = loader, mel, torch.device(device)
         self.dataset = loader.dataset
         self._resamplers = {}
+        self._h2d = None
 
     def __len__(self):
         return len(self.loader)
@@ -453,17 +480,32 @@ class DeviceMelLoader:
         if hasattr(sampler, "set_epoch"):
             sampler.set_epoch(epoch)
 
+    def _finish(self, ticket):
+        waves, lengths, crops, f0s, sils, src_sr = self._h2d.acquire(ticket)
+        if src_sr and src_sr != self.mel.sample_rate:
+            rs = self._resamplers.setdefault(src_sr, Resampler(src_sr, self.mel.sample_rate))
+            waves = rs(waves)                                 # zero-padded rows resample exactly like each item alone
+            lengths = torch.tensor([rs.out_len(int(n)) for n in self._host_lengths.pop(0)], dtype=torch.int32,
+                                   device=self.device)
+        else:
+            self._host_lengths.pop(0)
+        mels = self.mel.log_mel_ragged(waves, lengths, crops, max_frames=MAX_MEL_LENGTH)
+        return mels, f0s, sils
+
     def __iter__(self):
-        for waves, lengths, crops, f0s, sils, src_sr in self.loader:
-            waves = waves.to(self.device, non_blocking=True)
-            if src_sr and src_sr != self.mel.sample_rate:
-                rs = self._resamplers.setdefault(src_sr, Resampler(src_sr, self.mel.sample_rate))
-                waves = rs(waves)                             # zero-padded rows resample exactly like each item alone
-                lengths = torch.tensor([rs.out_len(int(n)) for n in lengths], dtype=torch.int32)
-            lengths = lengths.to(self.device, non_blocking=True)
-            crops = crops.to(self.device, non_blocking=True)
-            mels = self.mel.log_mel_ragged(waves, lengths, crops, max_frames=MAX_MEL_LENGTH)
-            yield mels, f0s.to(self.device, non_blocking=True), sils.to(self.device, non_blocking=True)
+        """Double-buffered: batch k+1's H2D is in flight on the side stream while batch k is being consumed."""
+        if self._h2d is None:
+            self._h2d = H2DPrefetcher(self.device)
+        self._host_lengths = []
+        pending = None
+        for host in self.loader:
+            self._host_lengths.append(host[1].tolist())
+            ticket = self._h2d.submit(host)
+            if pending is not None:
+                yield self._finish(pending)
+            pending = ticket
+        if pending is not None:
+            yield self._finish(pending)
 
 
 def build_dataloader(path_list, validation=False, batch_size=4, num_workers=1, device="cpu", collate_config=None,

@@ -249,6 +249,16 @@ def oracle_b8():
     return state, x8, f0, sil, _f64_oracle_grads(state, dict(SEQ_CFG), x8, f0, sil)
 
 
+def _hip_step_grads(state, x, f0, sil, device):
+    net = build(state, 1, 384, device).train()
+    net.block_dropout = 0.0
+    cls, det = net(x.to(device))
+    out3, d_f0, d_sil = ops.f0_sil_loss(cls.detach().reshape(-1), f0.to(device).reshape(-1), det.detach().reshape(-1),
+                                        sil.to(device).reshape(-1), 0.1)
+    torch.autograd.backward([cls, det], [d_f0.view_as(cls), d_sil.view_as(det)])
+    return cls, det, out3[0].item(), {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+
+
 @pytest.mark.parametrize("fp32_mode", ["x3", "native"])
 def test_full_size_training_step_matches_oracle_by_tiling(hip_device, oracle_b8, fp32_mode, monkeypatch):
     """BASELINE config[1] size (B = 256, train mode, default BiLSTM) against the float64 oracle.
@@ -257,36 +267,34 @@ def test_full_size_training_step_matches_oracle_by_tiling(hip_device, oracle_b8,
     the tiled batch equal those of the eight-sample batch exactly in real arithmetic, so the float64
     oracle at B = 8 is the oracle for B = 256 too.  This is where the split-K planner, the XCD remap, the
     9-tap weight-gradient slab reduction over 3.9 M pixels and the full persistent-LSTM grid run at their
-    bench shapes.  Tolerances are the golden test's (logits 1e-4 of scale, loss 1e-5, gradient norms 2e-3)
-    plus an element-wise bound of 2e-3 of each gradient tensor's largest element (fp32 summation over
-    32x more terms than the B = 8 run)."""
+    bench shapes.  Tolerances: logits 1e-4 of scale, loss 1e-5, per-parameter gradient norms 2e-3 (the golden
+    test's), every gradient ELEMENT within 2.5e-2 of its tensor's largest element against float64 -- the
+    weight gradients in front of a train-mode BatchNorm are sums with heavy cancellation: the reference's own
+    fp32 CPU path is off by up to 5.8e-3 there and this path by 1.1e-2 (native) / 1.4e-2 (x3) -- and, the
+    actual point of the test, within 1e-3 of the SAME path run at B = 8 (measured: identical to 3 digits)."""
     monkeypatch.setattr(ops, "FP32_MATMUL", fp32_mode)
     state, x8, f0, sil, (ref_cls, ref_det, ref_loss, ref_g) = oracle_b8
-    net = build(state, 1, 384, hip_device).train()
-    net.block_dropout = 0.0
     reps = 32
-    x = x8.repeat(reps, 1, 1, 1).to(hip_device)
-    f0b, silb = f0.repeat(reps, 1).to(hip_device), sil.repeat(reps, 1).to(hip_device)
-    cls, det = net(x)
-    out3, d_f0, d_sil = ops.f0_sil_loss(cls.detach().reshape(-1), f0b.reshape(-1), det.detach().reshape(-1),
-                                        silb.reshape(-1), 0.1)
-    torch.autograd.backward([cls, det], [d_f0.view_as(cls), d_sil.view_as(det)])
+    _, _, loss8, g8 = _hip_step_grads(state, x8, f0, sil, hip_device)
+    cls, det, loss, g = _hip_step_grads(state, x8.repeat(reps, 1, 1, 1), f0.repeat(reps, 1), sil.repeat(reps, 1),
+                                        hip_device)
     assert not ops.persistent_lstm_error(hip_device)
     assert cls.shape == (256, 192, 1)
     for r in (0, 13, 31):                                           # every replica of the tile, same numbers
         close(cls[8 * r:8 * r + 8], ref_cls.numpy(), 1e-4)
         close(det[8 * r:8 * r + 8], ref_det.numpy(), 1e-4)
-    assert abs(out3[0].item() - ref_loss) <= 1e-5 * abs(ref_loss)
+    assert abs(loss - ref_loss) <= 1e-5 * abs(ref_loss) and abs(loss - loss8) <= 1e-6 * abs(ref_loss)
     bad = []
-    for n, p in net.named_parameters():
+    for n, got in g.items():
         ref = ref_g[n]
-        got = p.grad.detach().cpu().double()
+        got64, top = got.cpu().double(), ref.abs().max().item()
         rn = ref.norm().item()
-        if abs(got.norm().item() - rn) > 2e-3 * rn + 1e-9:
-            bad.append((n, "norm", got.norm().item(), rn))
-        err = (got - ref).abs().max().item()
-        if err > 2e-3 * ref.abs().max().item() + 1e-9:
-            bad.append((n, "elem", err, ref.abs().max().item()))
+        if abs(got64.norm().item() - rn) > 2e-3 * rn + 1e-9:
+            bad.append((n, "norm", got64.norm().item(), rn))
+        if (got64 - ref).abs().max().item() > 2.5e-2 * top + 1e-9:
+            bad.append((n, "elem vs float64", (got64 - ref).abs().max().item(), top))
+        if (got - g8[n]).abs().max().item() > 1e-3 * top + 1e-9:
+            bad.append((n, "elem vs B=8", (got - g8[n]).abs().max().item(), top))
     assert not bad, bad
 
 
