@@ -115,6 +115,18 @@ int pe_conv3x3_fwd_bf16(const float* x, const float* w_packed, float* y, int B, 
                         int accumulate, void* stream);   /* bf16 operands, fp32 accumulate (see pe_gemm_nt_bf16) */
 int pe_conv3x3_fwd_x3(const float* x, const float* w_packed, float* y, int B, int T, int F, int C, int N,
                       int accumulate, void* stream);     /* fp32-accurate, three-term bf16 split (see pe_gemm_nt_x3) */
+/* Weights pre-packed as MFMA B-operand fragments (x3: three exact bf16 terms, terms = 3; mixed precision: one
+ * RNE-rounded term, terms = 1).  w is [N][K] row-major fp32 (K % 16 == 0); fragment (kb, nb, term) holds, for
+ * lane 32 h + r, w[32 nb + r][16 kb + 8 h .. + 7] in 16 bytes, the 64 lanes contiguous (1 KB).  The halo
+ * convolution then loads its weight operands straight from L2 into registers: LDS carries only activations.
+ * pe_conv3x3_wf_supported: 1 if (F, C, N) is served by the fragment-fed kernel (else use pe_conv3x3_fwd_*). */
+size_t pe_wfrag_bytes(int N, int K, int terms);
+int pe_wfrag_pack(const float* w, long ld, int N, int K, int terms, void* wfrag, void* stream);
+int pe_conv3x3_wf_supported(int F, int C, int N);
+int pe_conv3x3_fwd_wf_x3(const float* x, const void* wfrag, float* y, int B, int T, int F, int C, int N,
+                         int accumulate, void* stream);
+int pe_conv3x3_fwd_wf_bf16(const float* x, const void* wfrag, float* y, int B, int T, int F, int C, int N,
+                           int accumulate, void* stream);
 size_t pe_conv3x3_wgrad_workspace_bytes(int B, int T, int F, int Cin, int Cout);
 int pe_conv3x3_wgrad(const float* x, const float* dy, float* dw_oihw, int B, int T, int F, int Cin,
                      int Cout, float* workspace, size_t workspace_bytes, void* stream);

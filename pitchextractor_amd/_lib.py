@@ -51,6 +51,11 @@ PROTOTYPES = {
     "pe_conv3x3_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "pe_conv3x3_fwd_bf16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "pe_conv3x3_fwd_x3": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "pe_wfrag_bytes": (_z, [_i, _i, _i]),
+    "pe_wfrag_pack": (_i, [_p, _l, _i, _i, _i, _p, _p]),
+    "pe_conv3x3_wf_supported": (_i, [_i, _i, _i]),
+    "pe_conv3x3_fwd_wf_x3": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "pe_conv3x3_fwd_wf_bf16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "pe_conv3x3_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
     "pe_conv3x3_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
     "pe_conv3x3_wgrad_x3": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),

@@ -256,6 +256,191 @@ int launch_conv_halo(const float* x, const float* wp, float* y, int B, int T, in
   return PE_OK;
 }
 
+// ---------------------------------------------------------------- weights as MFMA fragments straight from L2
+// The kernel above stages a 32-k weight slab per tap through LDS: every workgroup repeats the split of the
+// same few hundred KB of weights, and each of the nine stages of a channel chunk costs two workgroup
+// barriers although the activation window does not change.  Here the weights are packed ONCE per call
+// (wfrag_pack_kernel) into the B-operand fragment order of v_mfma_f32_32x32x16_bf16 -- for every
+// (16-k block, 32-row block, term) the 64 lanes' 16-byte pieces are contiguous (1 KB) -- and a wave loads
+// its fragments directly into registers with one coalesced global_load_dwordx4 per fragment, a ring of
+// D steps ahead of the MFMAs that consume them.  LDS holds only the activation window: two barriers per
+// channel chunk (9 taps = 18 k-blocks) instead of per tap, no weight split, no weight LDS traffic.
+//   fragment (kb, nb, c), lane l = 32 h + r  <->  B[n = 32 nb + r][k = 16 kb + 8 h .. + 7] of term c.
+template <int NT>
+__global__ void wfrag_pack_kernel(const float* __restrict__ w, long ld, int N, int K, uint4* __restrict__ out) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int NB32 = (N + 31) >> 5, KB = K >> 4;
+  const int lane = (int)(idx & 63);
+  const long blk = idx >> 6;
+  if (blk >= (long)NB32 * KB) return;
+  const int nb = (int)(blk % NB32), kb = (int)(blk / NB32);
+  const int n = nb * 32 + (lane & 31), k = kb * 16 + (lane >> 5) * 8;
+  float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+  if (n < N) {
+    v0 = *reinterpret_cast<const float4*>(w + (long)n * ld + k);
+    v1 = *reinterpret_cast<const float4*>(w + (long)n * ld + k + 4);
+  }
+  uint4* dst = out + ((long)(kb * NB32 + nb) * NT) * 64 + lane;
+  if constexpr (NT == 3) {
+    const Split3 a = split3(v0), b = split3(v1);
+    dst[0] = make_uint4(a.hi.x, a.hi.y, b.hi.x, b.hi.y);
+    dst[64] = make_uint4(a.mid.x, a.mid.y, b.mid.x, b.mid.y);
+    dst[128] = make_uint4(a.lo.x, a.lo.y, b.lo.x, b.lo.y);
+  } else {
+    const bf16x4 a = to_bf16x4(v0), b = to_bf16x4(v1);
+    const uint2 ua = __builtin_bit_cast(uint2, a), ub = __builtin_bit_cast(uint2, b);
+    dst[0] = make_uint4(ua.x, ua.y, ub.x, ub.y);
+  }
+}
+
+template <int BN, int MODE, int PASSES, int D, bool FA2>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_wf_kernel(const float* __restrict__ x,
+                                                                 const uint4* __restrict__ wf, ConvEpi ep, int T,
+                                                                 int F, int C, int N, int P, int tiles_m,
+                                                                 int tiles_n) {
+  constexpr int NT = MODE == kSplit ? 3 : 1;
+  constexpr int TM = 2, TN = BN / 64, WN = BN / 2;
+  constexpr int ZR = PASSES * 32;                                  // an all-zero row behind the window
+  constexpr int AIMG = (ZR + 4) * 32;                              // bf16 elements per image
+  constexpr int S = 18 * TN;                                       // steps (tap, kk, j) per channel chunk
+  static_assert(S % D == 0 && D >= 2, "the fragment ring wraps at chunk boundaries");
+  __shared__ __attribute__((aligned(16))) __bf16 As[NT * AIMG];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm = wv >> 1, wn = wv & 1, r = lane & 31, h = lane >> 5;
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int p0 = (tile / tiles_n) * 128, n0 = (tile % tiles_n) * BN;
+  const int WR = 128 + 2 * F + 2;
+  const int srow = tid >> 3, piece = tid & 7;
+  const int nchunks = C / 32;
+
+  unsigned vbits[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int p = p0 + wm * 64 + i * 32 + r;
+    unsigned b = 0;
+    if (p < P) {
+      const int f = p % F, t = (p / F) % T;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int tt = t + tap / 3 - 1, ff = f + tap % 3 - 1;
+        if (tt >= 0 && tt < T && ff >= 0 && ff < F) b |= 1u << tap;
+      }
+    }
+    vbits[i] = b;
+  }
+
+  float4 ra[PASSES];
+  auto fetch_a = [&](int cc) {
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int wr = ps * 32 + srow;
+      const long q = (long)p0 - F - 1 + wr;
+      ra[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (wr < WR && q >= 0 && q < P) ra[ps] = *reinterpret_cast<const float4*>(x + q * C + cc * 32 + piece * 4);
+    }
+  };
+
+  // weight fragments: element offsets (in uint4) of this wave's n-blocks; a tile hanging over N re-reads the last
+  // block (its columns are dropped by the epilogue)
+  const int NB32 = (N + 31) >> 5, kb_tap = C >> 4;
+  int nbo[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int nb = (n0 + wn * WN + j * 32) >> 5;
+    nbo[j] = (nb < NB32 ? nb : NB32 - 1) * NT * 64 + lane;
+  }
+  const int kb_stride = NB32 * NT * 64;                            // uint4 per 16-k block
+  bf16x8 ring[D][NT];
+  auto issue = [&](int slot, int cc, int s) {                      // s = (tap * 2 + kk) * TN + j
+    const int j = s % TN, kk = (s / TN) & 1, tap = s / (2 * TN);
+    const uint4* pw = wf + (long)(tap * kb_tap + cc * 2 + kk) * kb_stride + nbo[j];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) ring[slot][c] = __builtin_bit_cast(bf16x8, pw[c * 64]);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
+
+  if (tid < 8) {
+#pragma unroll
+    for (int c = 0; c < NT; ++c) *reinterpret_cast<uint2*>(As + c * AIMG + ZR * 32 + tid * 4) = make_uint2(0u, 0u);
+  }
+  fetch_a(0);
+#pragma unroll
+  for (int s = 0; s < D - 1; ++s) issue(s, 0, s);
+
+  auto load_fa = [&](bf16x8 (&fa)[TM][NT], int tap, int kk) {
+    const int shift = (tap / 3) * F + tap % 3;                     // (F + 1) + (dt * F + df)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row = (vbits[i] >> tap) & 1u ? wm * 64 + i * 32 + r + shift : ZR;
+#pragma unroll
+      for (int c = 0; c < NT; ++c)
+        fa[i][c] = *reinterpret_cast<const bf16x8*>(As + c * AIMG + swz_off(row, kk * 2 + h));
+    }
+  };
+
+  for (int cc = 0; cc < nchunks; ++cc) {
+    __syncthreads();                                               // every wave is done with the previous window
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) halo_store<NT>(As, AIMG, ps * 32 + srow, piece, ra[ps]);
+    __syncthreads();
+    if (cc + 1 < nchunks) fetch_a(cc + 1);
+    // FA2: the activation fragments of the next k-block are read under this block's MFMAs (24 more registers)
+    bf16x8 fa[FA2 ? 2 : 1][TM][NT];
+    if (FA2) load_fa(fa[0], 0, 0);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const int j = s % TN, blk = s / TN;                          // blk = tap * 2 + kk
+      {                                                            // keep the ring D - 1 steps ahead
+        const int sn = s + D - 1;
+        if (sn < S) issue(sn % D, cc, sn);
+        else if (cc + 1 < nchunks) issue(sn % D, cc + 1, sn - S);
+      }
+      if (FA2) {
+        if (j == 0 && blk + 1 < 18) load_fa(fa[(blk + 1) & 1], (blk + 1) >> 1, (blk + 1) & 1);
+      } else if (j == 0) {
+        load_fa(fa[0], blk >> 1, blk & 1);
+      }
+      const int fs = FA2 ? (blk & 1) : 0;
+      if constexpr (NT == 3) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][j] = mfma_split(fa[fs][i], ring[s % D], acc[i][j]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][j] = mfma_bf16(fa[fs][i][0], ring[s % D][0], acc[i][j]);
+      }
+      // hipcc otherwise sinks every prefetch down to its first use (seen in the .s: one step of lookahead
+      // whatever D says); pinning the step boundaries keeps the loads D - 1 steps ahead of their MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int g = 0; g < 16; ++g)
+        ep(p0 + wm * 64 + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * h, n0 + wn * WN + j * 32 + r, acc[i][j][g]);
+}
+
+template <int BN, int MODE, int PASSES, int D, bool FA2>
+int launch_conv_halo_wf(const float* x, const void* wf, float* y, int B, int T, int F, int C, int N, int accumulate,
+                        hipStream_t st) {
+  const int P = B * T * F;
+  ConvEpi ep{y, P, N, accumulate};
+  const int tm = pe_cdiv(P, 128), tn = pe_cdiv(N, BN);
+  hipLaunchKernelGGL((conv3x3_halo_wf_kernel<BN, MODE, PASSES, D, FA2>), dim3(tm * tn), dim3(256), 0, st, x,
+                     reinterpret_cast<const uint4*>(wf), ep, T, F, C, N, P, tm, tn);
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+
 // which staged-window variant serves (F, N): 7 passes + a 128/192-wide tile, 10 passes + a 64-wide tile
 // (two workgroups per CU must fit the LDS), or 0 = use the implicit-GEMM kernel
 int conv_halo_passes(int F, int N) {
@@ -720,6 +905,56 @@ extern "C" int pe_conv3x3_fwd_bf16(const float* x, const float* w_packed, float*
 extern "C" int pe_conv3x3_fwd_x3(const float* x, const float* w_packed, float* y, int B, int T, int F, int C,
                                  int N, int accumulate, void* stream) {
   return conv3x3_fwd_impl<kSplit>(x, w_packed, y, B, T, F, C, N, accumulate, stream);
+}
+
+// ---- weights pre-packed as MFMA fragments (x3: three bf16 terms; bf16: one rounded term)
+extern "C" size_t pe_wfrag_bytes(int N, int K, int terms) {
+  if (N <= 0 || K <= 0 || (K & 15) || (terms != 1 && terms != 3)) return 0;
+  return (size_t)((N + 31) / 32) * (K / 16) * terms * 1024;
+}
+
+extern "C" int pe_wfrag_pack(const float* w, long ld, int N, int K, int terms, void* out, void* stream) {
+  if (!w || !out || N <= 0 || K <= 0 || ld < K) return PE_E_ARG;
+  if ((K & 15) || (ld & 3) || (terms != 1 && terms != 3)) return PE_E_UNSUPPORTED;
+  const long threads = (long)((N + 31) / 32) * (K / 16) * 64;
+  if (terms == 3)
+    hipLaunchKernelGGL(wfrag_pack_kernel<3>, dim3(pe_cdiv(threads, 256)), dim3(256), 0, pe_stream(stream), w, ld, N, K,
+                       reinterpret_cast<uint4*>(out));
+  else
+    hipLaunchKernelGGL(wfrag_pack_kernel<1>, dim3(pe_cdiv(threads, 256)), dim3(256), 0, pe_stream(stream), w, ld, N, K,
+                       reinterpret_cast<uint4*>(out));
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+
+extern "C" int pe_conv3x3_wf_supported(int F, int C, int N) {
+  return (C % 32) == 0 && conv_halo_passes(F, N) != 0 ? 1 : 0;
+}
+
+template <int MODE>
+static int conv3x3_fwd_wf_impl(const float* x, const void* wfrag, float* y, int B, int T, int F, int C, int N,
+                               int accumulate, void* stream) {
+  if (!x || !wfrag || !y || B <= 0 || T <= 0 || F <= 0 || C <= 0 || N <= 0) return PE_E_ARG;
+  if ((C % 32) != 0 || (long)B * T * F * (C > N ? C : N) >= (1L << 31)) return PE_E_UNSUPPORTED;
+  hipStream_t st = pe_stream(stream);
+  const int passes = conv_halo_passes(F, N);
+  if (passes == 10) return launch_conv_halo_wf<64, MODE, 10, 6, true>(x, wfrag, y, B, T, F, C, N, accumulate, st);
+  if (passes == 7) {
+    if (N % 192 == 0 && N % 128 != 0)
+      return launch_conv_halo_wf<192, MODE, 7, 3, false>(x, wfrag, y, B, T, F, C, N, accumulate, st);
+    return launch_conv_halo_wf<128, MODE, 7, 3, true>(x, wfrag, y, B, T, F, C, N, accumulate, st);
+  }
+  return PE_E_UNSUPPORTED;
+}
+
+extern "C" int pe_conv3x3_fwd_wf_x3(const float* x, const void* wfrag, float* y, int B, int T, int F, int C, int N,
+                                    int accumulate, void* stream) {
+  return conv3x3_fwd_wf_impl<kSplit>(x, wfrag, y, B, T, F, C, N, accumulate, stream);
+}
+
+extern "C" int pe_conv3x3_fwd_wf_bf16(const float* x, const void* wfrag, float* y, int B, int T, int F, int C, int N,
+                                      int accumulate, void* stream) {
+  return conv3x3_fwd_wf_impl<kBf16>(x, wfrag, y, B, T, F, C, N, accumulate, stream);
 }
 
 extern "C" size_t pe_conv3x3_wgrad_workspace_bytes(int B, int T, int F, int Cin, int Cout) {

@@ -200,30 +200,79 @@ def transpose2d(x, out=None):
 
 
 # ------------------------------------------------------------------ conv
+# x3 / bf16 modes: 3x3 weights are packed once per step into MFMA B-fragment order (three exact bf16 terms, or
+# one rounded term) and the halo kernel loads them straight from L2 into registers (csrc/conv.hip).
+CONV_WFRAG = os.environ.get("PE_CONV_WFRAG", "1") == "1"
+
+
+class PackedWeight:
+    """One packed 3x3 weight: ``fp32`` [N, 9*C] (native MFMA path, fallback shapes) and, in the x3 / bf16 modes,
+    ``frag`` = the same matrix as bf16 MFMA fragments (``terms`` = 3 exact terms or 1 rounded term)."""
+
+    def __init__(self, fp32, frag=None, terms=0):
+        self.fp32, self.frag, self.terms = fp32, frag, terms
+
+    @property
+    def shape(self):
+        return self.fp32.shape
+
+
+def wfrag_pack(w2d, terms):
+    """[N, K] float32 (K % 16 == 0) -> fragment-ordered bf16 terms (uint8 buffer)."""
+    N, K, ld = _rows2d(w2d, "w")
+    lib = _lib.load()
+    nbytes = lib.pe_wfrag_bytes(N, K, terms)
+    _chk(nbytes > 0, "wfrag_pack: K must be a multiple of 16 and terms 1 or 3")
+    out = torch.empty((nbytes,), dtype=torch.uint8, device=w2d.device)
+    _call("pe_wfrag_pack", w2d.data_ptr(), ld, N, K, int(terms), out.data_ptr(), _s())
+    return out
+
+
+def _mode_terms():
+    sfx = _nt_suffix()
+    return 3 if sfx == "_x3" else 1 if sfx == "_bf16" else 0
+
+
 def conv3x3_repack(w, want_fwd=True, want_dgrad=True):
-    """OIHW (Cout,Cin,3,3) -> (w_fwd [Cout, 9*Cin], w_dgrad [Cin, 9*Cout])."""
+    """OIHW (Cout,Cin,3,3) -> (w_fwd [Cout, 9*Cin], w_dgrad [Cin, 9*Cout]) as ``PackedWeight``s."""
     w = _dense(w, "w")
     _chk(w.dim() == 4 and w.shape[2:] == (3, 3), "conv3x3_repack: OIHW 3x3")
     co, ci = w.shape[0], w.shape[1]
     wf = torch.empty((co, 9 * ci), dtype=torch.float32, device=w.device) if want_fwd else None
     wd = torch.empty((ci, 9 * co), dtype=torch.float32, device=w.device) if want_dgrad else None
     _call("pe_conv3x3_repack", w.data_ptr(), _lib.ptr(wf), _lib.ptr(wd), co, ci, _s())
-    return wf, wd
+    terms = _mode_terms() if CONV_WFRAG else 0
+    out = []
+    for t in (wf, wd):
+        if t is None:
+            out.append(None)
+        elif terms and t.shape[1] % 16 == 0:
+            out.append(PackedWeight(t, wfrag_pack(t, terms), terms))
+        else:
+            out.append(PackedWeight(t))
+    return out[0], out[1]
 
 
 def conv3x3_fwd(x, w_packed, out=None, accumulate=False):
-    """x [B,T,F,C], w_packed [N, 9*C] -> y [B,T,F,N] (+= when accumulate)."""
+    """x [B,T,F,C], w_packed [N, 9*C] (tensor or PackedWeight) -> y [B,T,F,N] (+= when accumulate)."""
     x = _dense(x, "x")
-    w_packed = _dense(w_packed, "w_packed")
-    _chk(x.dim() == 4 and w_packed.dim() == 2, "conv3x3_fwd: ranks")
+    pw = w_packed if isinstance(w_packed, PackedWeight) else PackedWeight(w_packed)
+    w32 = _dense(pw.fp32, "w_packed")
+    _chk(x.dim() == 4 and w32.dim() == 2, "conv3x3_fwd: ranks")
     B, T, F, Cc = x.shape
-    N = w_packed.shape[0]
-    _chk(w_packed.shape[1] == 9 * Cc, "conv3x3_fwd: weight K")
+    N = w32.shape[0]
+    _chk(w32.shape[1] == 9 * Cc, "conv3x3_fwd: weight K")
     if out is None:
         _chk(not accumulate, "accumulate needs out")
         out = torch.empty((B, T, F, N), dtype=torch.float32, device=x.device)
     _chk(_dense(out, "out").shape == (B, T, F, N), "conv3x3_fwd: out shape")
-    _call("pe_conv3x3_fwd" + _nt_suffix(), x.data_ptr(), w_packed.data_ptr(), out.data_ptr(), B, T, F, Cc, N,
+    sfx = _nt_suffix()
+    if (pw.frag is not None and pw.terms == _mode_terms() and CONV_WFRAG
+            and _lib.load().pe_conv3x3_wf_supported(F, Cc, N)):
+        _call("pe_conv3x3_fwd_wf" + sfx, x.data_ptr(), pw.frag.data_ptr(), out.data_ptr(), B, T, F, Cc, N,
+              int(bool(accumulate)), _s(), work=2.0 * B * T * F * N * 9 * Cc)
+        return out
+    _call("pe_conv3x3_fwd" + sfx, x.data_ptr(), w32.data_ptr(), out.data_ptr(), B, T, F, Cc, N,
           int(bool(accumulate)), _s(), work=2.0 * B * T * F * N * 9 * Cc)
     return out
 

@@ -174,6 +174,45 @@ def test_conv3x3_fwd_dgrad_wgrad(hip_device, B, T, Fq, Ci, Co, fp32_mode, monkey
     close(nchw(ops.conv3x3_fwd(xd, wf, out=acc, accumulate=True)), ref_acc)
 
 
+def test_weight_fragment_pack_layout(hip_device):
+    """pe_wfrag_pack: fragment (kb, nb, term), lane 32 h + r  <->  w[32 nb + r][16 kb + 8 h .. + 7]; the three
+    terms are the exact truncation split (hi + mid + lo == w bit for bit), one term = RNE bf16."""
+    N, K = 70, 96                                            # N not a multiple of 32: the tail rows pack as zeros
+    w = rnd(N, K, seed=3) * torch.exp(rnd(N, K, seed=4) * 3)
+    for terms in (3, 1):
+        raw = ops.wfrag_pack(w.to(hip_device), terms).cpu()
+        frag = raw.view(torch.bfloat16).view(K // 16, 3, terms, 64, 8).float()        # [kb][nb][term][lane][8]
+        wpad = torch.zeros(96, K)
+        wpad[:N] = w
+        ref = wpad.view(3, 32, K // 16, 2, 8).permute(2, 0, 3, 1, 4).reshape(K // 16, 3, 64, 8)   # lane = 32 h + r
+        if terms == 3:
+            assert torch.equal(frag[:, :, 0] + frag[:, :, 1] + frag[:, :, 2], ref)
+            hi = (ref.view(torch.int32) & -65536).view(torch.float32)
+            assert torch.equal(frag[:, :, 0], hi)
+        else:
+            assert torch.equal(frag[:, :, 0], ref.to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize("B,T,Fq,Ci,Co", [(3, 16, 40, 128, 128), (2, 5, 20, 128, 192), (1, 3, 80, 64, 64),
+                                          (1, 6, 10, 192, 256), (2, 7, 40, 128, 64)])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_conv3x3_fragment_fed_kernel_is_bit_identical(hip_device, B, T, Fq, Ci, Co, bf16, monkeypatch):
+    """The kernel that takes its weight operands as pre-packed fragments from L2 issues the same MFMAs on the same
+    operand bits in the same order as the one that stages weight slabs through LDS: equal outputs, bit for bit."""
+    monkeypatch.setattr(ops, "FP32_MATMUL", "x3")
+    x = nhwc(rnd(B, Ci, T, Fq, seed=1)).to(hip_device)
+    w = rnd(Co, Ci, 3, 3, seed=2, scale=0.1).to(hip_device)
+    outs = {}
+    for frag in (True, False):
+        monkeypatch.setattr(ops, "CONV_WFRAG", frag)
+        with ops.matmul_bf16(bf16):
+            wf, wd = ops.conv3x3_repack(w)
+            assert (wf.frag is not None) == frag
+            y = ops.conv3x3_fwd(x, wf)
+            outs[frag] = (y, ops.conv3x3_fwd(y, wd))
+    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
+
+
 def test_conv3x3_first_layer(hip_device):
     B, T, Fq = 3, 17, 80
     mel = rnd(B, 1, Fq, T, seed=1)                          # (B,1,80,T) as the loader yields it
