@@ -92,6 +92,12 @@ int pe_gemm_nt_bf16(const float* A, long lda, const float* B, long ldb, float* C
  * below 2^-23 of each product, i.e. under the rounding of an fp32 product.  Same contract as pe_gemm_nt. */
 int pe_gemm_nt_x3(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
                   int K, const float* bias0, const float* bias1, int accumulate, void* stream);
+/* pe_gemm_nt_wf_*: the same product with B given as pe_wfrag_pack(B, ldb, N, K, terms) (see the convolution
+ * section): the weight operand comes from L2 in MFMA fragment order, only A is staged through LDS. */
+int pe_gemm_nt_wf_x3(const float* A, long lda, const void* wfrag, float* C, long ldc, int M, int N, int K,
+                     const float* bias0, const float* bias1, int accumulate, void* stream);
+int pe_gemm_nt_wf_bf16(const float* A, long lda, const void* wfrag, float* C, long ldc, int M, int N, int K,
+                       const float* bias0, const float* bias1, int accumulate, void* stream);
 size_t pe_gemm_tn_workspace_bytes(int M, int N, int K);
 int pe_gemm_tn(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
                int K, int accumulate, float* workspace, size_t workspace_bytes, void* stream);

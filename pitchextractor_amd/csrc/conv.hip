@@ -94,23 +94,6 @@ int launch_conv(const float* x, const float* wp, float* y, int B, int T, int F, 
 // operand for the exact three-term split, 1 for mixed precision.
 // PASSES = staged window rows / 32: 7 (F <= 47) for the wide tiles, 10 (F <= 95) for the 64-channel layers.
 
-__device__ __forceinline__ int swz_off(int row, int chunk) {        // in bf16 elements
-  return row * 32 + ((chunk ^ ((row >> 2) & 3)) << 3);
-}
-
-template <int NT>
-__device__ __forceinline__ void halo_store(__bf16* img, int img_elems, int row, int piece, const float4& v) {
-  const int off = swz_off(row, piece >> 1) + (piece & 1) * 4;
-  if constexpr (NT == 3) {
-    const Split3 sp = split3(v);
-    *reinterpret_cast<uint2*>(img + off) = sp.hi;
-    *reinterpret_cast<uint2*>(img + off + img_elems) = sp.mid;
-    *reinterpret_cast<uint2*>(img + off + 2 * img_elems) = sp.lo;
-  } else {
-    *reinterpret_cast<bf16x4*>(img + off) = to_bf16x4(v);
-  }
-}
-
 template <int BN, int MODE, int PASSES>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const float* __restrict__ x,
                                                               const float* __restrict__ wp, ConvEpi ep, int T, int F,

@@ -51,6 +51,127 @@ int launch_nt(const RowLoader& al, const RowLoader& bl, const StoreEpi& ep, int 
   return PE_OK;
 }
 
+// ---- NT with the B operand (weights) pre-packed as MFMA fragments (pe_wfrag_pack, conv.hip)
+// Same idea as conv3x3_halo_wf_kernel: the weight matrix is packed once per call into B-fragment order and every
+// wave pulls its fragments straight from L2 into a register ring, D steps ahead of the MFMAs; only the activation
+// tile goes through LDS (split into bf16 terms on the way in), double-buffered: ONE barrier per 32-k tile and no
+// weight split / weight LDS traffic in the loop.  Tile 128 x BN, waves 2 x 2, step = (kk, j) = 2 TM MFMA groups.
+template <int BN, int MODE, int D, bool FA2>
+__global__ __launch_bounds__(256, 2) void gemm_nt_wf_kernel(RowLoader al, const uint4* __restrict__ wf, StoreEpi ep,
+                                                            int N, int K, int tiles_m, int tiles_n) {
+  constexpr int NT = MODE == kSplit ? 3 : 1;
+  constexpr int TM = 2, TN = BN / 64, WN = BN / 2;
+  constexpr int AIMG = 128 * 32;                                   // bf16 elements per term image
+  constexpr int S = 2 * TN;                                        // steps (kk, j) per k-tile
+  static_assert(S % D == 0 && D >= 2, "the fragment ring wraps at k-tile boundaries");
+  __shared__ __attribute__((aligned(16))) __bf16 As[2 * NT * AIMG];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm = wv >> 1, wn = wv & 1, r = lane & 31, h = lane >> 5;
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (tile / tiles_n) * 128, n0 = (tile % tiles_n) * BN;
+  const int srow = tid >> 3, piece = tid & 7;
+  const int nk = (K + kBK - 1) / kBK, KB = K >> 4;
+  al.init(m0);
+
+  const int NB32 = (N + 31) >> 5;
+  int nbo[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int nb = (n0 + wn * WN + j * 32) >> 5;
+    nbo[j] = (nb < NB32 ? nb : NB32 - 1) * NT * 64 + lane;         // a tile hanging over N re-reads the last block
+  }
+  const int kb_stride = NB32 * NT * 64;
+  bf16x8 ring[D][NT];
+  auto issue = [&](int slot, int kt, int s) {                      // s = kk * TN + j
+    const int j = s % TN, kk = s / TN;
+    int kb = kt * 2 + kk;
+    kb = kb < KB ? kb : KB - 1;                                    // K % 32 == 16: the activation half-tile is zero
+    const uint4* pw = wf + (long)kb * kb_stride + nbo[j];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) ring[slot][c] = __builtin_bit_cast(bf16x8, pw[c * 64]);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
+
+  float4 ra[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ra[i] = al.load(i, 0);
+#pragma unroll
+  for (int s = 0; s < D - 1; ++s) issue(s, 0, s);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) halo_store<NT>(As, AIMG, i * 32 + srow, piece, ra[i]);
+  __syncthreads();
+
+  auto load_fa = [&](bf16x8 (&fa)[TM][NT], const __bf16* buf, int kk) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int c = 0; c < NT; ++c)
+        fa[i][c] = *reinterpret_cast<const bf16x8*>(buf + c * AIMG + swz_off(wm * 64 + i * 32 + r, kk * 2 + h));
+  };
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const __bf16* cur = As + (kt & 1) * NT * AIMG;
+    __bf16* nxt = As + ((kt + 1) & 1) * NT * AIMG;
+    if (kt + 1 < nk) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ra[i] = al.load(i, kt + 1);
+    }
+    bf16x8 fa[FA2 ? 2 : 1][TM][NT];
+    if (FA2) load_fa(fa[0], cur, 0);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const int j = s % TN, kk = s / TN;
+      {
+        const int sn = s + D - 1;
+        if (sn < S) issue(sn % D, kt, sn);
+        else if (kt + 1 < nk) issue(sn % D, kt + 1, sn - S);
+      }
+      if (FA2) {
+        if (j == 0 && kk == 0) load_fa(fa[1], cur, 1);
+      } else if (j == 0) {
+        load_fa(fa[0], cur, kk);
+      }
+      const int fs = FA2 ? kk : 0;
+      if constexpr (NT == 3) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][j] = mfma_split(fa[fs][i], ring[s % D], acc[i][j]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][j] = mfma_bf16(fa[fs][i][0], ring[s % D][0], acc[i][j]);
+      }
+      __builtin_amdgcn_sched_barrier(0);                           // keep the prefetches where they are (see conv.hip)
+    }
+    if (kt + 1 < nk) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) halo_store<NT>(nxt, AIMG, i * 32 + srow, piece, ra[i]);
+    }
+    __syncthreads();                                               // tile kt + 1 is complete; tile kt is free
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int g = 0; g < 16; ++g)
+        ep(m0 + wm * 64 + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * h, n0 + wn * WN + j * 32 + r, acc[i][j][g]);
+}
+
+template <int BN, int MODE, int D, bool FA2>
+int launch_nt_wf(const RowLoader& al, const void* wf, const StoreEpi& ep, int M, int N, int K, hipStream_t st) {
+  const int tm = pe_cdiv(M, 128), tn = pe_cdiv(N, BN);
+  hipLaunchKernelGGL((gemm_nt_wf_kernel<BN, MODE, D, FA2>), dim3(tm * tn), dim3(256), 0, st, al,
+                     reinterpret_cast<const uint4*>(wf), ep, N, K, tm, tn);
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+
 // ---- TN with split-K
 template <int BM, int BN, int MODE>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(KRowLoader<BM> al, KRowLoader<BN> bl, float* out,
@@ -165,6 +286,30 @@ extern "C" int pe_gemm_nt_bf16(const float* A, long lda, const float* B, long ld
 extern "C" int pe_gemm_nt_x3(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
                              int K, const float* bias0, const float* bias1, int accumulate, void* stream) {
   return gemm_nt_impl<kSplit>(A, lda, B, ldb, C, ldc, M, N, K, bias0, bias1, accumulate, stream);
+}
+
+template <int MODE>
+static int gemm_nt_wf_impl(const float* A, long lda, const void* wfrag, float* C, long ldc, int M, int N, int K,
+                           const float* bias0, const float* bias1, int accumulate, void* stream) {
+  if (!A || !wfrag || !C || M < 0 || N < 0 || K <= 0) return PE_E_ARG;
+  if (M == 0 || N == 0) return PE_OK;
+  if ((K & 15) || (lda & 3) || !aligned16(A)) return PE_E_UNSUPPORTED;
+  RowLoader al{A, lda, M, K, 0};
+  StoreEpi ep{C, ldc, bias0, bias1, M, N, accumulate};
+  hipStream_t st = pe_stream(stream);
+  if (N <= 64) return launch_nt_wf<64, MODE, 2, true>(al, wfrag, ep, M, N, K, st);
+  if (N % 192 == 0) return launch_nt_wf<192, MODE, 3, true>(al, wfrag, ep, M, N, K, st);
+  return launch_nt_wf<128, MODE, 4, true>(al, wfrag, ep, M, N, K, st);
+}
+
+extern "C" int pe_gemm_nt_wf_x3(const float* A, long lda, const void* wfrag, float* C, long ldc, int M, int N,
+                                int K, const float* bias0, const float* bias1, int accumulate, void* stream) {
+  return gemm_nt_wf_impl<kSplit>(A, lda, wfrag, C, ldc, M, N, K, bias0, bias1, accumulate, stream);
+}
+
+extern "C" int pe_gemm_nt_wf_bf16(const float* A, long lda, const void* wfrag, float* C, long ldc, int M, int N,
+                                  int K, const float* bias0, const float* bias1, int accumulate, void* stream) {
+  return gemm_nt_wf_impl<kBf16>(A, lda, wfrag, C, ldc, M, N, K, bias0, bias1, accumulate, stream);
 }
 
 extern "C" size_t pe_gemm_tn_workspace_bytes(int M, int N, int K) {

@@ -267,6 +267,27 @@ __device__ __forceinline__ f32x16 mfma_split(const bf16x8 (&a)[3], const bf16x8 
   return c;
 }
 
+// bf16-term images [row][32 k] with NO padding: 16-byte chunk c of a row sits at chunk c ^ ((row >> 2) & 3), which
+// keeps ds_read_b128 fragment reads (32 consecutive rows at any row offset) and the ds_write_b64 staging stores
+// conflict-free (MI355X_MICROARCH.md, LDS lane groups).
+__device__ __forceinline__ int swz_off(int row, int chunk) {        // in bf16 elements
+  return row * 32 + ((chunk ^ ((row >> 2) & 3)) << 3);
+}
+
+// 4 consecutive k (piece = float4 index 0..7 within the 32-k row) of one row -> NT term images
+template <int NT>
+__device__ __forceinline__ void halo_store(__bf16* img, int img_elems, int row, int piece, const float4& v) {
+  const int off = swz_off(row, piece >> 1) + (piece & 1) * 4;
+  if constexpr (NT == 3) {
+    const Split3 sp = split3(v);
+    *reinterpret_cast<uint2*>(img + off) = sp.hi;
+    *reinterpret_cast<uint2*>(img + off + img_elems) = sp.mid;
+    *reinterpret_cast<uint2*>(img + off + 2 * img_elems) = sp.lo;
+  } else {
+    *reinterpret_cast<bf16x4*>(img + off) = to_bf16x4(v);
+  }
+}
+
 template <class TL, class AL, class BL>
 __device__ __forceinline__ void nt_mainloop_split(AL& al, BL& bl, int K, float* As_f, float* Bs_f,
                                                   f32x16 (&acc)[TL::TM][TL::TN]) {

@@ -153,6 +153,11 @@ class matmul_bf16:
 
 
 # ------------------------------------------------------------------ GEMM
+# x3 / bf16 modes: the B operand of gemm_nt is always a (possibly transposed) weight matrix; it is packed per call
+# into MFMA fragment order (a few MB at most) and the kernel reads it from L2, so only A goes through LDS.
+GEMM_WFRAG = os.environ.get("PE_GEMM_WFRAG", "1") == "1"
+
+
 def gemm_nt(A, B, bias0=None, bias1=None, out=None, accumulate=False):
     """out[M,N] = A[M,K] @ B[N,K]^T + bias0 + bias1 (+ out)."""
     M, K, lda = _rows2d(A, "A")
@@ -166,7 +171,14 @@ def gemm_nt(A, B, bias0=None, bias1=None, out=None, accumulate=False):
     for b in (bias0, bias1):
         if b is not None:
             _chk(_dense(b, "bias").numel() == N, "bias size")
-    _call("pe_gemm_nt" + _nt_suffix(), A.data_ptr(), lda, B.data_ptr(), ldb, out.data_ptr(), ldc, M, N, K,
+    sfx = _nt_suffix()
+    if GEMM_WFRAG and sfx and K % 16 == 0 and N > 32 and M >= 128 and N * K <= (1 << 23) and lda % 4 == 0 \
+            and A.data_ptr() % 16 == 0:
+        wf = wfrag_pack(B, _mode_terms())
+        _call("pe_gemm_nt_wf" + sfx, A.data_ptr(), lda, wf.data_ptr(), out.data_ptr(), ldc, M, N, K,
+              _lib.ptr(bias0), _lib.ptr(bias1), int(bool(accumulate)), _s(), work=2.0 * M * N * K)
+        return out
+    _call("pe_gemm_nt" + sfx, A.data_ptr(), lda, B.data_ptr(), ldb, out.data_ptr(), ldc, M, N, K,
           _lib.ptr(bias0), _lib.ptr(bias1), int(bool(accumulate)), _s(), work=2.0 * M * N * K)
     return out
 

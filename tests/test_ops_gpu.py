@@ -53,6 +53,26 @@ def test_gemm_nt(hip_device, M, N, K, fp32_mode, monkeypatch):
     close(ops.gemm_nt(A.to(hip_device), B.to(hip_device), out=out, accumulate=True), ref2)
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 1536, 384), (1000, 64, 576), (257, 192, 96), (1024, 256, 640), (200, 360, 784),
+                                   (129, 100, 48)])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_gemm_nt_fragment_fed_kernel_is_bit_identical(hip_device, M, N, K, bf16, monkeypatch):
+    """B pre-packed as MFMA fragments and read from L2 vs B staged through LDS: the same MFMAs on the same operand
+    bits in the same k order -> equal outputs bit for bit (incl. strided A rows, N tails, K % 32 == 16)."""
+    monkeypatch.setattr(ops, "FP32_MATMUL", "x3")
+    A = rnd(M, K + 8, seed=1).to(hip_device)[:, 4:K + 4]        # row stride K + 8, 16-byte aligned start
+    B, b0 = rnd(N, K, seed=2).to(hip_device), rnd(N, seed=3).to(hip_device)
+    outs = {}
+    for frag in (True, False):
+        monkeypatch.setattr(ops, "GEMM_WFRAG", frag)
+        with ops.matmul_bf16(bf16):
+            acc = rnd(M, N, seed=5).to(hip_device)
+            outs[frag] = (ops.gemm_nt(A, B, bias0=b0), ops.gemm_nt(A, B, out=acc, accumulate=True))
+    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
+    if not bf16:
+        close(outs[True][0], A.cpu().double() @ B.cpu().double().T + b0.cpu().double())
+
+
 def bf16r(t):      # what the bf16 kernels see: operands rounded to bf16 (RNE), products exact in fp32
     return t.to(torch.bfloat16).to(torch.float64)
 
