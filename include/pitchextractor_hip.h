@@ -98,6 +98,11 @@ int pe_gemm_nt_wf_x3(const float* A, long lda, const void* wfrag, float* C, long
                      const float* bias0, const float* bias1, int accumulate, void* stream);
 int pe_gemm_nt_wf_bf16(const float* A, long lda, const void* wfrag, float* C, long ldc, int M, int N, int K,
                        const float* bias0, const float* bias1, int accumulate, void* stream);
+/* Diagnostic only (tools/ablate_gemm.py): pe_gemm_nt_wf_x3's 128 x 192 kernel with parts of its loop removed
+ * (mask bits: 1 weight loads, 2 A split + LDS store, 4 A global loads, 8 epilogue, 16 barrier, 32 A LDS reads);
+ * the output is meaningless for mask != 0. */
+int pe_gemm_nt_wf_ablate(int mask, const float* A, long lda, const void* wfrag, float* C, long ldc, int M, int N,
+                         int K, void* stream);
 size_t pe_gemm_tn_workspace_bytes(int M, int N, int K);
 int pe_gemm_tn(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
                int K, int accumulate, float* workspace, size_t workspace_bytes, void* stream);

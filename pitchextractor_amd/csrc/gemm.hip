@@ -56,7 +56,10 @@ int launch_nt(const RowLoader& al, const RowLoader& bl, const StoreEpi& ep, int 
 // wave pulls its fragments straight from L2 into a register ring, D steps ahead of the MFMAs; only the activation
 // tile goes through LDS (split into bf16 terms on the way in), double-buffered: ONE barrier per 32-k tile and no
 // weight split / weight LDS traffic in the loop.  Tile 128 x BN, waves 2 x 2, step = (kk, j) = 2 TM MFMA groups.
-template <int BN, int MODE, int D, bool FA2>
+// ABL: timing-only ablation mask of the diagnostic entry pe_gemm_nt_wf_ablate (results are wrong when non-zero):
+//   1 no weight-fragment loads in the loop, 2 no split + LDS store of the next A tile, 4 no global loads of A,
+//   8 no epilogue stores, 16 no per-k-tile barrier, 32 no A-fragment LDS reads in the loop
+template <int BN, int MODE, int D, bool FA2, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void gemm_nt_wf_kernel(RowLoader al, const uint4* __restrict__ wf, StoreEpi ep,
                                                             int N, int K, int tiles_m, int tiles_n) {
   constexpr int NT = MODE == kSplit ? 3 : 1;
@@ -119,24 +122,26 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_wf_kernel(RowLoader al, const 
   for (int kt = 0; kt < nk; ++kt) {
     const __bf16* cur = As + (kt & 1) * NT * AIMG;
     __bf16* nxt = As + ((kt + 1) & 1) * NT * AIMG;
-    if (kt + 1 < nk) {
+    if (kt + 1 < nk && !(ABL & 4)) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) ra[i] = al.load(i, kt + 1);
     }
     bf16x8 fa[FA2 ? 2 : 1][TM][NT];
-    if (FA2) load_fa(fa[0], cur, 0);
+    if (FA2 && (!(ABL & 32) || kt == 0)) load_fa(fa[0], cur, 0);
 #pragma unroll
     for (int s = 0; s < S; ++s) {
       const int j = s % TN, kk = s / TN;
-      {
+      if (!(ABL & 1)) {
         const int sn = s + D - 1;
         if (sn < S) issue(sn % D, kt, sn);
         else if (kt + 1 < nk) issue(sn % D, kt + 1, sn - S);
       }
-      if (FA2) {
-        if (j == 0 && kk == 0) load_fa(fa[1], cur, 1);
-      } else if (j == 0) {
-        load_fa(fa[0], cur, kk);
+      if (!(ABL & 32) || kt == 0) {
+        if (FA2) {
+          if (j == 0 && kk == 0) load_fa(fa[1], cur, 1);
+        } else if (j == 0) {
+          load_fa(fa[0], cur, kk);
+        }
       }
       const int fs = FA2 ? kk : 0;
       if constexpr (NT == 3) {
@@ -148,12 +153,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_wf_kernel(RowLoader al, const 
       }
       __builtin_amdgcn_sched_barrier(0);                           // keep the prefetches where they are (see conv.hip)
     }
-    if (kt + 1 < nk) {
+    if (kt + 1 < nk && !(ABL & 2)) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) halo_store<NT>(nxt, AIMG, i * 32 + srow, piece, ra[i]);
     }
-    __syncthreads();                                               // tile kt + 1 is complete; tile kt is free
+    if (!(ABL & 16)) __syncthreads();                              // tile kt + 1 is complete; tile kt is free
   }
+  if ((ABL & 8) && tiles_m > 0) return;                            // (never false: keeps the accumulators live)
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -163,10 +169,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_wf_kernel(RowLoader al, const 
         ep(m0 + wm * 64 + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * h, n0 + wn * WN + j * 32 + r, acc[i][j][g]);
 }
 
-template <int BN, int MODE, int D, bool FA2>
+template <int BN, int MODE, int D, bool FA2, int ABL = 0>
 int launch_nt_wf(const RowLoader& al, const void* wf, const StoreEpi& ep, int M, int N, int K, hipStream_t st) {
   const int tm = pe_cdiv(M, 128), tn = pe_cdiv(N, BN);
-  hipLaunchKernelGGL((gemm_nt_wf_kernel<BN, MODE, D, FA2>), dim3(tm * tn), dim3(256), 0, st, al,
+  hipLaunchKernelGGL((gemm_nt_wf_kernel<BN, MODE, D, FA2, ABL>), dim3(tm * tn), dim3(256), 0, st, al,
                      reinterpret_cast<const uint4*>(wf), ep, N, K, tm, tn);
   PE_LAUNCH_CHECK();
   return PE_OK;
@@ -300,6 +306,28 @@ static int gemm_nt_wf_impl(const float* A, long lda, const void* wfrag, float* C
   if (N <= 64) return launch_nt_wf<64, MODE, 2, true>(al, wfrag, ep, M, N, K, st);
   if (N % 192 == 0) return launch_nt_wf<192, MODE, 3, true>(al, wfrag, ep, M, N, K, st);
   return launch_nt_wf<128, MODE, 4, true>(al, wfrag, ep, M, N, K, st);
+}
+
+// Diagnostic (tools/ablate_gemm.py): the 128 x 192 x3 kernel with parts of its loop removed.  Timing only.
+extern "C" int pe_gemm_nt_wf_ablate(int mask, const float* A, long lda, const void* wfrag, float* C, long ldc, int M,
+                                    int N, int K, void* stream) {
+  if (!A || !wfrag || !C || M <= 0 || N <= 0 || K <= 0 || (K & 31) || (N % 192)) return PE_E_ARG;
+  RowLoader al{A, lda, M, K, 0};
+  StoreEpi ep{C, ldc, nullptr, nullptr, M, N, 0};
+  hipStream_t st = pe_stream(stream);
+  switch (mask) {
+    case 0: return launch_nt_wf<192, kSplit, 3, true, 0>(al, wfrag, ep, M, N, K, st);
+    case 1: return launch_nt_wf<192, kSplit, 3, true, 1>(al, wfrag, ep, M, N, K, st);
+    case 2: return launch_nt_wf<192, kSplit, 3, true, 2>(al, wfrag, ep, M, N, K, st);
+    case 6: return launch_nt_wf<192, kSplit, 3, true, 6>(al, wfrag, ep, M, N, K, st);
+    case 8: return launch_nt_wf<192, kSplit, 3, true, 8>(al, wfrag, ep, M, N, K, st);
+    case 16: return launch_nt_wf<192, kSplit, 3, true, 16>(al, wfrag, ep, M, N, K, st);
+    case 22: return launch_nt_wf<192, kSplit, 3, true, 22>(al, wfrag, ep, M, N, K, st);
+    case 32: return launch_nt_wf<192, kSplit, 3, true, 32>(al, wfrag, ep, M, N, K, st);
+    case 63: return launch_nt_wf<192, kSplit, 3, true, 63>(al, wfrag, ep, M, N, K, st);
+    case 55: return launch_nt_wf<192, kSplit, 3, true, 55>(al, wfrag, ep, M, N, K, st);
+  }
+  return PE_E_UNSUPPORTED;
 }
 
 extern "C" int pe_gemm_nt_wf_x3(const float* A, long lda, const void* wfrag, float* C, long ldc, int M, int N,

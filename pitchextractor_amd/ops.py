@@ -153,9 +153,11 @@ class matmul_bf16:
 
 
 # ------------------------------------------------------------------ GEMM
-# x3 / bf16 modes: the B operand of gemm_nt is always a (possibly transposed) weight matrix; it is packed per call
-# into MFMA fragment order (a few MB at most) and the kernel reads it from L2, so only A goes through LDS.
-GEMM_WFRAG = os.environ.get("PE_GEMM_WFRAG", "1") == "1"
+# x3 / bf16 modes, opt-in: pack gemm_nt's B operand (always a weight matrix here) into MFMA fragment order per call
+# and let the kernel read it from L2, so only A goes through LDS.  Bit-identical to the default kernel; measured at
+# 0.97x its speed on the LSTM projection shapes (tools/ab_gemm.py: the fragment loads cost what the LDS staging
+# did, tools/ablate_gemm.py), so it stays off -- unlike the convolution, where the window reuse makes it +9 %.
+GEMM_WFRAG = os.environ.get("PE_GEMM_WFRAG", "0") == "1"
 
 
 def gemm_nt(A, B, bias0=None, bias1=None, out=None, accumulate=False):
