@@ -27,6 +27,7 @@
 // as the exact three-term split of gemm_engine.h -- W hi/mid terms in registers, lo terms in LDS, operand
 // rows split per use -- 144 v_mfma_f32_32x32x16_bf16 per item and wave instead of 192 fp32 MFMAs of
 // twice the cycles.  Everything about the hand-off protocol is identical in both forms.
+#include <stdlib.h>
 #include "gemm_engine.h"
 
 namespace {
@@ -387,6 +388,238 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_kernel(const PFwdC
   }
 }
 
+// --------------------------------------------------------------------------------------- forward, overlapped
+// Same tiling, same hand-off protocol, same arithmetic (bit for bit) as lstm_fwd_persistent_kernel, but the part of
+// an item that is not MFMA work -- partial-tile exchange, gate functions, the stores of h / gates / c, the store
+// drain, the arrival, the wait for the next item's h rows and their fetch -- no longer runs between two MFMA
+// phases: item i-1's epilogue executes UNDER item i's MFMAs.  One iteration (item i = (step, half)):
+//
+//     barrier #1   As(i) [h_{t-1} rows] and red(i-1) [partial tiles of the previous item] are complete
+//     MFMA blocks 0 .. NB/2-1      ||  E(i-1): red + x-projection -> gates -> c, h;  h stored sc1, then gates, c
+//     drain (vmcnt 0), barrier #2, ONE lane: arrive(i-1)
+//     MFMA blocks NB/2 .. NB-2     ||  ONE lane polls the counter of item i+1 (= the arrivals of item i-1)
+//     barrier #3, every lane issues the sc1 loads of item i+1's h rows (in flight under the last block)
+//     MFMA block NB-1;  accumulators -> red(i)
+//     barrier #0   every wave has finished reading As(i);  h rows of item i+1 -> As
+//
+// The consumer of item i-1's h is item i+1 (same half, next step), so the hand-off has half an MFMA phase to
+// become visible and the fetch the other half to land.  LDS: As (50 KB) and red (68 KB) can no longer share
+// space; the W_hh lo terms that do not fit the register file next to them keep (NB - NBR) blocks in LDS.
+template <int H, int TERMS, int NBR_>
+__global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_v2_kernel(const PFwdCells cells, int B, int T, long ldy,
+                                                                        unsigned y_bytes, unsigned* sync) {
+  static_assert(TERMS == 3 || TERMS == 1, "bf16-term pipelines only");
+  constexpr int KQ = H / 4, KH = KQ / 2, NJ = H / 32;
+  constexpr int ASTR = H + 4, ROW4 = H / 4, NST = ROW4 / 8;
+  constexpr int NB = KH / 8;                          // 8-k blocks per lane
+  constexpr int NBR = TERMS == 3 ? NBR_ : NB;         // blocks whose lo term lives in registers
+  static_assert(H % 64 == 0, "H % 64 == 0");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                                   // [32][ASTR]
+  float* red = smem + 32 * ASTR;                      // [4][32][kRs]
+  uint4* wlo_lds = reinterpret_cast<uint4*>(smem + 32 * ASTR + 4 * 32 * kRs);   // [4][NB - NBR][256]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int nbt = (B + 63) / 64;
+  int jt, gidx;
+  group_of_block(NJ, jt, gidx);
+  const int bt = gidx % nbt, cell = gidx / nbt;
+  const int j0 = jt * 32, b0 = bt * 64;
+  const int rev = cells.reverse[cell];
+  float* y = cells.y[cell];
+  float* gates = cells.gates[cell];
+  float* cb = cells.c[cell];
+  unsigned* err = sync;
+  unsigned* ctr = sync + kCtrStride * (1 + (cell * nbt + bt) * 2);
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(y, 0, y_bytes, 0x00020000);
+
+  bf16x8 bwhm[4][NB][TERMS == 3 ? 2 : 1], bwlo[4][NBR > 0 ? NBR : 1];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float* src = cells.whh[cell] + (long)(g * H + j0 + r) * H + wv * KQ + hh * KH;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const float4 w0 = *reinterpret_cast<const float4*>(src + 8 * b);
+      const float4 w1 = *reinterpret_cast<const float4*>(src + 8 * b + 4);
+      if constexpr (TERMS == 3) {
+        bf16x8 t3[3];
+        split8(w0, w1, t3);
+        bwhm[g][b][0] = t3[0];
+        bwhm[g][b][1] = t3[1];
+        if (b < NBR) bwlo[g][b < NBR ? b : 0] = t3[2];
+        else wlo_lds[(g * (NB - NBR) + (b - NBR)) * 256 + tid] = __builtin_bit_cast(uint4, t3[2]);
+      } else {
+        bwhm[g][b][0] = round8(w0, w1);
+      }
+    }
+  }
+  const int prow = tid >> 3, pq = tid & 7;            // cell-update item: row prow, hidden units j0 + 4 pq .. +3
+  float4 creg[2];
+  creg[0] = creg[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 stage[NST];
+  float4 xp_prev[4], xp_cur[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) xp_prev[g] = xp_cur[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  auto item_row = [&](int i) -> long {                // (batch row of this thread's update item) * T + t, of item i
+    const int step = i >> 1, hf = i & 1;
+    const int t = rev ? T - 1 - step : step;
+    return (long)(b0 + 32 * hf + prow) * T + t;
+  };
+  auto load_xp = [&](float4 (&xp)[4], int i) {
+    const int pb = b0 + 32 * (i & 1) + prow;
+    const long pi = item_row(i);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      xp[g] = pb < B ? *reinterpret_cast<const float4*>(gates + pi * 4 * H + g * H + j0 + 4 * pq)
+                     : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto fetch_rows = [&](int i) {                      // sc1 loads of h_{t-1} rows of item i (its group has arrived)
+    const int step = i >> 1, hf = i & 1;
+    const int t = rev ? T - 1 - step : step, tp = rev ? t + 1 : t - 1;
+    const int brow = b0 + 32 * hf + (tid >> 3);
+    const unsigned base = ((unsigned)(brow * T + tp) * (unsigned)ldy + (unsigned)(tid & 7) * 4u) * 4u;
+#pragma unroll
+    for (int v = 0; v < NST; ++v)
+      stage[v] = brow < B ? load_sc1(yrs, base + (unsigned)v * 128u) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  // gate functions + state update of item i from its partial tiles (have_acc: step > 0) and x-projection
+  auto cell_update = [&](int i, int hf, const float4 (&xp)[4], bool have_acc) {
+    const int pb = b0 + 32 * hf + prow;
+    if (pb >= B) return;
+    const long pi = item_row(i);
+    float4 pre[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      pre[g] = xp[g];
+      if (have_acc) {
+        const float* rp = red + prow * kRs + g * 32 + 4 * pq;
+        const float4 p0 = *reinterpret_cast<const float4*>(rp);
+        const float4 p1 = *reinterpret_cast<const float4*>(rp + 32 * kRs);
+        const float4 p2 = *reinterpret_cast<const float4*>(rp + 2 * 32 * kRs);
+        const float4 p3 = *reinterpret_cast<const float4*>(rp + 3 * 32 * kRs);
+        pre[g].x = ((p0.x + p1.x) + (p2.x + p3.x)) + xp[g].x;
+        pre[g].y = ((p0.y + p1.y) + (p2.y + p3.y)) + xp[g].y;
+        pre[g].z = ((p0.z + p1.z) + (p2.z + p3.z)) + xp[g].z;
+        pre[g].w = ((p0.w + p1.w) + (p2.w + p3.w)) + xp[g].w;
+      }
+    }
+    const float4 gi = make_float4(sigm(pre[0].x), sigm(pre[0].y), sigm(pre[0].z), sigm(pre[0].w));
+    const float4 gf = make_float4(sigm(pre[1].x), sigm(pre[1].y), sigm(pre[1].z), sigm(pre[1].w));
+    const float4 gg = make_float4(tanh_fast(pre[2].x), tanh_fast(pre[2].y), tanh_fast(pre[2].z), tanh_fast(pre[2].w));
+    const float4 go = make_float4(sigm(pre[3].x), sigm(pre[3].y), sigm(pre[3].z), sigm(pre[3].w));
+    float4 cn;
+    cn.x = gf.x * creg[hf].x + gi.x * gg.x;
+    cn.y = gf.y * creg[hf].y + gi.y * gg.y;
+    cn.z = gf.z * creg[hf].z + gi.z * gg.z;
+    cn.w = gf.w * creg[hf].w + gi.w * gg.w;
+    creg[hf] = cn;
+    const float4 hv = make_float4(go.x * tanh_fast(cn.x), go.y * tanh_fast(cn.y), go.z * tanh_fast(cn.z),
+                                  go.w * tanh_fast(cn.w));
+    store_sc1(yrs, (unsigned)((pi * ldy + j0 + 4 * pq) * 4), hv);          // h first: the group waits for it
+    float* gp = gates + pi * 4 * H + j0 + 4 * pq;
+    *reinterpret_cast<float4*>(gp) = gi;
+    *reinterpret_cast<float4*>(gp + H) = gf;
+    *reinterpret_cast<float4*>(gp + 2 * H) = gg;
+    *reinterpret_cast<float4*>(gp + 3 * H) = go;
+    *reinterpret_cast<float4*>(cb + pi * H + j0 + 4 * pq) = cn;
+  };
+
+  const int nitems = 2 * T;
+  f32x16 acc[4];
+  for (int step = 0; step < T; ++step) {
+#pragma unroll
+   for (int hf = 0; hf < 2; ++hf) {                    // unrolled: creg[hf] / counter halves are static
+    const int i = 2 * step + hf;
+    // ---- barrier #1 has been passed (end of the previous iteration): As(i), red(i-1) are complete
+    load_xp(xp_cur, i);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[g][q] = 0.f;
+    const float* asrc = As + r * ASTR + wv * KQ + hh * KH;
+    auto mfma_block = [&](int b) {
+      const float4 a0 = *reinterpret_cast<const float4*>(asrc + 8 * b);
+      const float4 a1 = *reinterpret_cast<const float4*>(asrc + 8 * b + 4);
+      if constexpr (TERMS == 3) {
+        bf16x8 fa[3];
+        split8(a0, a1, fa);
+        bf16x8 wl[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          wl[g] = b < NBR ? bwlo[g][b < NBR ? b : 0]
+                          : __builtin_bit_cast(bf16x8, wlo_lds[(g * (NB - NBR) + (b - NBR)) * 256 + tid]);
+#pragma unroll
+        for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            acc[g] = mfma_bf16(kTb[t6] == 2 ? wl[g] : bwhm[g][b][kTb[t6]], fa[kTa[t6]], acc[g]);
+      } else {
+        const bf16x8 fa = round8(a0, a1);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = mfma_bf16(bwhm[g][b][0], fa, acc[g]);
+      }
+    };
+    // ---- first half of the MFMAs, with the previous item's epilogue underneath
+    if (step > 0) {
+#pragma unroll
+      for (int b = 0; b < NB / 2; ++b) mfma_block(b);
+    }
+    if (i > 0) cell_update(i - 1, hf ^ 1, xp_prev, (i - 1) >= 2);
+    // ---- arrive(i-1): every storing wave drains, workgroup barrier #2, one relaxed agent-scope add
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (i > 0 && threadIdx.x == 0)
+      __hip_atomic_fetch_add(ctr + kCtrStride * (hf ^ 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ---- second half; one lane waits for the next item's group meanwhile
+    if (step > 0) {
+#pragma unroll
+      for (int b = NB / 2; b < NB - 1; ++b) mfma_block(b);
+    }
+    const int in = i + 1;
+    const bool want_fetch = in < nitems && (in >> 1) > 0;
+    if (want_fetch && threadIdx.x == 0) {
+      unsigned* c = ctr + kCtrStride * (in & 1);
+      const unsigned target = (unsigned)(NJ * (in >> 1));
+      unsigned spins = 0;
+      while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 63u) == 0u) {
+          if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+          if (spins > kSpinLimit) {
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __syncthreads();                                  // #3: the poll result reaches every wave
+    if (want_fetch) fetch_rows(in);
+    if (step > 0) mfma_block(NB - 1);
+    // ---- accumulators -> red(i); As(i) is free once every wave is here
+    if (step > 0) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+          *reinterpret_cast<float4*>(red + (wv * 32 + r) * kRs + g * 32 + 8 * q4 + 4 * hh) =
+              make_float4(acc[g][4 * q4], acc[g][4 * q4 + 1], acc[g][4 * q4 + 2], acc[g][4 * q4 + 3]);
+    }
+    __syncthreads();                                  // #0
+    if (want_fetch) {
+      float* adst = As + (tid >> 3) * ASTR + (tid & 7) * 4;
+#pragma unroll
+      for (int v = 0; v < NST; ++v) *reinterpret_cast<float4*>(adst + 32 * v) = stage[v];
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) xp_prev[g] = xp_cur[g];
+    __syncthreads();                                  // #1 of the next iteration
+   }
+  }
+  cell_update(nitems - 1, 1, xp_prev, (nitems - 1) >= 2);
+}
+
 // --------------------------------------------------------------------------------------- backward
 // dh_t = dY_t + dgates_{t+1} . W_hh  (K = 4H: wave w owns gate block w; each lane half takes H/2
 // contiguous k, streamed through LDS in chunks of CH per lane).  W_hh^T rows j0 + r stay in registers.
@@ -670,6 +903,34 @@ int launch_fwd(const PFwdCells& cells, int grid, int B, int T, long ldy, unsigne
   return PE_OK;
 }
 
+template <int H, int TERMS, int NBR>
+constexpr size_t fwd_v2_lds() {
+  constexpr int NB = H / 64, NBL = TERMS == 3 ? NB - NBR : 0;
+  return (size_t)(32 * (H + 4) + 4 * 32 * kRs) * sizeof(float) + (size_t)4 * NBL * 256 * 16;
+}
+
+template <int H, int TERMS, int NBR>
+int launch_fwd_v2(const PFwdCells& cells, int grid, int B, int T, long ldy, unsigned* sync, hipStream_t st) {
+  static_assert(fwd_v2_lds<H, TERMS, NBR>() <= 160 * 1024, "LDS budget");
+  static bool attr = false;
+  if (!attr) {
+    PE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_persistent_v2_kernel<H, TERMS, NBR>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_v2_lds<H, TERMS, NBR>()));
+    attr = true;
+  }
+  const unsigned y_bytes = (unsigned)((size_t)B * T * ldy * sizeof(float));
+  hipLaunchKernelGGL((lstm_fwd_persistent_v2_kernel<H, TERMS, NBR>), dim3(grid), dim3(256),
+                     (fwd_v2_lds<H, TERMS, NBR>()), st, cells, B, T, ldy, y_bytes, sync);
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+
+// PE_LSTM_V1=1 selects the non-overlapped kernels (A/B timing, tools/bench_lstm.py)
+bool lstm_use_v2() {
+  static const bool v2 = !(getenv("PE_LSTM_V1") && getenv("PE_LSTM_V1")[0] == '1');
+  return v2;
+}
+
 template <int H, int X3>
 int launch_bwd(const PBwdCells& cells, int grid, int B, int T, long lddy, unsigned* sync, hipStream_t st) {
   static bool attr = false;
@@ -718,6 +979,12 @@ static int lstm_fwd_persistent_impl(int terms, int ncells, const float* const* w
   // word 0 is the sticky error flag (cleared only by the owner of the buffer); counters start at line 1
   PE_CHECK_HIP(hipMemsetAsync(sync + kCtrStride, 0, pe_lstm_persistent_sync_bytes(ncells, B) - kCtrStride * 4, st));
   const int grid = ncells * ((B + 63) / 64) * (H / 32);
+  if (lstm_use_v2() && terms != 0) {
+    if (H == 64) return terms == 3 ? launch_fwd_v2<64, 3, 1>(cells, grid, B, T, ldy, sync, st)
+                                   : launch_fwd_v2<64, 1, 1>(cells, grid, B, T, ldy, sync, st);
+    if (H == 384) return terms == 3 ? launch_fwd_v2<384, 3, 4>(cells, grid, B, T, ldy, sync, st)
+                                    : launch_fwd_v2<384, 1, 6>(cells, grid, B, T, ldy, sync, st);
+  }
   switch (H) {                                   // the split form needs H % 64 == 0; other sizes stay native
     case 32: return launch_fwd<32, 0>(cells, grid, B, T, ldy, sync, st);
     case 64: return terms == 3 ? launch_fwd<64, 3>(cells, grid, B, T, ldy, sync, st)
