@@ -392,27 +392,50 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_kernel(const PFwdC
 // Same tiling, same hand-off protocol, same arithmetic (bit for bit) as lstm_fwd_persistent_kernel, but the part of
 // an item that is not MFMA work -- partial-tile exchange, gate functions, the stores of h / gates / c, the store
 // drain, the arrival, the wait for the next item's h rows and their fetch -- no longer runs between two MFMA
-// phases: item i-1's epilogue executes UNDER item i's MFMAs.  One iteration (item i = (step, half)):
+// phases: item i-1's epilogue executes UNDER item i's MFMAs.  One iteration (item i = (step, half), step >= 1):
 //
 //     barrier #1   As(i) [h_{t-1} rows] and red(i-1) [partial tiles of the previous item] are complete
-//     MFMA blocks 0 .. NB/2-1      ||  E(i-1): red + x-projection -> gates -> c, h;  h stored sc1, then gates, c
-//     drain (vmcnt 0), barrier #2, ONE lane: arrive(i-1)
-//     MFMA blocks NB/2 .. NB-2     ||  ONE lane polls the counter of item i+1 (= the arrivals of item i-1)
+//     MFMA blocks 0 .. NB/2-1  interleaved with  E(i-1): red + x-projection -> gates -> c, h;  h stored sc1 FIRST,
+//                                                 then gates, c;  s_waitcnt vmcnt(5) = the h store has completed
+//     barrier #2, ONE lane: arrive(i-1)
+//     MFMA blocks NB/2 .. NB-2;  ONE lane polls the counter of item i+1 (= the arrivals of item i-1)
 //     barrier #3, every lane issues the sc1 loads of item i+1's h rows (in flight under the last block)
 //     MFMA block NB-1;  accumulators -> red(i)
 //     barrier #0   every wave has finished reading As(i);  h rows of item i+1 -> As
 //
+// A wave issues in order, so "under the MFMAs" has to be literal: the epilogue's VALU / LDS / memory instructions
+// are spread between the MFMAs of the first half by sched_group_barrier (one MFMA, then a few of the others).
+// The region is kept branch-free for that: step 0 (no recurrent input) is peeled, rows beyond B are handled by
+// the buffer range check (loads return 0, stores are dropped) instead of exec-masked branches.
 // The consumer of item i-1's h is item i+1 (same half, next step), so the hand-off has half an MFMA phase to
 // become visible and the fetch the other half to land.  LDS: As (50 KB) and red (68 KB) can no longer share
 // space; the W_hh lo terms that do not fit the register file next to them keep (NB - NBR) blocks in LDS.
-template <int H, int TERMS, int NBR_>
+// diagnostic stamps (PE_LSTM_STAMP=1, tools/stamp_lstm.py): s_memtime around the regions of an iteration, summed per
+// workgroup by wave 0 into words [2048 + 16 * block, +16) of the sync buffer.  Never active in the product build.
+__device__ __forceinline__ unsigned long long stamp_now() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define PE_STAMP(k)                                         \
+  if constexpr (STAMP) {                                    \
+    const unsigned long long _n = stamp_now();              \
+    st_acc[k] += _n - st_last;                              \
+    st_last = _n;                                           \
+  }
+
+template <int H, int TERMS, int NBR_, bool STAMP = false>
 __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_v2_kernel(const PFwdCells cells, int B, int T, long ldy,
-                                                                        unsigned y_bytes, unsigned* sync) {
+                                                                        unsigned y_bytes, unsigned g_bytes,
+                                                                        unsigned c_bytes, unsigned* sync) {
   static_assert(TERMS == 3 || TERMS == 1, "bf16-term pipelines only");
   constexpr int KQ = H / 4, KH = KQ / 2, NJ = H / 32;
   constexpr int ASTR = H + 4, ROW4 = H / 4, NST = ROW4 / 8;
   constexpr int NB = KH / 8;                          // 8-k blocks per lane
   constexpr int NBR = TERMS == 3 ? NBR_ : NB;         // blocks whose lo term lives in registers
+  constexpr int NB1 = NB / 2;                         // blocks of the first half (epilogue underneath)
   static_assert(H % 64 == 0, "H % 64 == 0");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                                   // [32][ASTR]
@@ -426,12 +449,11 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_v2_kernel(const PF
   const int bt = gidx % nbt, cell = gidx / nbt;
   const int j0 = jt * 32, b0 = bt * 64;
   const int rev = cells.reverse[cell];
-  float* y = cells.y[cell];
-  float* gates = cells.gates[cell];
-  float* cb = cells.c[cell];
   unsigned* err = sync;
   unsigned* ctr = sync + kCtrStride * (1 + (cell * nbt + bt) * 2);
-  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(y, 0, y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(cells.y[cell], 0, y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(cells.gates[cell], 0, g_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(cells.c[cell], 0, c_bytes, 0x00020000);
 
   bf16x8 bwhm[4][NB][TERMS == 3 ? 2 : 1], bwlo[4][NBR > 0 ? NBR : 1];
 #pragma unroll
@@ -458,51 +480,52 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_v2_kernel(const PF
   creg[0] = creg[1] = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 stage[NST];
   float4 xp_prev[4], xp_cur[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) xp_prev[g] = xp_cur[g] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  auto item_row = [&](int i) -> long {                // (batch row of this thread's update item) * T + t, of item i
-    const int step = i >> 1, hf = i & 1;
+  // element (batch row of this thread's update item, time) of item (step, hf); 0x7fffffff past the batch: every
+  // byte offset formed from it lies outside its buffer (loads give 0, stores are dropped; 32-bit wrap is harmless
+  // because the descriptors' sizes are far below 2^31 elements -- checked by the host)
+  auto item_elem = [&](int step, int hf) -> unsigned {
+    const int pb = b0 + 32 * hf + prow;
     const int t = rev ? T - 1 - step : step;
-    return (long)(b0 + 32 * hf + prow) * T + t;
+    return pb < B ? (unsigned)(pb * T + t) : 0x7fffffffu;
   };
-  auto load_xp = [&](float4 (&xp)[4], int i) {
-    const int pb = b0 + 32 * (i & 1) + prow;
-    const long pi = item_row(i);
+  auto oob = [&](unsigned e, unsigned off) -> unsigned { return e == 0x7fffffffu ? 0xfffffff0u : off; };
+  auto load_xp = [&](float4 (&xp)[4], int step, int hf) {
+    const unsigned e = item_elem(step, hf);
+    const unsigned base = oob(e, (e * (unsigned)(4 * H) + (unsigned)(j0 + 4 * pq)) * 4u);
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-      xp[g] = pb < B ? *reinterpret_cast<const float4*>(gates + pi * 4 * H + g * H + j0 + 4 * pq)
-                     : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int g = 0; g < 4; ++g) {
+      const u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(grs, base, (unsigned)(g * H * 4), 0);
+      xp[g] = make_float4(__uint_as_float(d.x), __uint_as_float(d.y), __uint_as_float(d.z), __uint_as_float(d.w));
+    }
   };
-  auto fetch_rows = [&](int i) {                      // sc1 loads of h_{t-1} rows of item i (its group has arrived)
-    const int step = i >> 1, hf = i & 1;
+  auto fetch_rows = [&](int step, int hf) {           // sc1 loads of h_{t-1} rows of item (step, hf): its group arrived
     const int t = rev ? T - 1 - step : step, tp = rev ? t + 1 : t - 1;
     const int brow = b0 + 32 * hf + (tid >> 3);
-    const unsigned base = ((unsigned)(brow * T + tp) * (unsigned)ldy + (unsigned)(tid & 7) * 4u) * 4u;
+    const unsigned base = brow < B ? ((unsigned)(brow * T + tp) * (unsigned)ldy + (unsigned)(tid & 7) * 4u) * 4u
+                                   : 0xfffffff0u;
 #pragma unroll
-    for (int v = 0; v < NST; ++v)
-      stage[v] = brow < B ? load_sc1(yrs, base + (unsigned)v * 128u) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int v = 0; v < NST; ++v) stage[v] = load_sc1(yrs, base + (brow < B ? (unsigned)v * 128u : 0u));
   };
-  // gate functions + state update of item i from its partial tiles (have_acc: step > 0) and x-projection
-  auto cell_update = [&](int i, int hf, const float4 (&xp)[4], bool have_acc) {
-    const int pb = b0 + 32 * hf + prow;
-    if (pb >= B) return;
-    const long pi = item_row(i);
+  auto store4 = [&](__amdgpu_buffer_rsrc_t rs, unsigned off, unsigned soff, const float4& v) {
+    const u32x4 d = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(d, rs, off, soff, 0);
+  };
+  // gate functions + state update of item (step, hf) from its partial tiles in red and its x-projection; branch-free
+  auto cell_update = [&](int step, int hf, const float4 (&xp)[4]) {
+    const unsigned e = item_elem(step, hf);
     float4 pre[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      pre[g] = xp[g];
-      if (have_acc) {
-        const float* rp = red + prow * kRs + g * 32 + 4 * pq;
-        const float4 p0 = *reinterpret_cast<const float4*>(rp);
-        const float4 p1 = *reinterpret_cast<const float4*>(rp + 32 * kRs);
-        const float4 p2 = *reinterpret_cast<const float4*>(rp + 2 * 32 * kRs);
-        const float4 p3 = *reinterpret_cast<const float4*>(rp + 3 * 32 * kRs);
-        pre[g].x = ((p0.x + p1.x) + (p2.x + p3.x)) + xp[g].x;
-        pre[g].y = ((p0.y + p1.y) + (p2.y + p3.y)) + xp[g].y;
-        pre[g].z = ((p0.z + p1.z) + (p2.z + p3.z)) + xp[g].z;
-        pre[g].w = ((p0.w + p1.w) + (p2.w + p3.w)) + xp[g].w;
-      }
+      const float* rp = red + prow * kRs + g * 32 + 4 * pq;
+      const float4 p0 = *reinterpret_cast<const float4*>(rp);
+      const float4 p1 = *reinterpret_cast<const float4*>(rp + 32 * kRs);
+      const float4 p2 = *reinterpret_cast<const float4*>(rp + 2 * 32 * kRs);
+      const float4 p3 = *reinterpret_cast<const float4*>(rp + 3 * 32 * kRs);
+      pre[g].x = ((p0.x + p1.x) + (p2.x + p3.x)) + xp[g].x;
+      pre[g].y = ((p0.y + p1.y) + (p2.y + p3.y)) + xp[g].y;
+      pre[g].z = ((p0.z + p1.z) + (p2.z + p3.z)) + xp[g].z;
+      pre[g].w = ((p0.w + p1.w) + (p2.w + p3.w)) + xp[g].w;
     }
     const float4 gi = make_float4(sigm(pre[0].x), sigm(pre[0].y), sigm(pre[0].z), sigm(pre[0].w));
     const float4 gf = make_float4(sigm(pre[1].x), sigm(pre[1].y), sigm(pre[1].z), sigm(pre[1].w));
@@ -516,71 +539,19 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_v2_kernel(const PF
     creg[hf] = cn;
     const float4 hv = make_float4(go.x * tanh_fast(cn.x), go.y * tanh_fast(cn.y), go.z * tanh_fast(cn.z),
                                   go.w * tanh_fast(cn.w));
-    store_sc1(yrs, (unsigned)((pi * ldy + j0 + 4 * pq) * 4), hv);          // h first: the group waits for it
-    float* gp = gates + pi * 4 * H + j0 + 4 * pq;
-    *reinterpret_cast<float4*>(gp) = gi;
-    *reinterpret_cast<float4*>(gp + H) = gf;
-    *reinterpret_cast<float4*>(gp + 2 * H) = gg;
-    *reinterpret_cast<float4*>(gp + 3 * H) = go;
-    *reinterpret_cast<float4*>(cb + pi * H + j0 + 4 * pq) = cn;
+    // h first and write-through: it is what the group waits for; the five stores behind it need not have
+    // completed when this workgroup arrives (vmcnt counts in order)
+    store_sc1(yrs, oob(e, (e * (unsigned)ldy + (unsigned)(j0 + 4 * pq)) * 4u), hv);
+    const unsigned gb = oob(e, (e * (unsigned)(4 * H) + (unsigned)(j0 + 4 * pq)) * 4u);
+    store4(grs, gb, 0u, gi);
+    store4(grs, gb, (unsigned)(H * 4), gf);
+    store4(grs, gb, (unsigned)(2 * H * 4), gg);
+    store4(grs, gb, (unsigned)(3 * H * 4), go);
+    store4(crs, oob(e, (e * (unsigned)H + (unsigned)(j0 + 4 * pq)) * 4u), 0u, cn);
   };
-
-  const int nitems = 2 * T;
-  f32x16 acc[4];
-  for (int step = 0; step < T; ++step) {
-#pragma unroll
-   for (int hf = 0; hf < 2; ++hf) {                    // unrolled: creg[hf] / counter halves are static
-    const int i = 2 * step + hf;
-    // ---- barrier #1 has been passed (end of the previous iteration): As(i), red(i-1) are complete
-    load_xp(xp_cur, i);
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[g][q] = 0.f;
-    const float* asrc = As + r * ASTR + wv * KQ + hh * KH;
-    auto mfma_block = [&](int b) {
-      const float4 a0 = *reinterpret_cast<const float4*>(asrc + 8 * b);
-      const float4 a1 = *reinterpret_cast<const float4*>(asrc + 8 * b + 4);
-      if constexpr (TERMS == 3) {
-        bf16x8 fa[3];
-        split8(a0, a1, fa);
-        bf16x8 wl[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          wl[g] = b < NBR ? bwlo[g][b < NBR ? b : 0]
-                          : __builtin_bit_cast(bf16x8, wlo_lds[(g * (NB - NBR) + (b - NBR)) * 256 + tid]);
-#pragma unroll
-        for (int t6 = 0; t6 < 6; ++t6)
-#pragma unroll
-          for (int g = 0; g < 4; ++g)
-            acc[g] = mfma_bf16(kTb[t6] == 2 ? wl[g] : bwhm[g][b][kTb[t6]], fa[kTa[t6]], acc[g]);
-      } else {
-        const bf16x8 fa = round8(a0, a1);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] = mfma_bf16(bwhm[g][b][0], fa, acc[g]);
-      }
-    };
-    // ---- first half of the MFMAs, with the previous item's epilogue underneath
-    if (step > 0) {
-#pragma unroll
-      for (int b = 0; b < NB / 2; ++b) mfma_block(b);
-    }
-    if (i > 0) cell_update(i - 1, hf ^ 1, xp_prev, (i - 1) >= 2);
-    // ---- arrive(i-1): every storing wave drains, workgroup barrier #2, one relaxed agent-scope add
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (i > 0 && threadIdx.x == 0)
-      __hip_atomic_fetch_add(ctr + kCtrStride * (hf ^ 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // ---- second half; one lane waits for the next item's group meanwhile
-    if (step > 0) {
-#pragma unroll
-      for (int b = NB / 2; b < NB - 1; ++b) mfma_block(b);
-    }
-    const int in = i + 1;
-    const bool want_fetch = in < nitems && (in >> 1) > 0;
-    if (want_fetch && threadIdx.x == 0) {
-      unsigned* c = ctr + kCtrStride * (in & 1);
-      const unsigned target = (unsigned)(NJ * (in >> 1));
+  auto poll = [&](int half, unsigned target) {         // ONE lane; relaxed sc1 polls, bounded
+    if (threadIdx.x == 0) {
+      unsigned* c = ctr + kCtrStride * half;
       unsigned spins = 0;
       while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(1);
@@ -594,30 +565,126 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_v2_kernel(const PF
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    __syncthreads();                                  // #3: the poll result reaches every wave
-    if (want_fetch) fetch_rows(in);
-    if (step > 0) mfma_block(NB - 1);
-    // ---- accumulators -> red(i); As(i) is free once every wave is here
-    if (step > 0) {
+  };
+  auto arrive = [&](int half) {
+    if (threadIdx.x == 0)
+      __hip_atomic_fetch_add(ctr + kCtrStride * half, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto commit_rows = [&]() {
+    float* adst = As + (tid >> 3) * ASTR + (tid & 7) * 4;
+#pragma unroll
+    for (int v = 0; v < NST; ++v) *reinterpret_cast<float4*>(adst + 32 * v) = stage[v];
+  };
+
+  // ---- step 0 (h_{-1} = 0: no recurrent product).  Item (0,0) completes here; item (0,1) is left pending with
+  // all-zero partial tiles so that the steady-state loop needs no special case.
+  for (int z = tid; z < 4 * 32 * kRs / 4; z += 256) reinterpret_cast<float4*>(red)[z] = make_float4(0.f, 0.f, 0.f, 0.f);
+  load_xp(xp_prev, 0, 0);
+  __syncthreads();
+  cell_update(0, 0, xp_prev);
+  asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  __syncthreads();
+  arrive(0);
+  load_xp(xp_prev, 0, 1);
+  if (T > 1) {
+    poll(0, (unsigned)NJ);
+    __syncthreads();
+    fetch_rows(1, 0);
+    commit_rows();
+    __syncthreads();
+  }
+
+  f32x16 acc[4];
+  const float* asrc = As + r * ASTR + wv * KQ + hh * KH;
+  auto mfma_block = [&](int b) {
+    const float4 a0 = *reinterpret_cast<const float4*>(asrc + 8 * b);
+    const float4 a1 = *reinterpret_cast<const float4*>(asrc + 8 * b + 4);
+    if constexpr (TERMS == 3) {
+      bf16x8 fa[3];
+      split8(a0, a1, fa);
+      bf16x8 wl[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        wl[g] = b < NBR ? bwlo[g][b < NBR ? b : 0]
+                        : __builtin_bit_cast(bf16x8, wlo_lds[(g * (NB - NBR) + (b - NBR)) * 256 + tid]);
+#pragma unroll
+      for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          acc[g] = mfma_bf16(kTb[t6] == 2 ? wl[g] : bwhm[g][b][kTb[t6]], fa[kTa[t6]], acc[g]);
+    } else {
+      const bf16x8 fa = round8(a0, a1);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = mfma_bf16(bwhm[g][b][0], fa, acc[g]);
+    }
+  };
+  unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;
+  if constexpr (STAMP) st_last = stamp_now();
+
+  for (int step = 1; step < T; ++step) {
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {                   // unrolled: creg[hf] and the counter halves are static
+      // item i = (step, hf); pending epilogue: item i-1 = (step - 1 + hf, hf ^ 1)
+      const int pstep = hf ? step : step - 1, phf = hf ^ 1;
+      // ---- region 1 (straight-line): first MFMA blocks with the pending epilogue spread between them
+      load_xp(xp_cur, step, hf);
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[g][q] = 0.f;
+#pragma unroll
+      for (int b = 0; b < NB1; ++b) mfma_block(b);
+      cell_update(pstep, phf, xp_prev);
+      if constexpr (NB1 > 0) {
+        constexpr int NM = NB1 * (TERMS == 3 ? 24 : 4);
+        __builtin_amdgcn_sched_group_barrier(0x100, 16 + 2, 0);   // the epilogue's partial tiles + the first A block
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA ...
+          __builtin_amdgcn_sched_group_barrier(0x402, TERMS == 3 ? 5 : 30, 0);   // ... a few VALU / transcendentals
+          if (m % 12 == 11) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // the next A block's LDS reads
+        }
+      }
+      PE_STAMP(0)                                                 // region 1: MFMAs + pending epilogue issued
+      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");            // the h store (issued first) has completed
+      PE_STAMP(1)                                                 // ... its store drain
+      __syncthreads();                                            // #2
+      PE_STAMP(2)
+      arrive(phf);
+      // ---- region 2: second part of the MFMAs; one lane waits for the next item's group
+#pragma unroll
+      for (int b = NB1; b < NB - 1; ++b) mfma_block(b);
+      const int nstep = hf ? step + 1 : step, nhf = hf ^ 1;       // item i+1
+      const bool want_fetch = nstep < T;
+      PE_STAMP(3)                                                 // region 2 MFMAs issued
+      if (want_fetch) poll(nhf, (unsigned)(NJ * nstep));
+      PE_STAMP(4)                                                 // poll (wave 0)
+      __syncthreads();                                            // #3: the poll result reaches every wave
+      PE_STAMP(5)
+      if (want_fetch) fetch_rows(nstep, nhf);
+      mfma_block(NB - 1);
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4)
           *reinterpret_cast<float4*>(red + (wv * 32 + r) * kRs + g * 32 + 8 * q4 + 4 * hh) =
               make_float4(acc[g][4 * q4], acc[g][4 * q4 + 1], acc[g][4 * q4 + 2], acc[g][4 * q4 + 3]);
-    }
-    __syncthreads();                                  // #0
-    if (want_fetch) {
-      float* adst = As + (tid >> 3) * ASTR + (tid & 7) * 4;
+      PE_STAMP(6)                                                 // last block + accumulators -> red
+      __syncthreads();                                            // #0: As(i) is free, red(i) complete
+      PE_STAMP(7)
+      if (want_fetch) commit_rows();
 #pragma unroll
-      for (int v = 0; v < NST; ++v) *reinterpret_cast<float4*>(adst + 32 * v) = stage[v];
+      for (int g = 0; g < 4; ++g) xp_prev[g] = xp_cur[g];
+      PE_STAMP(8)                                                 // wait for the fetched rows + LDS writes
+      __syncthreads();                                            // #1
+      PE_STAMP(9)
     }
-#pragma unroll
-    for (int g = 0; g < 4; ++g) xp_prev[g] = xp_cur[g];
-    __syncthreads();                                  // #1 of the next iteration
-   }
   }
-  cell_update(nitems - 1, 1, xp_prev, (nitems - 1) >= 2);
+  cell_update(T - 1, 1, xp_prev);
+  if constexpr (STAMP) {
+    if (tid == 0)
+      for (int k = 0; k < 10; ++k) sync[2048 + 16 * blockIdx.x + k] = (unsigned)(st_acc[k] >> 4);
+  }
 }
 
 // --------------------------------------------------------------------------------------- backward
@@ -909,18 +976,20 @@ constexpr size_t fwd_v2_lds() {
   return (size_t)(32 * (H + 4) + 4 * 32 * kRs) * sizeof(float) + (size_t)4 * NBL * 256 * 16;
 }
 
-template <int H, int TERMS, int NBR>
+template <int H, int TERMS, int NBR, bool STAMP = false>
 int launch_fwd_v2(const PFwdCells& cells, int grid, int B, int T, long ldy, unsigned* sync, hipStream_t st) {
   static_assert(fwd_v2_lds<H, TERMS, NBR>() <= 160 * 1024, "LDS budget");
   static bool attr = false;
   if (!attr) {
-    PE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_persistent_v2_kernel<H, TERMS, NBR>),
+    PE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_persistent_v2_kernel<H, TERMS, NBR, STAMP>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_v2_lds<H, TERMS, NBR>()));
     attr = true;
   }
   const unsigned y_bytes = (unsigned)((size_t)B * T * ldy * sizeof(float));
-  hipLaunchKernelGGL((lstm_fwd_persistent_v2_kernel<H, TERMS, NBR>), dim3(grid), dim3(256),
-                     (fwd_v2_lds<H, TERMS, NBR>()), st, cells, B, T, ldy, y_bytes, sync);
+  const unsigned g_bytes = (unsigned)((size_t)B * T * 4 * H * sizeof(float));
+  const unsigned c_bytes = (unsigned)((size_t)B * T * H * sizeof(float));
+  hipLaunchKernelGGL((lstm_fwd_persistent_v2_kernel<H, TERMS, NBR, STAMP>), dim3(grid), dim3(256),
+                     (fwd_v2_lds<H, TERMS, NBR>()), st, cells, B, T, ldy, y_bytes, g_bytes, c_bytes, sync);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }
@@ -979,9 +1048,13 @@ static int lstm_fwd_persistent_impl(int terms, int ncells, const float* const* w
   // word 0 is the sticky error flag (cleared only by the owner of the buffer); counters start at line 1
   PE_CHECK_HIP(hipMemsetAsync(sync + kCtrStride, 0, pe_lstm_persistent_sync_bytes(ncells, B) - kCtrStride * 4, st));
   const int grid = ncells * ((B + 63) / 64) * (H / 32);
-  if (lstm_use_v2() && terms != 0) {
+  if (lstm_use_v2() && terms != 0 && (size_t)B * T * 4 * H * sizeof(float) < (1ull << 31) &&
+      (size_t)B * T * ldy * sizeof(float) < (1ull << 31)) {
     if (H == 64) return terms == 3 ? launch_fwd_v2<64, 3, 1>(cells, grid, B, T, ldy, sync, st)
                                    : launch_fwd_v2<64, 1, 1>(cells, grid, B, T, ldy, sync, st);
+    static const bool stamp = getenv("PE_LSTM_STAMP") && getenv("PE_LSTM_STAMP")[0] == '1';
+    if (H == 384 && terms == 3 && stamp && grid <= 128)
+      return launch_fwd_v2<384, 3, 4, true>(cells, grid, B, T, ldy, sync, st);
     if (H == 384) return terms == 3 ? launch_fwd_v2<384, 3, 4>(cells, grid, B, T, ldy, sync, st)
                                     : launch_fwd_v2<384, 1, 6>(cells, grid, B, T, ldy, sync, st);
   }
