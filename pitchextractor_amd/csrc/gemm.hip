@@ -39,31 +39,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(RowLoader al, RowLoader bl
   f32x16 acc[TL::TM][TL::TN];
   zero_acc<TL>(acc);
   nt_mainloop_mode<TL, MODE>(al, bl, K, As, Bs, acc);
-  // epilogue: a lane's column is fixed per column tile, so the two bias vectors are read once per tile (not once
-  // per element) and the 16 rows of a tile are stored back to back
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int wm = wv / TL::WAVES_N, wn = wv % TL::WAVES_N;
-  const int r = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int j = 0; j < TL::TN; ++j) {
-    const int col = n0 + wn * TL::WN + j * 32 + r;
-    if (col >= ep.N) continue;
-    const float b0v = ep.bias0 ? ep.bias0[col] : 0.f, b1v = ep.bias1 ? ep.bias1[col] : 0.f;
-#pragma unroll
-    for (int i = 0; i < TL::TM; ++i)
-#pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        const int row = m0 + wm * TL::WM + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
-        if (row < ep.M) {
-          float* dst = ep.C + (long)row * ep.ldc + col;
-          float v = acc[i][j][g];
-          if (ep.bias0) v += b0v;                                  // same order of additions as StoreEpi
-          if (ep.bias1) v += b1v;
-          if (ep.accumulate) v += *dst;
-          *dst = v;
-        }
-      }
-  }
+  for_each_acc<TL>(acc, [&](int r, int c, float v) { ep(m0 + r, n0 + c, v); });
 }
 
 template <class TL, int MODE>
