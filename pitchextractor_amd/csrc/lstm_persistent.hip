@@ -71,6 +71,38 @@ __device__ __forceinline__ float tanh_fast(float x) {
   return copysignf(ax < 0.25f ? small : big, x);
 }
 
+// The same two functions for N independent values, stage by stage (all exponentials, then all reciprocals, ...):
+// at one wave per SIMD nothing else hides the latency of a dependent v_exp -> v_add -> v_rcp chain, so the
+// independent chains have to be interleaved in program order.  Results are bit-identical to sigm / tanh_fast.
+template <int N>
+__device__ __forceinline__ void sigm_n(const float (&x)[N], float (&y)[N]) {
+  float e[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) e[k] = __builtin_amdgcn_exp2f(-x[k] * 1.44269504088896340736f);
+#pragma unroll
+  for (int k = 0; k < N; ++k) e[k] = 1.0f + e[k];
+#pragma unroll
+  for (int k = 0; k < N; ++k) y[k] = __builtin_amdgcn_rcpf(e[k]);
+}
+template <int N>
+__device__ __forceinline__ void tanh_n(const float (&x)[N], float (&y)[N]) {
+  float ax[N], e[N], rc[N], sm[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) ax[k] = fabsf(x[k]);
+#pragma unroll
+  for (int k = 0; k < N; ++k) e[k] = __builtin_amdgcn_exp2f((-2.0f * ax[k]) * 1.44269504088896340736f);
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const float x2 = x[k] * x[k];
+    sm[k] = ax[k] * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 62.0f / 2835.0f, -17.0f / 315.0f), 2.0f / 15.0f),
+                              -1.0f / 3.0f), 1.0f);
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) rc[k] = __builtin_amdgcn_rcpf(1.0f + e[k]);
+#pragma unroll
+  for (int k = 0; k < N; ++k) y[k] = copysignf(ax[k] < 0.25f ? sm[k] : (1.0f - e[k]) * rc[k], x[k]);
+}
+
 // X3 variants: the recurrent products run as the exact three-term bf16 split (gemm_engine.h).  The W_hh
 // slice is split once; its hi and mid terms stay in registers for the whole sequence, the lo terms of the
 // last blocks live in LDS (they feed one product in six and the register file is full).  The h / dgates
@@ -403,10 +435,13 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_kernel(const PFwdC
 //     MFMA block NB-1;  accumulators -> red(i)
 //     barrier #0   every wave has finished reading As(i);  h rows of item i+1 -> As
 //
-// A wave issues in order, so "under the MFMAs" has to be literal: the epilogue's VALU / LDS / memory instructions
-// are spread between the MFMAs of the first half by sched_group_barrier (one MFMA, then a few of the others).
-// The region is kept branch-free for that: step 0 (no recurrent input) is peeled, rows beyond B are handled by
-// the buffer range check (loads return 0, stores are dropped) instead of exec-masked branches.
+// What overlaps is the MEMORY side of the epilogue (store drain, hand-off propagation, counter poll, h-row fetch):
+// all of it is in flight under MFMAs.  The gate arithmetic itself still issues after the first-half MFMAs of the
+// same wave (a wave issues in order; hipcc keeps the two instruction groups apart even under
+// sched_group_barrier -- s_memtime stamps, tools/stamp_lstm.py: 5.2 k of an item's 12.4 k cycles are that
+// region, 4.6 k are MFMA issue); interleaving it by hand is the open item.  The region is branch-free: step 0
+// (no recurrent input) is peeled, rows beyond B are handled by the buffer range check (loads return 0, stores
+// are dropped) instead of exec-masked branches.
 // The consumer of item i-1's h is item i+1 (same half, next step), so the hand-off has half an MFMA phase to
 // become visible and the fetch the other half to land.  LDS: As (50 KB) and red (68 KB) can no longer share
 // space; the W_hh lo terms that do not fit the register file next to them keep (NB - NBR) blocks in LDS.
@@ -527,18 +562,26 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_v2_kernel(const PF
       pre[g].z = ((p0.z + p1.z) + (p2.z + p3.z)) + xp[g].z;
       pre[g].w = ((p0.w + p1.w) + (p2.w + p3.w)) + xp[g].w;
     }
-    const float4 gi = make_float4(sigm(pre[0].x), sigm(pre[0].y), sigm(pre[0].z), sigm(pre[0].w));
-    const float4 gf = make_float4(sigm(pre[1].x), sigm(pre[1].y), sigm(pre[1].z), sigm(pre[1].w));
-    const float4 gg = make_float4(tanh_fast(pre[2].x), tanh_fast(pre[2].y), tanh_fast(pre[2].z), tanh_fast(pre[2].w));
-    const float4 go = make_float4(sigm(pre[3].x), sigm(pre[3].y), sigm(pre[3].z), sigm(pre[3].w));
+    const float sx[12] = {pre[0].x, pre[0].y, pre[0].z, pre[0].w, pre[1].x, pre[1].y, pre[1].z, pre[1].w,
+                          pre[3].x, pre[3].y, pre[3].z, pre[3].w};
+    const float tx[4] = {pre[2].x, pre[2].y, pre[2].z, pre[2].w};
+    float sy[12], ty[4];
+    sigm_n<12>(sx, sy);
+    tanh_n<4>(tx, ty);
+    const float4 gi = make_float4(sy[0], sy[1], sy[2], sy[3]);
+    const float4 gf = make_float4(sy[4], sy[5], sy[6], sy[7]);
+    const float4 go = make_float4(sy[8], sy[9], sy[10], sy[11]);
+    const float4 gg = make_float4(ty[0], ty[1], ty[2], ty[3]);
     float4 cn;
     cn.x = gf.x * creg[hf].x + gi.x * gg.x;
     cn.y = gf.y * creg[hf].y + gi.y * gg.y;
     cn.z = gf.z * creg[hf].z + gi.z * gg.z;
     cn.w = gf.w * creg[hf].w + gi.w * gg.w;
     creg[hf] = cn;
-    const float4 hv = make_float4(go.x * tanh_fast(cn.x), go.y * tanh_fast(cn.y), go.z * tanh_fast(cn.z),
-                                  go.w * tanh_fast(cn.w));
+    const float cx[4] = {cn.x, cn.y, cn.z, cn.w};
+    float cy[4];
+    tanh_n<4>(cx, cy);
+    const float4 hv = make_float4(go.x * cy[0], go.y * cy[1], go.z * cy[2], go.w * cy[3]);
     // h first and write-through: it is what the group waits for; the five stores behind it need not have
     // completed when this workgroup arrives (vmcnt counts in order)
     store_sc1(yrs, oob(e, (e * (unsigned)ldy + (unsigned)(j0 + 4 * pq)) * 4u), hv);
@@ -635,16 +678,6 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_v2_kernel(const PF
 #pragma unroll
       for (int b = 0; b < NB1; ++b) mfma_block(b);
       cell_update(pstep, phf, xp_prev);
-      if constexpr (NB1 > 0) {
-        constexpr int NM = NB1 * (TERMS == 3 ? 24 : 4);
-        __builtin_amdgcn_sched_group_barrier(0x100, 16 + 2, 0);   // the epilogue's partial tiles + the first A block
-#pragma unroll
-        for (int m = 0; m < NM; ++m) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA ...
-          __builtin_amdgcn_sched_group_barrier(0x402, TERMS == 3 ? 5 : 30, 0);   // ... a few VALU / transcendentals
-          if (m % 12 == 11) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // the next A block's LDS reads
-        }
-      }
       PE_STAMP(0)                                                 // region 1: MFMAs + pending epilogue issued
       asm volatile("s_waitcnt vmcnt(5)" ::: "memory");            // the h store (issued first) has completed
       PE_STAMP(1)                                                 // ... its store drain
