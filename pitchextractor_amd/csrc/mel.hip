@@ -4,15 +4,14 @@
 // Replaces torchaudio.transforms.MelSpectrogram as used by the reference at
 // meldataset.py:34-40,58-77,644 and the log/affine of meldataset.py:650.
 //
-// Work decomposition: one 256-thread workgroup = FB consecutive frames of one
-// utterance.  The (FB-1)*hop + 1024 samples those frames touch are staged in
-// LDS once (coalesced HBM reads, reflect indices resolved on load), so HBM sees
-// each sample ~1.2x instead of the 3.4x frame overlap.  Each of the 4 waves
-// transforms one frame at a time: the 1024 real samples are packed as 512
-// complex points, 8 per lane, and run through three in-register radix-8 passes
+// Work decomposition: a 256-thread workgroup walks items of FB consecutive frames
+// of one utterance.  Each of the 4 waves transforms one frame at a time, read
+// straight from global memory in 512-byte runs (reflect indices resolved per
+// sample on edge frames only): the 1024 real samples are packed as 512 complex
+// points, 8 per lane, and run through three in-register radix-8 passes
 // (512 = 8*8*8) with two LDS exchanges between them; the real-FFT split, the
 // power and the (<= 2 non-zero weights per bin) mel filterbank follow from LDS.
-// Window and twiddles are per-lane constants held in registers across frames.
+// Window and twiddles are per-lane constants held in registers for the whole launch.
 #include <math.h>
 #include <string.h>
 #include <vector>
@@ -85,172 +84,200 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Persistent form: the grid is sized to the chip (4 workgroups per CU fit: 29 KB of LDS, 126 VGPRs) and every
+// workgroup walks (utterance, block of FB frames) items, so the per-lane window / twiddle constants are loaded
+// once per workgroup, not once per 16 frames.  Frames are read straight from global memory: lane l takes the
+// float2 at complex index 64 r + l, so every load instruction is one contiguous 512-byte run; the 3.4x overlap
+// of consecutive frames is absorbed by L2 (HBM sees each sample once), and no staging barrier is needed.
+// The three radix-8 passes exchange through ONE LDS region per wave: within a phase every lane first reads
+// its 8 values, then writes 8, and a wave's LDS instructions execute in program order, so the region can be
+// overwritten in place.
 template <int FB>
-__global__ __launch_bounds__(256) void mel_fwd_kernel(const MelArgs a) {
+__global__ __launch_bounds__(256, 4) void mel_fwd_kernel(const MelArgs a, int blocks_per_utt, int n_items) {
   static_assert(FB % 4 == 0, "FB frames are dealt to 4 waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* s_audio = reinterpret_cast<float*>(smem);
-  float2* s_A = reinterpret_cast<float2*>(s_audio + a.audio_len);   // [4][kXchg]
-  float2* s_B = s_A + 4 * kXchg;                                    // [4][kXchg]
-  float* s_out = reinterpret_cast<float*>(s_B + 4 * kXchg);         // [n_mels][FB+1]
-  float* s_fbw = s_out + ((a.n_mels * (FB + 1) + 3) & ~3);          // [n_pairs][8], 16-byte aligned
-  int* s_fbi = reinterpret_cast<int*>(s_fbw + a.n_pairs * 8);       // k0[n_pairs] | first[n_mels] | cnt[n_mels]
+  float2* s_X = reinterpret_cast<float2*>(smem);                     // [4][kXchg] exchange / Z / P
+  float* s_part = reinterpret_cast<float*>(s_X + 4 * kXchg);         // [4][256] chunk sums
+  float* s_out = s_part + 4 * 256;                                   // [n_mels][FB+1]
+  float* s_fbw = s_out + ((a.n_mels * (FB + 1) + 3) & ~3);           // [n_pairs][8], 16-byte aligned
+  int* s_fbi = reinterpret_cast<int*>(s_fbw + a.n_pairs * 8);        // k0[n_pairs] | first[n_mels] | cnt[n_mels]
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int b = blockIdx.y;
   const int hop = a.hop, n_mels = a.n_mels;
-  const int n_samples = a.n_samples_arr ? a.n_samples_arr[b] : a.n_samples;
-  // reflect padding needs more than n_fft/2 samples; shorter items come out as padding only
-  const int n_valid = n_samples > kHalf ? 1 + n_samples / hop : 0;
-  const int f_out0 = blockIdx.x * FB;                       // first output frame of this block
-  const int f0 = f_out0 + (a.frame_start ? max(a.frame_start[b], 0) : 0);   // first source frame
+  for (int j = tid; j < a.n_pairs * 8; j += 256) s_fbw[j] = a.fb_w[j];
+  for (int j = tid; j < a.n_pairs + 2 * n_mels; j += 256) s_fbi[j] = a.fb_idx[j];
 
-  if (f0 < n_valid) {
-    // ---- stage the audio chunk (reflect padding resolved here) and the filterbank
-    const float* wsrc = a.wave + (long)b * a.wave_stride;
-    const long base = (long)f0 * hop - kHalf;
-    const long N = n_samples;
-    if (base >= 0 && base + a.audio_len <= N && ((base & 3) == 0) && ((a.wave_stride & 3) == 0)) {
-      // interior block: straight 16-byte copies
-      for (int j = tid * 4; j < a.audio_len; j += 1024)
-        *reinterpret_cast<float4*>(s_audio + j) = *reinterpret_cast<const float4*>(wsrc + base + j);
-    } else {
-      for (int j = tid; j < a.audio_len; j += 256) {
-        long g = base + j;
-        if (g < 0) g = -g;
-        if (g >= N) g = 2 * (N - 1) - g;
-        s_audio[j] = (g >= 0 && g < N) ? wsrc[g] : 0.0f;
-      }
-    }
-    for (int j = tid; j < a.n_pairs * 8; j += 256) s_fbw[j] = a.fb_w[j];
-    for (int j = tid; j < a.n_pairs + 2 * n_mels; j += 256) s_fbi[j] = a.fb_idx[j];
-
-    // ---- per-lane constants, kept in registers across frames
-    float2 win[8], tw1[8], tw2[8], twp[4];
-    const int c_ = lane & 7;
+  // ---- per-lane constants, kept in registers across all items of this workgroup
+  float2 win[8], tw1[8], tw2[8];
+  const int c_ = lane & 7;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int n = 64 * r + lane;                      // complex sample index, stage 1
-      win[r] = make_float2(a.win[2 * n], a.win[2 * n + 1]);
-      tw1[r] = a.tw512[(lane * r) & 511];               // W512^(m*k0)
-      tw2[r] = a.tw512[(8 * c_ * r) & 511];             // W64^(c*k1)
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) twp[j] = a.tw1024[lane + 64 * j];
-
-    float2* A = s_A + wv * kXchg;
-    float2* B = s_B + wv * kXchg;
-    float* P = reinterpret_cast<float*>(B);             // 513 floats, after stage 3
-    __syncthreads();
-
-    for (int it = 0; it < FB / 4; ++it) {
-      const int fi = it * 4 + wv;
-      const bool valid = (f0 + fi) < n_valid;           // wave-uniform
-      float2 v[8];
-      if (valid) {
-        // pass 1: radix-8 over a, lane = m = 8b+c, x[n = 64a + m]
-        const float* fr = s_audio + fi * hop;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          const int n = 64 * r + lane;
-          v[r] = make_float2(fr[2 * n] * win[r].x, fr[2 * n + 1] * win[r].y);
-        }
-        fft8(v);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) A[r * 72 + lane] = (r == 0) ? v[0] : cmul(v[r], tw1[r]);
-      }
-      wave_lds_sync();
-      if (valid) {
-        // pass 2: lane = 8*k0 + c, radix-8 over b
-        const int k0 = lane >> 3;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = A[k0 * 72 + 8 * r + c_];
-        fft8(v);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) B[(k0 + 8 * r) * 9 + c_] = (r == 0) ? v[0] : cmul(v[r], tw2[r]);
-      }
-      wave_lds_sync();
-      if (valid) {
-        // pass 3: lane = k0 + 8*k1, radix-8 over c -> Z[lane + 64*k2]
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = B[lane * 9 + r];
-        fft8(v);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) A[lane + 64 * r] = v[r];
-      }
-      wave_lds_sync();
-      if (valid) {
-        // real-FFT split: X[k] = E + W^k O, X[512-k] = conj(E - W^k O); keep powers
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int k = lane + 64 * j;
-          const float2 zk = A[k], zn = A[(kHalf - k) & 511];
-          const float2 E = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-          const float2 O = make_float2(0.5f * (zk.y + zn.y), 0.5f * (zn.x - zk.x));
-          const float2 wo = cmul(twp[j], O);
-          const float2 xp = cadd(E, wo), xm = csub(E, wo);
-          P[k] = xp.x * xp.x + xp.y * xp.y;
-          P[kNfft / 2 - k] = xm.x * xm.x + xm.y * xm.y;
-        }
-        if (lane == 0) {
-          const float2 z = A[256];                      // k = 256: W = -i, |X|^2 = |Z|^2
-          P[256] = z.x * z.x + z.y * z.y;
-        } else if (lane < 8) {
-          P[kNfft / 2 + lane] = 0.0f;                   // zero tail read by the padded 8-tap chunks
-        }
-      }
-      wave_lds_sync();
-      // mel filterbank, two balanced rounds: every filter is cut into chunks of 8 taps (zero padded);
-      // a lane sums one chunk with a fixed, fully unrolled trip count, then each mel bin adds its
-      // <= kMaxParts chunk sums.  (A serial per-filter loop of up to 36 dependent LDS round trips was
-      // the longest phase of the frame.)
-      if (valid) {
-        float* part = reinterpret_cast<float*>(A);      // Z is dead after the power pass
-        for (int id = lane; id < a.n_pairs; id += 64) {
-          const int k0 = s_fbi[id];
-          const float4 w0 = *reinterpret_cast<const float4*>(s_fbw + id * 8);
-          const float4 w1 = *reinterpret_cast<const float4*>(s_fbw + id * 8 + 4);
-          float acc = w0.x * P[k0];
-          acc = fmaf(w0.y, P[k0 + 1], acc); acc = fmaf(w0.z, P[k0 + 2], acc); acc = fmaf(w0.w, P[k0 + 3], acc);
-          acc = fmaf(w1.x, P[k0 + 4], acc); acc = fmaf(w1.y, P[k0 + 5], acc); acc = fmaf(w1.z, P[k0 + 6], acc);
-          acc = fmaf(w1.w, P[k0 + 7], acc);
-          part[id] = acc;
-        }
-      }
-      wave_lds_sync();
-      if (valid) {
-        const float* part = reinterpret_cast<const float*>(A);
-        for (int m = lane; m < n_mels; m += 64) {
-          const int first = s_fbi[a.n_pairs + m], cnt = s_fbi[a.n_pairs + n_mels + m];
-          float acc = 0.0f;
-#pragma unroll
-          for (int j = 0; j < kMaxParts; ++j) acc += (j < cnt) ? part[first + j] : 0.0f;
-          s_out[m * (FB + 1) + fi] = a.log_mode ? (logf(a.log_eps + acc) - a.mean) * a.inv_std : acc;
-        }
-      }
-      wave_lds_sync();                                  // `part` lives in A, which pass 1 of the next frame rewrites
-    }
-    __syncthreads();
+  for (int r = 0; r < 8; ++r) {
+    const int n = 64 * r + lane;                        // complex sample index, stage 1
+    win[r] = make_float2(a.win[2 * n], a.win[2 * n + 1]);
+    tw1[r] = a.tw512[(lane * r) & 511];                 // W512^(m*k0)
+    tw2[r] = a.tw512[(8 * c_ * r) & 511];               // W64^(c*k1)
   }
+  const float2* twp = a.tw1024 + lane;                  // W1024^k of the real-FFT split: 4 cached loads per frame
+  float2* X = s_X + wv * kXchg;
+  float* P = reinterpret_cast<float*>(X);               // 513 (+7 zero) floats, after the real-FFT split
+  float* part = s_part + wv * 256;
+  __syncthreads();
 
-  // ---- store (frames past the utterance's last frame are padding)
-  float* dst = a.out + (long)b * a.out_sb;
-  const bool mel_fastest = (a.out_sm == 1);
-  for (int idx = tid; idx < n_mels * FB; idx += 256) {
-    const int m = mel_fastest ? idx % n_mels : idx / FB;
-    const int fo = mel_fastest ? idx / n_mels : idx % FB;
-    const int frame = f_out0 + fo;
-    if (frame < a.out_frames) {
-      const float val = (f0 + fo < n_valid) ? s_out[m * (FB + 1) + fo] : a.pad_value;
-      dst[(long)m * a.out_sm + (long)frame * a.out_st] = val;
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int b = item / blocks_per_utt;
+    const int f_out0 = (item - b * blocks_per_utt) * FB;      // first output frame of this item
+    const int n_samples = a.n_samples_arr ? a.n_samples_arr[b] : a.n_samples;
+    // reflect padding needs more than n_fft/2 samples; shorter items come out as padding only
+    const int n_valid = n_samples > kHalf ? 1 + n_samples / hop : 0;
+    const int f0 = f_out0 + (a.frame_start ? max(a.frame_start[b], 0) : 0);   // first source frame
+    const float* wsrc = a.wave + (long)b * a.wave_stride;
+    const long N = n_samples;
+
+    if (f0 < n_valid) {
+      for (int it = 0; it < FB / 4; ++it) {
+        const int fi = it * 4 + wv;
+        const bool valid = (f0 + fi) < n_valid;         // wave-uniform
+        float2 v[8];
+        if (valid) {
+          // pass 1: radix-8 over a, lane = m = 8b+c, x[n = 64a + m]
+          const long base = (long)(f0 + fi) * hop - kHalf;      // first sample of the frame (may be < 0)
+          if (base >= 0 && base + kNfft <= N && ((base | a.wave_stride) & 1) == 0) {
+            const float2* fr = reinterpret_cast<const float2*>(wsrc + base);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              const float2 x = fr[64 * r + lane];
+              v[r] = make_float2(x.x * win[r].x, x.y * win[r].y);
+            }
+          } else {                                      // edge frame / odd alignment: reflect indices per sample
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              float x2[2];
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                long g = base + 2 * (64 * r + lane) + e;
+                if (g < 0) g = -g;
+                if (g >= N) g = 2 * (N - 1) - g;
+                x2[e] = (g >= 0 && g < N) ? wsrc[g] : 0.0f;
+              }
+              v[r] = make_float2(x2[0] * win[r].x, x2[1] * win[r].y);
+            }
+          }
+          fft8(v);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) X[r * 72 + lane] = (r == 0) ? v[0] : cmul(v[r], tw1[r]);
+        }
+        wave_lds_sync();
+        if (valid) {
+          // pass 2: lane = 8*k0 + c, radix-8 over b (all 8 reads precede the writes: in place)
+          const int k0 = lane >> 3;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] = X[k0 * 72 + 8 * r + c_];
+          fft8(v);
+          wave_lds_sync();
+#pragma unroll
+          for (int r = 0; r < 8; ++r) X[(k0 + 8 * r) * 9 + c_] = (r == 0) ? v[0] : cmul(v[r], tw2[r]);
+        }
+        wave_lds_sync();
+        if (valid) {
+          // pass 3: lane = k0 + 8*k1, radix-8 over c -> Z[lane + 64*k2]
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] = X[lane * 9 + r];
+          fft8(v);
+          wave_lds_sync();
+#pragma unroll
+          for (int r = 0; r < 8; ++r) X[lane + 64 * r] = v[r];
+        }
+        wave_lds_sync();
+        if (valid) {
+          // real-FFT split: X[k] = E + W^k O, X[512-k] = conj(E - W^k O); keep powers (P overwrites Z in place)
+          float2 zk[4], zn[4], tp[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int k = lane + 64 * j;
+            tp[j] = twp[64 * j];
+            zk[j] = X[k];
+            zn[j] = X[(kHalf - k) & 511];
+          }
+          const float2 z256 = X[256];
+          wave_lds_sync();
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int k = lane + 64 * j;
+            const float2 E = make_float2(0.5f * (zk[j].x + zn[j].x), 0.5f * (zk[j].y - zn[j].y));
+            const float2 O = make_float2(0.5f * (zk[j].y + zn[j].y), 0.5f * (zn[j].x - zk[j].x));
+            const float2 wo = cmul(tp[j], O);
+            const float2 xp = cadd(E, wo), xm = csub(E, wo);
+            P[k] = xp.x * xp.x + xp.y * xp.y;
+            P[kNfft / 2 - k] = xm.x * xm.x + xm.y * xm.y;
+          }
+          if (lane == 0) {
+            P[256] = z256.x * z256.x + z256.y * z256.y;     // k = 256: W = -i, |X|^2 = |Z|^2
+          } else if (lane < 8) {
+            P[kNfft / 2 + lane] = 0.0f;                     // zero tail read by the padded 8-tap chunks
+          }
+        }
+        wave_lds_sync();
+        // mel filterbank, two balanced rounds: every filter is cut into chunks of 8 taps (zero padded);
+        // a lane sums one chunk with a fixed, fully unrolled trip count, then each mel bin adds its
+        // <= kMaxParts chunk sums.
+        if (valid) {
+          for (int id = lane; id < a.n_pairs; id += 64) {
+            const int k0 = s_fbi[id];
+            const float4 w0 = *reinterpret_cast<const float4*>(s_fbw + id * 8);
+            const float4 w1 = *reinterpret_cast<const float4*>(s_fbw + id * 8 + 4);
+            float acc = w0.x * P[k0];
+            acc = fmaf(w0.y, P[k0 + 1], acc); acc = fmaf(w0.z, P[k0 + 2], acc); acc = fmaf(w0.w, P[k0 + 3], acc);
+            acc = fmaf(w1.x, P[k0 + 4], acc); acc = fmaf(w1.y, P[k0 + 5], acc); acc = fmaf(w1.z, P[k0 + 6], acc);
+            acc = fmaf(w1.w, P[k0 + 7], acc);
+            part[id] = acc;
+          }
+        }
+        wave_lds_sync();
+        if (valid) {
+          for (int m = lane; m < n_mels; m += 64) {
+            const int first = s_fbi[a.n_pairs + m], cnt = s_fbi[a.n_pairs + n_mels + m];
+            float acc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < kMaxParts; ++j) acc += (j < cnt) ? part[first + j] : 0.0f;
+            s_out[m * (FB + 1) + fi] = a.log_mode ? (logf(a.log_eps + acc) - a.mean) * a.inv_std : acc;
+          }
+        }
+        wave_lds_sync();                                // P / part are rewritten by the next frame
+      }
     }
+    __syncthreads();
+
+    // ---- store (frames past the utterance's last frame are padding)
+    float* dst = a.out + (long)b * a.out_sb;
+    const bool mel_fastest = (a.out_sm == 1);
+    for (int idx = tid; idx < n_mels * FB; idx += 256) {
+      const int m = mel_fastest ? idx % n_mels : idx / FB;
+      const int fo = mel_fastest ? idx / n_mels : idx % FB;
+      const int frame = f_out0 + fo;
+      if (frame < a.out_frames) {
+        const float val = (f0 + fo < n_valid) ? s_out[m * (FB + 1) + fo] : a.pad_value;
+        dst[(long)m * a.out_sm + (long)frame * a.out_st] = val;
+      }
+    }
+    __syncthreads();                                    // s_out is rewritten by the next item
   }
 }
 
 constexpr int kFB = 16;
 
-size_t mel_lds_bytes(int audio_len, int n_mels, int n_pairs, int fb) {
-  size_t bytes = (size_t)audio_len * 4 + 2 * 4 * kXchg * 8 + (size_t)((n_mels * (fb + 1) + 3) & ~3) * 4 +
+int mel_cus() {
+  static int cus = 0;
+  if (cus <= 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+              ? prop.multiProcessorCount : 256;
+  }
+  return cus;
+}
+
+size_t mel_lds_bytes(int n_mels, int n_pairs, int fb) {
+  size_t bytes = (size_t)4 * kXchg * 8 + 4 * 256 * 4 + (size_t)((n_mels * (fb + 1) + 3) & ~3) * 4 +
                  (size_t)n_pairs * 8 * 4 + (size_t)(n_pairs + 2 * n_mels) * 4;
   return (bytes + 15) & ~(size_t)15;
 }
@@ -393,12 +420,16 @@ static int mel_launch(const pe_mel_plan* plan, const float* wave, int batch, int
   a.pad_value = pad_value;
   a.win = plan->d_win; a.tw512 = plan->d_tw512; a.tw1024 = plan->d_tw1024;
   a.fb_idx = plan->d_fb_idx; a.fb_w = plan->d_fb_w; a.n_pairs = plan->n_pairs;
-  a.audio_len = ((kFB - 1) * plan->hop + kNfft + 3) & ~3;
+  a.audio_len = 0;
 
-  const size_t lds = mel_lds_bytes(a.audio_len, plan->n_mels, plan->n_pairs, kFB);
+  const size_t lds = mel_lds_bytes(plan->n_mels, plan->n_pairs, kFB);
   if (lds > 160 * 1024) return PE_E_UNSUPPORTED;
-  dim3 grid(pe_cdiv(out_frames, kFB), batch);
-  hipLaunchKernelGGL(mel_fwd_kernel<kFB>, grid, dim3(256), lds, pe_stream(stream), a);
+  const int blocks_per_utt = pe_cdiv(out_frames, kFB);
+  const long n_items = (long)blocks_per_utt * batch;
+  const long resident = (long)mel_cus() * ((160 * 1024) / (long)lds < 4 ? (160 * 1024) / (long)lds : 4);
+  const int grid = (int)(n_items < resident ? n_items : resident);
+  hipLaunchKernelGGL(mel_fwd_kernel<kFB>, dim3(grid), dim3(256), lds, pe_stream(stream), a, blocks_per_utt,
+                     (int)n_items);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }
