@@ -92,8 +92,12 @@ __device__ __forceinline__ void wave_lds_sync() {
 // The three radix-8 passes exchange through ONE LDS region per wave: within a phase every lane first reads
 // its 8 values, then writes 8, and a wave's LDS instructions execute in program order, so the region can be
 // overwritten in place.
+// Work split: every utterance is cut into `parts` contiguous frame ranges of `span` frames (a multiple of 4, chosen
+// by the host so that parts * batch fills the resident grid and the VALID frames divide evenly: 161 frames over 4
+// workgroups = 41 each, where a fixed 16-frame block grid would give one workgroup 48 and another 32); a workgroup
+// walks its range in chunks of FB frames.  Frames >= the utterance's frame count are written as padding.
 template <int FB>
-__global__ __launch_bounds__(256, 4) void mel_fwd_kernel(const MelArgs a, int blocks_per_utt, int n_items) {
+__global__ __launch_bounds__(256, 4) void mel_fwd_kernel(const MelArgs a, int parts, int span, int n_items) {
   static_assert(FB % 4 == 0, "FB frames are dealt to 4 waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float2* s_X = reinterpret_cast<float2*>(smem);                     // [4][kXchg] exchange / Z / P
@@ -124,8 +128,11 @@ __global__ __launch_bounds__(256, 4) void mel_fwd_kernel(const MelArgs a, int bl
   __syncthreads();
 
   for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-    const int b = item / blocks_per_utt;
-    const int f_out0 = (item - b * blocks_per_utt) * FB;      // first output frame of this item
+   const int b = item / parts, prt = item - b * parts;
+   // ranges [prt * span, +span) cover the first parts * span output frames; the last one also takes the rest
+   const int r_lo = prt * span, r_hi = prt + 1 == parts ? a.out_frames : min(a.out_frames, r_lo + span);
+   for (int f_out0 = r_lo; f_out0 < r_hi; f_out0 += FB) {      // first output frame of this chunk
+    const int n_out = min(FB, r_hi - f_out0);
     const int n_samples = a.n_samples_arr ? a.n_samples_arr[b] : a.n_samples;
     // reflect padding needs more than n_fft/2 samples; shorter items come out as padding only
     const int n_valid = n_samples > kHalf ? 1 + n_samples / hop : 0;
@@ -136,7 +143,7 @@ __global__ __launch_bounds__(256, 4) void mel_fwd_kernel(const MelArgs a, int bl
     if (f0 < n_valid) {
       for (int it = 0; it < FB / 4; ++it) {
         const int fi = it * 4 + wv;
-        const bool valid = (f0 + fi) < n_valid;         // wave-uniform
+        const bool valid = fi < n_out && (f0 + fi) < n_valid;   // wave-uniform
         float2 v[8];
         if (valid) {
           // pass 1: radix-8 over a, lane = m = 8b+c, x[n = 64a + m]
@@ -254,12 +261,13 @@ __global__ __launch_bounds__(256, 4) void mel_fwd_kernel(const MelArgs a, int bl
       const int m = mel_fastest ? idx % n_mels : idx / FB;
       const int fo = mel_fastest ? idx / n_mels : idx % FB;
       const int frame = f_out0 + fo;
-      if (frame < a.out_frames) {
+      if (fo < n_out) {
         const float val = (f0 + fo < n_valid) ? s_out[m * (FB + 1) + fo] : a.pad_value;
         dst[(long)m * a.out_sm + (long)frame * a.out_st] = val;
       }
     }
-    __syncthreads();                                    // s_out is rewritten by the next item
+    __syncthreads();                                    // s_out is rewritten by the next chunk
+   }
   }
 }
 
@@ -424,11 +432,20 @@ static int mel_launch(const pe_mel_plan* plan, const float* wave, int batch, int
 
   const size_t lds = mel_lds_bytes(plan->n_mels, plan->n_pairs, kFB);
   if (lds > 160 * 1024) return PE_E_UNSUPPORTED;
-  const int blocks_per_utt = pe_cdiv(out_frames, kFB);
-  const long n_items = (long)blocks_per_utt * batch;
+  // parts per utterance: fill the resident grid; the frames that carry work (the valid ones when the batch is
+  // not ragged) are divided evenly, in multiples of 4 frames (one per wave)
   const long resident = (long)mel_cus() * ((160 * 1024) / (long)lds < 4 ? (160 * 1024) / (long)lds : 4);
+  int work_frames = out_frames;
+  if (!n_samples_arr && !frame_start && a.n_valid < work_frames) work_frames = a.n_valid;
+  int parts = (int)((resident + batch - 1) / batch);
+  const int max_parts = pe_cdiv(work_frames, 4);
+  if (parts > max_parts) parts = max_parts;
+  if (parts < 1) parts = 1;
+  const int span = pe_cdiv(pe_cdiv(work_frames, parts), 4) * 4;
+  parts = pe_cdiv(work_frames, span);
+  const long n_items = (long)parts * batch;
   const int grid = (int)(n_items < resident ? n_items : resident);
-  hipLaunchKernelGGL(mel_fwd_kernel<kFB>, dim3(grid), dim3(256), lds, pe_stream(stream), a, blocks_per_utt,
+  hipLaunchKernelGGL(mel_fwd_kernel<kFB>, dim3(grid), dim3(256), lds, pe_stream(stream), a, parts, span,
                      (int)n_items);
   PE_LAUNCH_CHECK();
   return PE_OK;
