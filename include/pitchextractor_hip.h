@@ -150,6 +150,33 @@ int pe_conv3x3_c1_fwd(const float* x, long sb, long st, long sf, const float* w_
 int pe_conv3x3_c1_wgrad(const float* x, long sb, long st, long sf, const float* dy, float* dw_oihw,
                         int B, int T, int F, float* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- fp16 operands (the reference's autocast default dtype, trainer.py:64-102) -------------------------------
+ * Same contracts as the *_bf16 entry points above with operands rounded (RNE) to IEEE half instead of bf16 and
+ * multiplied by v_mfma_f32_32x32x16_f16; accumulation and every tensor in memory stay fp32.  fp16 has 5 exponent
+ * bits: the caller scales the loss (Trainer's GradScaler) so that gradients stay above 2^-24.
+ * pe_wfrag_pack_f16: fragment order of pe_wfrag_pack with one fp16 term per weight. */
+int pe_gemm_nt_f16(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
+                    int K, const float* bias0, const float* bias1, int accumulate, void* stream);
+int pe_gemm_nt_wf_f16(const float* A, long lda, const void* wfrag, float* C, long ldc, int M, int N, int K,
+                       const float* bias0, const float* bias1, int accumulate, void* stream);
+int pe_gemm_tn_f16(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
+                    int K, int accumulate, float* workspace, size_t workspace_bytes, void* stream);
+int pe_conv3x3_fwd_f16(const float* x, const float* w_packed, float* y, int B, int T, int F, int C, int N,
+                        int accumulate, void* stream);
+int pe_conv3x3_fwd_wf_f16(const float* x, const void* wfrag, float* y, int B, int T, int F, int C, int N,
+                           int accumulate, void* stream);
+int pe_conv3x3_wgrad_f16(const float* x, const float* dy, float* dw_oihw, int B, int T, int F, int Cin,
+                          int Cout, float* workspace, size_t workspace_bytes, void* stream);
+int pe_lstm_fwd_persistent_f16(int ncells, const float* const* whh, float* const* gates, float* const* y,
+                           float* const* cbuf, const int* reverse, long ldy, int B, int T, int H,
+                           unsigned* sync, void* stream);
+int pe_lstm_bwd_persistent_f16(int ncells, const float* const* whh_t, float* const* gates,
+                           const float* const* cbuf, const float* const* dy, const int* reverse, long lddy,
+                           int B, int T, int H, unsigned* sync, void* stream);
+int pe_lstm_whh_grad_f16(const float* dgates, const float* y, long ldy, float* dwhh, int B, int T, int H,
+                     int reverse, float* workspace, size_t workspace_bytes, void* stream);
+int pe_wfrag_pack_f16(const float* w, long ld, int N, int K, void* wfrag, void* stream);
+
 /* ---- BatchNorm2d (train statistics) / LeakyReLU / MaxPool2d((1,k)) / dropout -
  * Activations are [rows = B*T][F][C].  pe_bn_train_stats: batch mean / biased variance over all
  * n_pix = rows*F pixels (model.py:25,37,54,150,159), running-stat update with `momentum` and the
@@ -263,6 +290,8 @@ int pe_f0_bins_ce_loss(const float* logits, long ldl, int C, const float* f0, co
 int pe_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr,
                   float beta1, float beta2, float eps, float weight_decay, double bias_correction1,
                   double bias_correction2, float grad_scale, void* stream);
+/* GradScaler support (reference trainer.py:241-244): *flag = 1 if any of x[0..n) is inf or nan, else 0. */
+int pe_nonfinite_flag(const float* x, long n, int* flag, void* stream);
 
 /* ---- Transformer temporal head (model.py:178-193,229-241,253-255) ---------------------------
  * pe_bgemm: batched 64x64-tiled fp32 MFMA GEMM over `batch` matrices; matrix b of operand X lives

@@ -110,6 +110,17 @@ PROTOTYPES = {
     "pe_resample_forward": (_i, [_p, _p, _i, _i, _l, _p, _l, _i, _p]),
     "pe_f0_bins_ce_workspace_bytes": (_z, [_l]),
     "pe_f0_bins_ce_loss": (_i, [_p, _l, _i, _p, _p, _p, _f, _l, _f, _p, _p, _l, _p, _p, _z, _p]),
+    "pe_gemm_nt_f16": (_i, [_p, _l, _p, _l, _p, _l, _i, _i, _i, _p, _p, _i, _p]),
+    "pe_gemm_nt_wf_f16": (_i, [_p, _l, _p, _p, _l, _i, _i, _i, _p, _p, _i, _p]),
+    "pe_gemm_tn_f16": (_i, [_p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _p, _z, _p]),
+    "pe_conv3x3_fwd_f16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "pe_conv3x3_fwd_wf_f16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "pe_conv3x3_wgrad_f16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "pe_lstm_fwd_persistent_f16": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _p, _p]),
+    "pe_lstm_bwd_persistent_f16": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _p, _p]),
+    "pe_lstm_whh_grad_f16": (_i, [_p, _p, _l, _p, _i, _i, _i, _i, _p, _z, _p]),
+    "pe_wfrag_pack_f16": (_i, [_p, _l, _i, _i, _p, _p]),
+    "pe_nonfinite_flag": (_i, [_p, _l, _p, _p]),
     "pe_adamw_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _d, _d, _f, _p]),
 }
 

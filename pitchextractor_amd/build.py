@@ -37,10 +37,16 @@ def _needs(target: Path, deps) -> bool:
     return any(d.stat().st_mtime > t for d in deps)
 
 
-def _compile(src: Path, verbose: bool) -> Path:
-    obj = OBJ_DIR / (src.stem + ".o")
+# sources whose single-term ("mixed precision") MFMA pipelines are compiled a second time for fp16 operands
+# (-DPE_F16_BUILD: same kernels, v_cvt_f16_f32 / v_mfma_f32_32x32x16_f16, exports pe_*_f16 only)
+F16_SOURCES = ("gemm", "conv", "lstm", "lstm_persistent")
+
+
+def _compile(job, verbose: bool) -> Path:
+    src, f16 = job
+    obj = OBJ_DIR / (src.stem + ("_f16" if f16 else "") + ".o")
     if _needs(obj, [src] + _headers()):
-        cmd = [HIPCC, *CXXFLAGS, "-c", str(src), "-o", str(obj)]
+        cmd = [HIPCC, *CXXFLAGS, *(["-DPE_F16_BUILD"] if f16 else []), "-c", str(src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
@@ -55,8 +61,9 @@ def build_library(force: bool = False, verbose: bool = True, jobs: int = 4) -> P
     srcs = _sources()
     if not srcs:
         raise RuntimeError(f"no .hip sources under {CSRC}")
+    work = [(s, False) for s in srcs] + [(s, True) for s in srcs if s.stem in F16_SOURCES]
     with ThreadPoolExecutor(max_workers=jobs) as ex:
-        objs = list(ex.map(lambda s: _compile(s, verbose), srcs))
+        objs = list(ex.map(lambda j: _compile(j, verbose), work))
     if force or _needs(LIB_PATH, objs):
         cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc",
                "-o", str(LIB_PATH), *map(str, objs)]

@@ -836,6 +836,7 @@ constexpr int kC1WgradBlocks = 2048;
 
 }  // namespace
 
+#ifndef PE_F16_BUILD
 extern "C" int pe_conv3x3_repack(const float* w_oihw, float* w_fwd, float* w_dgrad, int Cout, int Cin,
                                  void* stream) {
   if (!w_oihw || Cout <= 0 || Cin <= 0) return PE_E_ARG;
@@ -853,6 +854,7 @@ extern "C" int pe_transpose2d(const float* in, float* out, int rows, int cols, v
   PE_LAUNCH_CHECK();
   return PE_OK;
 }
+#endif
 
 template <int MODE>
 static int conv3x3_fwd_impl(const float* x, const float* w_packed, float* y, int B, int T, int F, int C, int N,
@@ -875,22 +877,27 @@ static int conv3x3_fwd_impl(const float* x, const float* w_packed, float* y, int
   return launch_conv<Tile<128, 128, 2, 2>, MODE>(x, w_packed, y, B, T, F, C, N, accumulate, st);
 }
 
+#ifndef PE_F16_BUILD
 extern "C" int pe_conv3x3_fwd(const float* x, const float* w_packed, float* y, int B, int T, int F, int C, int N,
                               int accumulate, void* stream) {
   return conv3x3_fwd_impl<kNative>(x, w_packed, y, B, T, F, C, N, accumulate, stream);
 }
+#endif
 
-extern "C" int pe_conv3x3_fwd_bf16(const float* x, const float* w_packed, float* y, int B, int T, int F, int C,
+extern "C" int PE_HALF(pe_conv3x3_fwd)(const float* x, const float* w_packed, float* y, int B, int T, int F, int C,
                                    int N, int accumulate, void* stream) {
   return conv3x3_fwd_impl<kBf16>(x, w_packed, y, B, T, F, C, N, accumulate, stream);
 }
 
+#ifndef PE_F16_BUILD
 extern "C" int pe_conv3x3_fwd_x3(const float* x, const float* w_packed, float* y, int B, int T, int F, int C,
                                  int N, int accumulate, void* stream) {
   return conv3x3_fwd_impl<kSplit>(x, w_packed, y, B, T, F, C, N, accumulate, stream);
 }
+#endif
 
 // ---- weights pre-packed as MFMA fragments (x3: three bf16 terms; bf16: one rounded term)
+#ifndef PE_F16_BUILD
 extern "C" size_t pe_wfrag_bytes(int N, int K, int terms) {
   if (N <= 0 || K <= 0 || (K & 15) || (terms != 1 && terms != 3)) return 0;
   return (size_t)((N + 31) / 32) * (K / 16) * terms * 1024;
@@ -913,7 +920,20 @@ extern "C" int pe_wfrag_pack(const float* w, long ld, int N, int K, int terms, v
 extern "C" int pe_conv3x3_wf_supported(int F, int C, int N) {
   return (C % 32) == 0 && conv_halo_passes(F, N) != 0 ? 1 : 0;
 }
+#endif
 
+#ifdef PE_F16_BUILD
+// fp16 build: one RNE-rounded fp16 term per weight, same fragment order as pe_wfrag_pack(..., terms = 1, ...)
+extern "C" int pe_wfrag_pack_f16(const float* w, long ld, int N, int K, void* out, void* stream) {
+  if (!w || !out || N <= 0 || K <= 0 || ld < K) return PE_E_ARG;
+  if ((K & 15) || (ld & 3)) return PE_E_UNSUPPORTED;
+  const long threads = (long)((N + 31) / 32) * (K / 16) * 64;
+  hipLaunchKernelGGL(wfrag_pack_kernel<1>, dim3(pe_cdiv(threads, 256)), dim3(256), 0, pe_stream(stream), w, ld, N, K,
+                     reinterpret_cast<uint4*>(out));
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+#endif
 template <int MODE>
 static int conv3x3_fwd_wf_impl(const float* x, const void* wfrag, float* y, int B, int T, int F, int C, int N,
                                int accumulate, void* stream) {
@@ -930,22 +950,26 @@ static int conv3x3_fwd_wf_impl(const float* x, const void* wfrag, float* y, int 
   return PE_E_UNSUPPORTED;
 }
 
+#ifndef PE_F16_BUILD
 extern "C" int pe_conv3x3_fwd_wf_x3(const float* x, const void* wfrag, float* y, int B, int T, int F, int C, int N,
                                     int accumulate, void* stream) {
   return conv3x3_fwd_wf_impl<kSplit>(x, wfrag, y, B, T, F, C, N, accumulate, stream);
 }
+#endif
 
-extern "C" int pe_conv3x3_fwd_wf_bf16(const float* x, const void* wfrag, float* y, int B, int T, int F, int C, int N,
+extern "C" int PE_HALF(pe_conv3x3_fwd_wf)(const float* x, const void* wfrag, float* y, int B, int T, int F, int C, int N,
                                       int accumulate, void* stream) {
   return conv3x3_fwd_wf_impl<kBf16>(x, wfrag, y, B, T, F, C, N, accumulate, stream);
 }
 
+#ifndef PE_F16_BUILD
 extern "C" size_t pe_conv3x3_wgrad_workspace_bytes(int B, int T, int F, int Cin, int Cout) {
   if (Cin == 1) return (size_t)kC1WgradBlocks * 576 * sizeof(float);
   int bm, bn, splits, kps;
   wgrad_plan(B * T * F, Cout, Cin, &bm, &bn, &splits, &kps);
   return (size_t)splits * 9 * Cout * Cin * sizeof(float);
 }
+#endif
 
 template <int MODE>
 static int conv3x3_wgrad_impl(const float* x, const float* dy, float* dw_oihw, int B, int T, int F, int Cin,
@@ -981,16 +1005,19 @@ static int conv3x3_wgrad_impl(const float* x, const float* dy, float* dw_oihw, i
   return launch_wgrad<128, 128>(x, dy, dw_oihw, workspace, B, T, F, Cin, Cout, splits, kps, st);
 }
 
+#ifndef PE_F16_BUILD
 extern "C" int pe_conv3x3_wgrad(const float* x, const float* dy, float* dw_oihw, int B, int T, int F, int Cin,
                                 int Cout, float* workspace, size_t workspace_bytes, void* stream) {
   return conv3x3_wgrad_impl<kNative>(x, dy, dw_oihw, B, T, F, Cin, Cout, workspace, workspace_bytes, stream);
 }
+#endif
 
-extern "C" int pe_conv3x3_wgrad_bf16(const float* x, const float* dy, float* dw_oihw, int B, int T, int F, int Cin,
+extern "C" int PE_HALF(pe_conv3x3_wgrad)(const float* x, const float* dy, float* dw_oihw, int B, int T, int F, int Cin,
                                      int Cout, float* workspace, size_t workspace_bytes, void* stream) {
   return conv3x3_wgrad_impl<kBf16>(x, dy, dw_oihw, B, T, F, Cin, Cout, workspace, workspace_bytes, stream);
 }
 
+#ifndef PE_F16_BUILD
 extern "C" int pe_conv3x3_wgrad_x3(const float* x, const float* dy, float* dw_oihw, int B, int T, int F, int Cin,
                                    int Cout, float* workspace, size_t workspace_bytes, void* stream) {
   return conv3x3_wgrad_impl<kSplit>(x, dy, dw_oihw, B, T, F, Cin, Cout, workspace, workspace_bytes, stream);
@@ -1020,3 +1047,4 @@ extern "C" int pe_conv3x3_c1_wgrad(const float* x, long sb, long st, long sf, co
   PE_LAUNCH_CHECK();
   return PE_OK;
 }
+#endif

@@ -278,21 +278,25 @@ static int gemm_nt_impl(const float* A, long lda, const float* B, long ldb, floa
   return launch_nt<Tile<128, 128, 2, 2>, MODE>(al, bl, ep, M, N, K, st);
 }
 
+#ifndef PE_F16_BUILD
 extern "C" int pe_gemm_nt(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
                           int K, const float* bias0, const float* bias1, int accumulate, void* stream) {
   return gemm_nt_impl<kNative>(A, lda, B, ldb, C, ldc, M, N, K, bias0, bias1, accumulate, stream);
 }
+#endif
 
-extern "C" int pe_gemm_nt_bf16(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M,
+extern "C" int PE_HALF(pe_gemm_nt)(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M,
                                int N, int K, const float* bias0, const float* bias1, int accumulate,
                                void* stream) {
   return gemm_nt_impl<kBf16>(A, lda, B, ldb, C, ldc, M, N, K, bias0, bias1, accumulate, stream);
 }
 
+#ifndef PE_F16_BUILD
 extern "C" int pe_gemm_nt_x3(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
                              int K, const float* bias0, const float* bias1, int accumulate, void* stream) {
   return gemm_nt_impl<kSplit>(A, lda, B, ldb, C, ldc, M, N, K, bias0, bias1, accumulate, stream);
 }
+#endif
 
 template <int MODE>
 static int gemm_nt_wf_impl(const float* A, long lda, const void* wfrag, float* C, long ldc, int M, int N, int K,
@@ -309,6 +313,7 @@ static int gemm_nt_wf_impl(const float* A, long lda, const void* wfrag, float* C
 }
 
 // Diagnostic (tools/ablate_gemm.py): the 128 x 192 x3 kernel with parts of its loop removed.  Timing only.
+#ifndef PE_F16_BUILD
 extern "C" int pe_gemm_nt_wf_ablate(int mask, const float* A, long lda, const void* wfrag, float* C, long ldc, int M,
                                     int N, int K, void* stream) {
   if (!A || !wfrag || !C || M <= 0 || N <= 0 || K <= 0 || (K & 31) || (N % 192)) return PE_E_ARG;
@@ -334,12 +339,14 @@ extern "C" int pe_gemm_nt_wf_x3(const float* A, long lda, const void* wfrag, flo
                                 int K, const float* bias0, const float* bias1, int accumulate, void* stream) {
   return gemm_nt_wf_impl<kSplit>(A, lda, wfrag, C, ldc, M, N, K, bias0, bias1, accumulate, stream);
 }
+#endif
 
-extern "C" int pe_gemm_nt_wf_bf16(const float* A, long lda, const void* wfrag, float* C, long ldc, int M, int N,
+extern "C" int PE_HALF(pe_gemm_nt_wf)(const float* A, long lda, const void* wfrag, float* C, long ldc, int M, int N,
                                   int K, const float* bias0, const float* bias1, int accumulate, void* stream) {
   return gemm_nt_wf_impl<kBf16>(A, lda, wfrag, C, ldc, M, N, K, bias0, bias1, accumulate, stream);
 }
 
+#ifndef PE_F16_BUILD
 extern "C" size_t pe_gemm_tn_workspace_bytes(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   size_t need = 0;
@@ -351,6 +358,7 @@ extern "C" size_t pe_gemm_tn_workspace_bytes(int M, int N, int K) {
   }
   return need;
 }
+#endif
 
 template <int MODE>
 static int gemm_tn_impl(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
@@ -368,6 +376,7 @@ static int gemm_tn_impl(const float* A, long lda, const float* B, long ldb, floa
   return launch_tn<128, 128, MODE>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, st);
 }
 
+#ifndef PE_F16_BUILD
 extern "C" int pe_gemm_tn(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
                           int K, int accumulate, float* workspace, size_t workspace_bytes, void* stream) {
   return gemm_tn_impl<kNative>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, stream);
@@ -377,8 +386,9 @@ extern "C" int pe_gemm_tn_x3(const float* A, long lda, const float* B, long ldb,
                              int K, int accumulate, float* workspace, size_t workspace_bytes, void* stream) {
   return gemm_tn_impl<kSplit>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, stream);
 }
+#endif
 
-extern "C" int pe_gemm_tn_bf16(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
+extern "C" int PE_HALF(pe_gemm_tn)(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
                                int K, int accumulate, float* workspace, size_t workspace_bytes, void* stream) {
   return gemm_tn_impl<kBf16>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, stream);
 }

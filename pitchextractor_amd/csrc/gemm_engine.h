@@ -160,14 +160,34 @@ __device__ __forceinline__ void nt_mainloop(AL& al, BL& bl, int K, float* As, fl
 // v_mfma_f32_32x32x16_bf16; accumulation, epilogue and every tensor in HBM stay fp32.
 // LDS images are [row][40] bf16 (32 + one 16-byte pad): lane (r, h) reads k = 16*kk + 8*h .. +7 of
 // row r with one ds_read_b128, which is exactly the 32x32x16 A/B operand layout.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+// The single-term ("mixed precision") pipelines exist for two 16-bit operand types: bf16 (the default build) and
+// fp16 = the reference's literal autocast dtype (trainer.py:64-102).  The fp16 form is the SAME source compiled a
+// second time with -DPE_F16_BUILD (pitchextractor_amd/build.py): only the conversion instruction and the MFMA
+// opcode differ, and that build exports only the pe_*_f16 entry points (PE_HALF names).  The three-term split
+// paths are bf16 by construction and are not exported from the fp16 build.
+#ifdef PE_F16_BUILD
+typedef _Float16 pe_half_t;
+#define PE_HALF(name) name##_f16
+#else
+typedef __bf16 pe_half_t;
+#define PE_HALF(name) name##_bf16
+#endif
+typedef pe_half_t bf16x8 __attribute__((ext_vector_type(8)));
+typedef pe_half_t bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int kLdsStrideH = kBK + 8;   // in bf16 elements
 
-__device__ __forceinline__ bf16x4 to_bf16x4(const float4& v) {
+__device__ __forceinline__ bf16x4 to_bf16x4(const float4& v) {     // RNE to the build's 16-bit operand type
   bf16x4 o;
-  o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+  o[0] = (pe_half_t)v.x; o[1] = (pe_half_t)v.y; o[2] = (pe_half_t)v.z; o[3] = (pe_half_t)v.w;
   return o;
+}
+
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+#ifdef PE_F16_BUILD
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
 }
 
 template <class TL, class AL, class BL>
@@ -217,7 +237,7 @@ __device__ __forceinline__ void nt_mainloop_bf16(AL& al, BL& bl, int K, float* A
       for (int i = 0; i < TL::TM; ++i)
 #pragma unroll
         for (int j = 0; j < TL::TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma_bf16(fa[i], fb[j], acc[i][j]);
     }
   }
 }
@@ -250,10 +270,6 @@ __device__ __forceinline__ Split3 split3(const float4& v) {
   o.mid = make_uint2(pack_hi16(r1[0], r1[1]), pack_hi16(r1[2], r1[3]));
   o.lo = make_uint2(pack_hi16(r2[0], r2[1]), pack_hi16(r2[2], r2[3]));
   return o;
-}
-
-__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
 // acc += a * b to fp32 accuracy, a and b given as their three bf16 terms

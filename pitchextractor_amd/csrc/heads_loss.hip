@@ -237,6 +237,22 @@ struct AdamArgs {
   float lr, beta1, beta2, eps, weight_decay, step_size, bc2_sqrt, grad_scale;
 };
 
+// GradScaler's inf / nan test (reference trainer.py:241-244 -> torch.amp.GradScaler.step): flag = 1 if any element
+// of the flat gradient buffer is not finite.  Every thread that sees one stores the same value: no atomics needed.
+__global__ __launch_bounds__(256) void nonfinite_kernel(const float* __restrict__ g, long n, int* __restrict__ flag) {
+  const long n4 = n >> 2;
+  bool bad = false;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(g)[i];
+    // exponent all ones <=> inf or nan
+    bad |= ((__float_as_uint(v.x) & 0x7f800000u) == 0x7f800000u) | ((__float_as_uint(v.y) & 0x7f800000u) == 0x7f800000u) |
+           ((__float_as_uint(v.z) & 0x7f800000u) == 0x7f800000u) | ((__float_as_uint(v.w) & 0x7f800000u) == 0x7f800000u);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3))
+    bad |= (__float_as_uint(g[(n4 << 2) + threadIdx.x]) & 0x7f800000u) == 0x7f800000u;
+  if (bad) *flag = 1;
+}
+
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, long n,
                                                     const AdamArgs a) {
@@ -360,6 +376,20 @@ extern "C" int pe_adamw_step(float* param, const float* grad, float* exp_avg, fl
   if (g < 1) g = 1;
   hipLaunchKernelGGL(adamw_kernel, dim3((int)g), dim3(256), 0, pe_stream(stream), param, grad, exp_avg, exp_avg_sq, n,
                      a);
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+
+extern "C" int pe_nonfinite_flag(const float* x, long n, int* flag, void* stream) {
+  if (!x || !flag || n < 0) return PE_E_ARG;
+  if (reinterpret_cast<uintptr_t>(x) & 15) return PE_E_UNSUPPORTED;
+  hipStream_t st = pe_stream(stream);
+  PE_CHECK_HIP(hipMemsetAsync(flag, 0, sizeof(int), st));
+  if (n == 0) return PE_OK;
+  long g = ((n >> 2) + 255) / 256;
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(nonfinite_kernel, dim3((int)g), dim3(256), 0, st, x, n, flag);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }

@@ -285,6 +285,7 @@ constexpr int kColsumParts = 256;
 
 }  // namespace
 
+#ifndef PE_F16_BUILD
 extern "C" int pe_lstm_fwd(int ncells, const float* const* whh, float* const* gates, float* const* y,
                            float* const* cbuf, const int* reverse, long ldy, int B, int T, int H, void* stream) {
   if (ncells < 1 || ncells > kMaxCells || !whh || !gates || !y || !cbuf || !reverse) return PE_E_ARG;
@@ -336,6 +337,7 @@ extern "C" size_t pe_lstm_whh_grad_workspace_bytes(int B, int T, int H) {
   }
   return need;
 }
+#endif
 
 // dW_hh[4H][H] = sum_{b,t} dgates[b][t][:]^T . y[b][t -/+ 1][:]   (y = this direction's output slice)
 template <int MODE>
@@ -362,6 +364,7 @@ static int whh_grad_impl(const float* dgates, const float* y, long ldy, float* d
   return PE_OK;
 }
 
+#ifndef PE_F16_BUILD
 extern "C" int pe_lstm_whh_grad(const float* dgates, const float* y, long ldy, float* dwhh, int B, int T, int H,
                                 int reverse, float* workspace, size_t workspace_bytes, void* stream) {
   return whh_grad_impl<kNative>(dgates, y, ldy, dwhh, B, T, H, reverse, workspace, workspace_bytes, stream);
@@ -371,15 +374,19 @@ extern "C" int pe_lstm_whh_grad_x3(const float* dgates, const float* y, long ldy
                                    int reverse, float* workspace, size_t workspace_bytes, void* stream) {
   return whh_grad_impl<kSplit>(dgates, y, ldy, dwhh, B, T, H, reverse, workspace, workspace_bytes, stream);
 }
+#endif
 
-extern "C" int pe_lstm_whh_grad_bf16(const float* dgates, const float* y, long ldy, float* dwhh, int B, int T, int H,
+extern "C" int PE_HALF(pe_lstm_whh_grad)(const float* dgates, const float* y, long ldy, float* dwhh, int B, int T, int H,
                                    int reverse, float* workspace, size_t workspace_bytes, void* stream) {
   return whh_grad_impl<kBf16>(dgates, y, ldy, dwhh, B, T, H, reverse, workspace, workspace_bytes, stream);
 }
 
+#ifndef PE_F16_BUILD
 extern "C" size_t pe_colsum_workspace_bytes(int cols) { return (size_t)kColsumParts * cols * sizeof(double); }
+#endif
 
 // out0[c] = out1[c] = sum_r x[r*ld + c]   (out1 optional: b_ih and b_hh share one gradient)
+#ifndef PE_F16_BUILD
 extern "C" int pe_colsum(const float* x, long rows, int cols, long ld, float* out0, float* out1, void* workspace,
                          size_t workspace_bytes, void* stream) {
   if (!x || !out0 || rows <= 0 || cols <= 0) return PE_E_ARG;
@@ -396,3 +403,4 @@ extern "C" int pe_colsum(const float* x, long rows, int cols, long ld, float* ou
   PE_LAUNCH_CHECK();
   return PE_OK;
 }
+#endif

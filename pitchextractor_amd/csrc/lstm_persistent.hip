@@ -134,8 +134,8 @@ __device__ __forceinline__ void split8(const float4& p, const float4& q, bf16x8 
 // mixed precision: 8 consecutive k rounded to bf16 (RNE)
 __device__ __forceinline__ bf16x8 round8(const float4& p, const float4& q) {
   bf16x8 o;
-  o[0] = (__bf16)p.x; o[1] = (__bf16)p.y; o[2] = (__bf16)p.z; o[3] = (__bf16)p.w;
-  o[4] = (__bf16)q.x; o[5] = (__bf16)q.y; o[6] = (__bf16)q.z; o[7] = (__bf16)q.w;
+  o[0] = (pe_half_t)p.x; o[1] = (pe_half_t)p.y; o[2] = (pe_half_t)p.z; o[3] = (pe_half_t)p.w;
+  o[4] = (pe_half_t)q.x; o[5] = (pe_half_t)q.y; o[6] = (pe_half_t)q.z; o[7] = (pe_half_t)q.w;
   return o;
 }
 constexpr int kTa[6] = {2, 1, 1, 0, 0, 0}, kTb[6] = {0, 1, 0, 1, 0, 2};
@@ -1052,18 +1052,22 @@ int sync_words(int ncells, int B) { return kCtrStride * (1 + 2 * ncells * ((B + 
 
 }  // namespace
 
+#ifndef PE_F16_BUILD
 extern "C" size_t pe_lstm_persistent_sync_bytes(int ncells, int B) {
   return (size_t)sync_words(ncells, B) * sizeof(unsigned);
 }
+#endif
 
 // 1 if the persistent kernels can run this shape on the current device (hidden size instantiated,
 // and the whole grid is co-resident at one workgroup per CU), else 0.
+#ifndef PE_F16_BUILD
 extern "C" int pe_lstm_persistent_supported(int ncells, int B, int H) {
   if (ncells < 1 || ncells > kMaxCells || B <= 0) return 0;
   if (!(H == 32 || H == 64 || H == 96 || H == 384)) return 0;
   const int grid = ncells * ((B + 63) / 64) * (H / 32);
   return grid <= device_cus() ? 1 : 0;
 }
+#endif
 
 static int lstm_fwd_persistent_impl(int terms, int ncells, const float* const* whh, float* const* gates,
                                     float* const* y, float* const* cbuf, const int* reverse, long ldy, int B, int T,
@@ -1104,6 +1108,7 @@ static int lstm_fwd_persistent_impl(int terms, int ncells, const float* const* w
   return PE_E_UNSUPPORTED;
 }
 
+#ifndef PE_F16_BUILD
 extern "C" int pe_lstm_fwd_persistent(int ncells, const float* const* whh, float* const* gates, float* const* y,
                                       float* const* cbuf, const int* reverse, long ldy, int B, int T, int H,
                                       unsigned* sync, void* stream) {
@@ -1115,6 +1120,7 @@ extern "C" int pe_lstm_fwd_persistent_x3(int ncells, const float* const* whh, fl
                                          unsigned* sync, void* stream) {
   return lstm_fwd_persistent_impl(3, ncells, whh, gates, y, cbuf, reverse, ldy, B, T, H, sync, stream);
 }
+#endif
 
 static int lstm_bwd_persistent_impl(int terms, int ncells, const float* const* whh_t, float* const* gates,
                                     const float* const* cbuf, const float* const* dy, const int* reverse, long lddy,
@@ -1144,6 +1150,7 @@ static int lstm_bwd_persistent_impl(int terms, int ncells, const float* const* w
   return PE_E_UNSUPPORTED;
 }
 
+#ifndef PE_F16_BUILD
 extern "C" int pe_lstm_bwd_persistent(int ncells, const float* const* whh_t, float* const* gates,
                                       const float* const* cbuf, const float* const* dy, const int* reverse,
                                       long lddy, int B, int T, int H, unsigned* sync, void* stream) {
@@ -1155,14 +1162,15 @@ extern "C" int pe_lstm_bwd_persistent_x3(int ncells, const float* const* whh_t, 
                                          long lddy, int B, int T, int H, unsigned* sync, void* stream) {
   return lstm_bwd_persistent_impl(3, ncells, whh_t, gates, cbuf, dy, reverse, lddy, B, T, H, sync, stream);
 }
+#endif
 
-extern "C" int pe_lstm_fwd_persistent_bf16(int ncells, const float* const* whh, float* const* gates, float* const* y,
+extern "C" int PE_HALF(pe_lstm_fwd_persistent)(int ncells, const float* const* whh, float* const* gates, float* const* y,
                                            float* const* cbuf, const int* reverse, long ldy, int B, int T, int H,
                                            unsigned* sync, void* stream) {
   return lstm_fwd_persistent_impl(1, ncells, whh, gates, y, cbuf, reverse, ldy, B, T, H, sync, stream);
 }
 
-extern "C" int pe_lstm_bwd_persistent_bf16(int ncells, const float* const* whh_t, float* const* gates,
+extern "C" int PE_HALF(pe_lstm_bwd_persistent)(int ncells, const float* const* whh_t, float* const* gates,
                                            const float* const* cbuf, const float* const* dy, const int* reverse,
                                            long lddy, int B, int T, int H, unsigned* sync, void* stream) {
   return lstm_bwd_persistent_impl(1, ncells, whh_t, gates, cbuf, dy, reverse, lddy, B, T, H, sync, stream);

@@ -99,6 +99,9 @@ def _s():
 # accumulate in fp32; the persistent LSTM recurrences round W_hh and h to bf16 as well (cell state fp32);
 # attention and everything in HBM stay fp32.  False is the parity mode.
 MATMUL_BF16 = False
+# 16-bit operand type of that mode: "bf16" (default: fp32 exponent range, no loss scaling needed) or "f16" (the
+# reference's literal autocast dtype; Trainer(amp_dtype="fp16") drives it together with a GradScaler)
+HALF_DTYPE = "bf16"
 # How fp32 products run (always, for the weight-gradient products; when MATMUL_BF16 is off for the rest):
 #   "x3"     every fp32 operand is split exactly into three bf16 terms and six cross products are
 #            accumulated in fp32 on the bf16 MFMA pipe (16x the fp32 MFMA rate on gfx950); measured
@@ -112,7 +115,7 @@ def _tn_suffix():
     otherwise fp32-accurate (native or three-term split)."""
     _chk(FP32_MATMUL in ("native", "x3"), "ops.FP32_MATMUL must be 'native' or 'x3'")
     if MATMUL_BF16:
-        return "_bf16"
+        return "_" + HALF_DTYPE
     return "_x3" if FP32_MATMUL == "x3" else ""
 
 
@@ -122,13 +125,13 @@ LSTM_X3 = {"fwd": os.environ.get("PE_LSTM_X3_FWD", "1") == "1", "bwd": os.enviro
 
 def _lstm_suffix(which):
     if MATMUL_BF16:
-        return "_bf16"                 # mixed precision: bf16 recurrent products (as autocast runs nn.LSTM)
+        return "_" + HALF_DTYPE        # mixed precision: 16-bit recurrent products (as autocast runs nn.LSTM)
     return "_x3" if (FP32_MATMUL == "x3" and LSTM_X3[which]) else ""
 
 
 def _nt_suffix():
     if MATMUL_BF16:
-        return "_bf16"
+        return "_" + HALF_DTYPE
     if FP32_MATMUL == "x3":
         return "_x3"
     _chk(FP32_MATMUL == "native", "ops.FP32_MATMUL must be 'native' or 'x3'")
@@ -138,17 +141,19 @@ def _nt_suffix():
 class matmul_bf16:
     """``with ops.matmul_bf16(True): ...`` -- the autocast-like scope Trainer.run opens for a mixed-precision step."""
 
-    def __init__(self, enabled=True):
-        self.enabled = bool(enabled)
+    def __init__(self, enabled=True, dtype="bf16"):
+        _chk(dtype in ("bf16", "f16"), "matmul_bf16: dtype must be 'bf16' or 'f16'")
+        self.enabled, self.dtype = bool(enabled), dtype
 
     def __enter__(self):
-        global MATMUL_BF16
-        self._prev, MATMUL_BF16 = MATMUL_BF16, self.enabled
+        global MATMUL_BF16, HALF_DTYPE
+        self._prev = (MATMUL_BF16, HALF_DTYPE)
+        MATMUL_BF16, HALF_DTYPE = self.enabled, self.dtype
         return self
 
     def __exit__(self, *exc):
-        global MATMUL_BF16
-        MATMUL_BF16 = self._prev
+        global MATMUL_BF16, HALF_DTYPE
+        MATMUL_BF16, HALF_DTYPE = self._prev
         return False
 
 
@@ -220,11 +225,12 @@ CONV_WFRAG = os.environ.get("PE_CONV_WFRAG", "1") == "1"
 
 
 class PackedWeight:
-    """One packed 3x3 weight: ``fp32`` [N, 9*C] (native MFMA path, fallback shapes) and, in the x3 / bf16 modes,
-    ``frag`` = the same matrix as bf16 MFMA fragments (``terms`` = 3 exact terms or 1 rounded term)."""
+    """One packed 3x3 weight: ``fp32`` [N, 9*C] (native MFMA path, fallback shapes) and, in the x3 / bf16 / f16 modes,
+    ``frag`` = the same matrix as 16-bit MFMA fragments (``terms`` = 3 exact bf16 terms or 1 rounded term of
+    ``half``)."""
 
-    def __init__(self, fp32, frag=None, terms=0):
-        self.fp32, self.frag, self.terms = fp32, frag, terms
+    def __init__(self, fp32, frag=None, terms=0, half=None):
+        self.fp32, self.frag, self.terms, self.half = fp32, frag, terms, half
 
     @property
     def shape(self):
@@ -238,13 +244,16 @@ def wfrag_pack(w2d, terms):
     nbytes = lib.pe_wfrag_bytes(N, K, terms)
     _chk(nbytes > 0, "wfrag_pack: K must be a multiple of 16 and terms 1 or 3")
     out = torch.empty((nbytes,), dtype=torch.uint8, device=w2d.device)
-    _call("pe_wfrag_pack", w2d.data_ptr(), ld, N, K, int(terms), out.data_ptr(), _s())
+    if terms == 1 and MATMUL_BF16 and HALF_DTYPE == "f16":
+        _call("pe_wfrag_pack_f16", w2d.data_ptr(), ld, N, K, out.data_ptr(), _s())
+    else:
+        _call("pe_wfrag_pack", w2d.data_ptr(), ld, N, K, int(terms), out.data_ptr(), _s())
     return out
 
 
 def _mode_terms():
     sfx = _nt_suffix()
-    return 3 if sfx == "_x3" else 1 if sfx == "_bf16" else 0
+    return 3 if sfx == "_x3" else 1 if sfx in ("_bf16", "_f16") else 0
 
 
 def conv3x3_repack(w, want_fwd=True, want_dgrad=True):
@@ -261,7 +270,7 @@ def conv3x3_repack(w, want_fwd=True, want_dgrad=True):
         if t is None:
             out.append(None)
         elif terms and t.shape[1] % 16 == 0:
-            out.append(PackedWeight(t, wfrag_pack(t, terms), terms))
+            out.append(PackedWeight(t, wfrag_pack(t, terms), terms, HALF_DTYPE if terms == 1 else None))
         else:
             out.append(PackedWeight(t))
     return out[0], out[1]
@@ -282,7 +291,7 @@ def conv3x3_fwd(x, w_packed, out=None, accumulate=False):
     _chk(_dense(out, "out").shape == (B, T, F, N), "conv3x3_fwd: out shape")
     sfx = _nt_suffix()
     if (pw.frag is not None and pw.terms == _mode_terms() and CONV_WFRAG
-            and _lib.load().pe_conv3x3_wf_supported(F, Cc, N)):
+            and (pw.terms != 1 or pw.half == HALF_DTYPE) and _lib.load().pe_conv3x3_wf_supported(F, Cc, N)):
         _call("pe_conv3x3_fwd_wf" + sfx, x.data_ptr(), pw.frag.data_ptr(), out.data_ptr(), B, T, F, Cc, N,
               int(bool(accumulate)), _s(), work=2.0 * B * T * F * N * 9 * Cc)
         return out
@@ -660,6 +669,16 @@ def f0_bins_ce_loss(logits, f0, sil_pred, sil, lambda_f0, grad_scale=1.0, want_g
           float(lambda_f0), R, float(grad_scale), out4.data_ptr(), _lib.ptr(d_logits), C, _lib.ptr(d_sil),
           ws.data_ptr(), ws.numel(), _s())
     return out4, d_logits, d_sil
+
+
+def nonfinite_flag(x, flag=None):
+    """int32 device scalar: 1 if any element of the flat float32 tensor ``x`` is inf / nan (GradScaler's test)."""
+    x = _dense(x, "x")
+    if flag is None:
+        flag = torch.empty((1,), dtype=torch.int32, device=x.device)
+    _chk(flag.is_cuda and flag.dtype == torch.int32 and flag.numel() == 1, "flag: int32 device scalar")
+    _call("pe_nonfinite_flag", x.data_ptr(), x.numel(), flag.data_ptr(), _s())
+    return flag
 
 
 def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):

@@ -30,6 +30,7 @@ class FusedAdamW(Optimizer):
                         maximize=False, foreach=None, capturable=False, differentiable=False, fused=None)
         super().__init__(params, defaults)
         self.grad_scale = 1.0
+        self.loss_scale_inv = 1.0            # Trainer's GradScaler: gradients are unscaled inside the kernel
         self._flat_plans = {}
 
     # ---- flat-buffer detection -----------------------------------------------------------
@@ -107,7 +108,7 @@ class FusedAdamW(Optimizer):
                 st0 = self.state[params[0]]
                 step = int(st0["step"].item()) + 1
                 ops.adamw_step(plan["flat_p"], plan["flat_g"], plan["m"], plan["v"], group["lr"], beta1, beta2,
-                               group["eps"], group["weight_decay"], step, self.grad_scale)
+                               group["eps"], group["weight_decay"], step, self.grad_scale * self.loss_scale_inv)
                 new_step = torch.tensor(float(step))
                 for p in params:
                     self.state[p]["step"] = new_step
@@ -124,7 +125,7 @@ class FusedAdamW(Optimizer):
                     raise RuntimeError("FusedAdamW needs contiguous parameters and gradients")
                 ops.adamw_step(pd.view(-1), p.grad.view(-1), st["exp_avg"].view(-1), st["exp_avg_sq"].view(-1),
                                group["lr"], beta1, beta2, group["eps"], group["weight_decay"], step,
-                               self.grad_scale)
+                               self.grad_scale * self.loss_scale_inv)
                 st["step"] = torch.tensor(float(step))
         return loss
 

@@ -28,6 +28,28 @@ except Exception:  # pragma: no cover
         return it
 
 
+class GradScaler:
+    """Dynamic loss scaling with torch.amp.GradScaler's defaults and update rule (reference trainer.py:64-102 builds
+    one whenever AMP is on): scale 2^16, halved after a step whose gradients hold inf / nan (that optimizer step is
+    skipped), doubled after 2000 consecutive clean steps.  Like the reference, its state is not checkpointed."""
+
+    def __init__(self, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        self.scale, self.growth_factor, self.backoff_factor = float(init_scale), growth_factor, backoff_factor
+        self.growth_interval, self._good_steps = int(growth_interval), 0
+        self.skipped_steps = 0
+
+    def update(self, found_inf: bool):
+        if found_inf:
+            self.scale *= self.backoff_factor
+            self._good_steps = 0
+            self.skipped_steps += 1
+        else:
+            self._good_steps += 1
+            if self._good_steps == self.growth_interval:
+                self.scale *= self.growth_factor
+                self._good_steps = 0
+
+
 class Trainer(object):
     """Keyword-compatible with the reference constructor (trainer.py:33-48), plus ``mel_transform`` (on-device
     mel for raw-audio batches) and ``data_parallel`` (a ``distributed.GradientAllReduce``)."""
@@ -35,7 +57,7 @@ class Trainer(object):
     def __init__(self, model=None, criterion=None, optimizer=None, scheduler=None, config={}, loss_config={},
                  device=torch.device("cpu"), logger=logger, train_dataloader=None, val_dataloader=None,
                  initial_steps=0, initial_epochs=0, use_mixed_precision=False, gradient_checkpointing=False,
-                 checkpoint_use_reentrant=None, mel_transform=None, data_parallel=None):
+                 checkpoint_use_reentrant=None, mel_transform=None, data_parallel=None, amp_dtype="bf16"):
         kind = torch.device(device).type if isinstance(device, (str, torch.device)) else "cpu"
         if kind != "cuda":
             raise RuntimeError("pitchextractor_amd.Trainer runs the HIP path only: device must be a HIP "
@@ -55,15 +77,23 @@ class Trainer(object):
         # gradient, Linear and LSTM input projections and their weight gradients, and the persistent LSTM
         # recurrences (W_hh and the h / dgates rows) -- takes bf16-rounded operands and accumulates in fp32;
         # attention scores, normalisations, losses, the LSTM cell state and every tensor in HBM stay fp32.
-        # bf16 keeps the fp32 exponent, so no GradScaler is needed; ``amp_dtype="fp16"`` selects the
-        # reference's literal autocast default (fp16 operands + dynamic loss scaling, trainer.py:64-102,241-244).
+        # bf16 (default) keeps the fp32 exponent, so no GradScaler is needed; ``amp_dtype="fp16"`` selects the
+        # reference's literal autocast default: fp16 operands + GradScaler (trainer.py:64-102,241-244) -- the loss
+        # gradients are scaled, non-finite gradients skip the update, the scale backs off / grows.
         # gradient_checkpointing: the reference's single whole-model segment (trainer.py:226-233) -- the forward
         # keeps no activations and backward recomputes it (JDCNet.checkpoint_forward).
         self.use_amp = bool(use_mixed_precision)
+        amp_dtype = {"fp16": "f16", "float16": "f16", "half": "f16", "f16": "f16", "bf16": "bf16",
+                     "bfloat16": "bf16"}.get(str(amp_dtype).lower())
+        if amp_dtype is None:
+            raise ValueError("amp_dtype must be 'bf16' or 'fp16'")
+        self.amp_dtype = amp_dtype
+        self.scaler = GradScaler() if (self.use_amp and amp_dtype == "f16") else None
         self.gradient_checkpointing = bool(gradient_checkpointing)
         self.gradient_checkpoint_use_reentrant = checkpoint_use_reentrant
         if self.use_amp:
-            logger.info("mixed_precision: bf16 MFMA operands for every matmul-shaped product, fp32 accumulate and state")
+            logger.info("mixed_precision: %s MFMA operands for every matmul-shaped product, fp32 accumulate and state%s",
+                        "fp16" if amp_dtype == "f16" else "bf16", " + dynamic loss scaling" if self.scaler else "")
         if self.gradient_checkpointing:
             logger.info("gradient_checkpointing: whole-model segment, forward recomputed in backward")
 
@@ -143,7 +173,7 @@ class Trainer(object):
             x = self.mel_transform.log_mel_batch(x, max_frames=f0.shape[-1])
         return x, f0.contiguous().float(), sil.contiguous().float()
 
-    def _loss(self, f0_pred, sil_pred, f0, sil, want_grads):
+    def _loss(self, f0_pred, sil_pred, f0, sil, want_grads, grad_scale=1.0):
         """num_class == 1: the reference's regression loss (train.py:104-106).  num_class > 1 has no loss in the
         reference; this build defines the CREPE-style bin classification of SURVEY 8f N4 for it
         (ops.f0_bins_ce_loss: voiced frames only, lambda_f0 * CE + BCE)."""
@@ -151,18 +181,20 @@ class Trainer(object):
         if f0_pred.shape[-1] != 1:
             C = f0_pred.shape[-1]
             out4, d_logits, d_sil = ops.f0_bins_ce_loss(f0_pred.detach().reshape(-1, C), f0.reshape(-1),
-                                                        sil_pred.detach().reshape(-1), sil.reshape(-1), lam, 1.0,
-                                                        want_grads)
+                                                        sil_pred.detach().reshape(-1), sil.reshape(-1), lam,
+                                                        grad_scale, want_grads)
             return out4[:3], d_logits, d_sil
         return ops.f0_sil_loss(f0_pred.detach().reshape(-1), f0.reshape(-1), sil_pred.detach().reshape(-1),
-                               sil.reshape(-1), lam, 1.0, want_grads)
+                               sil.reshape(-1), lam, grad_scale, want_grads)
 
     def _forward_backward(self, x, f0, sil):
-        with ops.matmul_bf16(self.use_amp):
+        with ops.matmul_bf16(self.use_amp, self.amp_dtype):
             self.model.checkpoint_forward = self.gradient_checkpointing
             try:
                 f0_pred, sil_pred = self.model(x.transpose(-1, -2))
-                out3, d_f0, d_sil = self._loss(f0_pred, sil_pred, f0, sil, True)
+                # scaler.scale(loss).backward(): the loss kernel multiplies its gradients by the scale
+                out3, d_f0, d_sil = self._loss(f0_pred, sil_pred, f0, sil, True,
+                                               self.scaler.scale if self.scaler else 1.0)
                 torch.autograd.backward([f0_pred, sil_pred], [d_f0.view_as(f0_pred), d_sil.view_as(sil_pred)])
             finally:
                 self.model.checkpoint_forward = False
@@ -191,7 +223,19 @@ class Trainer(object):
         if self._lstm_fault(x.device):                     # before the update: redo the step on the safe kernels
             self.optimizer.zero_grad(set_to_none=True)
             out3 = self._forward_backward(x, f0, sil)
-        self.optimizer.step()
+        if self.scaler is None:
+            self.optimizer.step()
+        else:                                              # scaler.step(optimizer); scaler.update()  (trainer.py:242-244)
+            found = bool(ops.nonfinite_flag(self.model.flat_gradients()).item())
+            if self.data_parallel is not None and self.data_parallel.world > 1:
+                found = self.data_parallel.any_rank(found)
+            if not found:
+                self.optimizer.loss_scale_inv = 1.0 / self.scaler.scale      # unscale inside the fused AdamW
+                try:
+                    self.optimizer.step()
+                finally:
+                    self.optimizer.loss_scale_inv = 1.0
+            self.scaler.update(found)
         self.scheduler.step()
         loss, loss_f0, loss_sil = out3.tolist()            # one device->host copy for all three scalars
         return {"loss": loss, "f0": loss_f0, "sil": loss_sil}
@@ -216,10 +260,10 @@ class Trainer(object):
     @torch.no_grad()
     def _eval_step(self, batch):
         x, f0, sil = self._inputs(batch)
-        with ops.matmul_bf16(self.use_amp):
+        with ops.matmul_bf16(self.use_amp, self.amp_dtype):
             f0_pred, sil_pred = self.model(x.transpose(-1, -2))
         if self._lstm_fault(x.device):
-            with ops.matmul_bf16(self.use_amp):
+            with ops.matmul_bf16(self.use_amp, self.amp_dtype):
                 f0_pred, sil_pred = self.model(x.transpose(-1, -2))
         out3, _, _ = self._loss(f0_pred, sil_pred, f0, sil, False)
         loss, loss_f0, loss_sil = out3.tolist()

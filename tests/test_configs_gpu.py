@@ -138,3 +138,41 @@ def test_gradient_checkpointing_recomputes_and_matches_plain_step(hip_device, he
             init = state[k].to(hip_device)
             twice = init + (1 - 0.9 ** 2) / 0.1 * (s0[k] - init)           # r <- 0.9 r + 0.1 s, applied twice
             assert torch.allclose(s1[k], twice, rtol=1e-5, atol=1e-7), k
+
+
+def test_fp16_gradscaler_mode(hip_device):
+    """training.precision: fp16 = the reference's literal AMP (trainer.py:64-102,241-244): fp16 operands + GradScaler.
+    12 optimiser steps track the fp32 CPU oracle trainer within 2 %; a step whose gradients overflow is skipped
+    (parameters and AdamW moments untouched, scheduler still advances) and halves the scale; 3 clean steps at
+    growth_interval = 3 double it."""
+    from tests.golden.make_golden import training_batches
+    state = model_ref.seeded_state(21)
+    net = JDCNet(num_class=1, sequence_model_config=dict(SEQ_CFG))
+    net.load_state_dict(state, strict=True)
+    net = net.to(hip_device).train()
+    net.block_dropout = 0.0
+    tr = _trainer(net, use_mixed_precision=True, amp_dtype="fp16")
+    assert tr.scaler is not None and tr.scaler.scale == 65536.0
+    torch.set_num_threads(16)
+    cpu = train_ref.CpuTrainer(state, dict(SEQ_CFG), max_lr=3e-4, total_steps=800, lambda_f0=0.1)
+    batches = list(training_batches(12))
+    for i, batch in enumerate(batches):
+        got, ref = tr.run(batch), cpu.run(batch)
+        assert abs(got["loss"] - ref["loss"]) <= 2e-2 * abs(ref["loss"]), (i, got, ref)
+    assert tr.scaler.skipped_steps == 0 and tr.scaler.scale == 65536.0
+    # overflow: a scale that pushes the loss gradients past fp32 range -> inf gradients -> skipped step
+    before = net.flat_parameters.detach().clone()
+    lr_before = tr._get_lr()
+    tr.scaler.scale = 3.0e38
+    tr.run(batches[0])
+    assert tr.scaler.skipped_steps == 1 and tr.scaler.scale == 1.5e38
+    assert torch.equal(net.flat_parameters.detach(), before)            # update skipped ...
+    assert tr._get_lr() != lr_before                                    # ... the scheduler stepped (trainer.py:248)
+    tr.scaler.scale, tr.scaler.growth_interval, tr.scaler._good_steps = 1024.0, 3, 0
+    for batch in batches[:3]:
+        tr.run(batch)
+    assert tr.scaler.scale == 2048.0 and not torch.equal(net.flat_parameters.detach(), before)
+    # bf16 mode has no scaler; unknown dtypes are refused
+    assert _trainer(net, use_mixed_precision=True).scaler is None
+    with pytest.raises(ValueError):
+        _trainer(net, use_mixed_precision=True, amp_dtype="fp8")

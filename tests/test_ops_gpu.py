@@ -519,3 +519,51 @@ def test_adamw_matches_torch(hip_device):
         torch.testing.assert_close(p.cpu(), ref_p.detach(), rtol=2e-6, atol=1e-7)
         torch.testing.assert_close(m.cpu(), opt.state[ref_p]["exp_avg"], rtol=2e-6, atol=1e-7)  # fma contraction: 1 ulp at |m| ~ 0.3
         torch.testing.assert_close(v.cpu(), opt.state[ref_p]["exp_avg_sq"], rtol=2e-6, atol=1e-10)
+
+
+# ------------------------------------------------------------------ fp16 operand mode (reference autocast dtype)
+def f16r(t):
+    return t.to(torch.float16).to(torch.float64)
+
+
+def test_fp16_operand_products(hip_device):
+    """The *_f16 entry points (same kernels compiled for IEEE half): products equal the fp64 product of the
+    fp16-rounded operands to fp32 accumulation accuracy -- GEMM NT / TN, 3x3 conv forward / weight gradient with
+    both weight paths."""
+    A, B = rnd(300, 384, seed=1), rnd(1536, 384, seed=2)
+    with ops.matmul_bf16(True, "f16"):
+        close(ops.gemm_nt(A.to(hip_device), B.to(hip_device)), f16r(A) @ f16r(B).T)
+        P, Q = rnd(4000, 128, seed=3), rnd(4000, 192, seed=4)
+        close(ops.gemm_tn(P.to(hip_device), Q.to(hip_device)), f16r(P).T @ f16r(Q), tol=2e-5)
+        x, w = rnd(2, 64, 12, 10, seed=5), rnd(128, 64, 3, 3, seed=6, scale=0.1)
+        ref = F.conv2d(f16r(x), f16r(w), padding=1)
+        for frag in (True, False):
+            prev, ops.CONV_WFRAG = ops.CONV_WFRAG, frag
+            try:
+                wf, _ = ops.conv3x3_repack(w.to(hip_device))
+                assert (wf.frag is not None) == frag
+                close(nchw(ops.conv3x3_fwd(nhwc(x).to(hip_device), wf)), ref)
+            finally:
+                ops.CONV_WFRAG = prev
+        dy = rnd(2, 128, 12, 10, seed=7)
+        dw = torch.empty(128, 64, 3, 3, device=hip_device)
+        xr, dyr = f16r(x).requires_grad_(False), f16r(dy)
+        wref = torch.zeros(128, 64, 3, 3, dtype=torch.float64, requires_grad=True)
+        F.conv2d(xr, wref, padding=1).backward(dyr)
+        close(ops.conv3x3_wgrad(nhwc(x).to(hip_device), nhwc(dy).to(hip_device), dw), wref.grad, tol=2e-5)
+    assert ops.MATMUL_BF16 is False and ops.HALF_DTYPE == "bf16"
+    # fp16 has 3 more significand bits than bf16: closer to the fp32 product
+    with ops.matmul_bf16(True, "bf16"):
+        e_bf = (ops.gemm_nt(A.to(hip_device), B.to(hip_device)).cpu().double() - A.double() @ B.double().T).abs().max()
+    with ops.matmul_bf16(True, "f16"):
+        e_f16 = (ops.gemm_nt(A.to(hip_device), B.to(hip_device)).cpu().double() - A.double() @ B.double().T).abs().max()
+    assert e_f16 < 0.3 * e_bf
+
+
+def test_nonfinite_flag(hip_device):
+    g = rnd(100003, seed=1).to(hip_device)
+    assert int(ops.nonfinite_flag(g).item()) == 0
+    for pos, val in ((0, float("inf")), (77777, float("nan")), (100002, float("-inf"))):
+        h = g.clone()
+        h[pos] = val
+        assert int(ops.nonfinite_flag(h).item()) == 1

@@ -126,6 +126,7 @@ def main(config_path):
                       train_dataloader=train_dataloader, val_dataloader=val_dataloader,
                       loss_config=config["loss_params"], logger=logger,
                       use_mixed_precision=training_config.get("mixed_precision", True),
+                      amp_dtype=training_config.get("precision", "bf16"),
                       gradient_checkpointing=training_config.get("gradient_checkpointing", False),
                       checkpoint_use_reentrant=training_config.get("gradient_checkpointing_use_reentrant"),
                       data_parallel=dp)
