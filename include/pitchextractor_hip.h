@@ -150,6 +150,20 @@ int pe_conv3x3_c1_fwd(const float* x, long sb, long st, long sf, const float* w_
 int pe_conv3x3_c1_wgrad(const float* x, long sb, long st, long sf, const float* dy, float* dw_oihw,
                         int B, int T, int F, float* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- fused self-attention (model.py:231-239: nn.MultiheadAttention inside TransformerEncoderLayer) -------------
+ * qkv [B*T][ld_qkv] packed projections (Q | K | V, head h at columns h*dh of each part); o [B*T][ld_o] merged
+ * heads; lse [B*H*T]; masks [B*H*T][T] bytes (1 = kept), element quad i = row * T/4 + key/4 draws Philox counter
+ * offset + i exactly like pe_dropout_fwd on the (B*H*T) x T probability matrix.  One workgroup per (batch, head),
+ * scores stay in registers; the backward recomputes them from lse.  pe_attn_supported: 1 for T = 192, dh = 64
+ * (other shapes: pe_bgemm + pe_softmax_*). */
+int pe_attn_supported(int T, int dh);
+int pe_attn_fwd(const float* qkv, long ld_qkv, float* o, long ld_o, float* lse, const unsigned char* mask_in,
+                unsigned char* mask_out, int B, int T, int H, int dh, float scale, float p_drop,
+                unsigned long long seed, unsigned long long offset, void* stream);
+int pe_attn_bwd(const float* qkv, long ld_qkv, const float* o, const float* d_o, long ld_o, const float* lse,
+                const unsigned char* mask, float* dqkv, int B, int T, int H, int dh, float scale, float p_drop,
+                void* stream);
+
 /* ---- fp16 operands (the reference's autocast default dtype, trainer.py:64-102) -------------------------------
  * Same contracts as the *_bf16 entry points above with operands rounded (RNE) to IEEE half instead of bf16 and
  * multiplied by v_mfma_f32_32x32x16_f16; accumulation and every tensor in memory stay fp32.  fp16 has 5 exponent

@@ -97,6 +97,9 @@ PROTOTYPES = {
     "pe_head_bwd": (_i, [_p, _l, _p, _p, _i, _p, _l, _p, _p, _l, _i, _p, _z, _p]),
     "pe_f0_sil_loss": (_i, [_p, _p, _p, _p, _f, _l, _f, _p, _p, _p, _p]),
     "pe_bgemm": (_i, [_i, _p, _l, _l, _l, _p, _l, _l, _l, _p, _l, _l, _l, _i, _i, _i, _i, _i, _f, _i, _p]),
+    "pe_attn_supported": (_i, [_i, _i]),
+    "pe_attn_fwd": (_i, [_p, _l, _p, _l, _p, _p, _p, _i, _i, _i, _i, _f, _f, _u64, _u64, _p]),
+    "pe_attn_bwd": (_i, [_p, _l, _p, _p, _l, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p]),
     "pe_softmax_fwd": (_i, [_p, _l, _i, _f, _p]),
     "pe_softmax_bwd": (_i, [_p, _p, _l, _i, _f, _p]),
     "pe_layernorm_fwd": (_i, [_p, _p, _p, _i, _p, _p, _f, _p, _p, _p, _p, _l, _i, _p]),

@@ -1,0 +1,390 @@
+// Fused self-attention of nn.TransformerEncoderLayer (reference model.py:231-239; torch's MultiheadAttention:
+// softmax(Q K^T / sqrt(dh)) -> dropout -> . V per head) for the geometry of this model: T = 192 frames, dh = 64.
+//
+// The unfused path materialises the (B*H*T) x T probability matrix in HBM (302 MB per layer and branch at B = 256)
+// and walks it five times forward and six times backward.  Here one workgroup owns one (batch, head): its Q / K / V
+// (48 KB each, fp32) sit in LDS or registers, scores never leave the register file, and what reaches HBM is O, the
+// per-row log-sum-exp (768 B per head) and, when dropout is live, the 1-byte keep mask the parity tests export.
+//
+// Arithmetic: exact fp32 on v_mfma_f32_16x16x4_f32 (attention is 3 % of the step's FLOPs; the operands change every
+// step, so a three-term bf16 split would cost more LDS than it saves MFMA time).  MFMA maps (CDNA guide section 3):
+// A lane l = A[i = l & 15][k = l >> 4], B lane l = B[k = l >> 4][j = l & 15], C/D lane l reg r = C[4 (l >> 4) + r][l & 15].
+//
+// "Accumulator as the next operand": a 16 x 16 result X has its column on the lane and rows 4g .. 4g+3 in the four
+// registers of lane group g, which is exactly the B-operand layout of a following MFMA that sums over X's ROW index:
+// register q of X feeds an MFMA whose k-slot g means row 4g + q, and the A operand reads the matching rows.  So the
+// products that sum over the score tile's rows take it straight from the registers:
+//     forward:   S^T = K Q^T  (keys x queries)  ->  O^T  = V^T P^T        (sum over keys)
+//     backward:  S   = Q K^T  (queries x keys)  ->  dV^T = dO^T Pd, dK^T = Q^T dS   (sum over queries)
+//                S^T again (keys x queries)     ->  dQ^T = K^T dS^T       (sum over keys)
+// and no score tile is ever transposed through LDS.  The backward recomputes S twice (two kernels) instead:
+// deterministic, no atomics, no cross-workgroup reduction.
+#include "common.h"
+
+namespace {
+
+constexpr int kDh = 64;
+constexpr int kStr = 68;                 // LDS row stride in floats (64 + one 16-byte pad)
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4v mfma16(float a, float b, f32x4v c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+struct AttnArgs {
+  const float* qkv;          // [B*T][ld_qkv]: Q at col h*64, K at D + h*64, V at 2D + h*64
+  long ld_qkv;
+  int D;                     // H * 64
+  float* o;                  // forward out / backward in: [B*T][ld_o], head h at col h*64
+  long ld_o;
+  float* lse;                // [B*H*T] log-sum-exp of the scaled scores
+  const uint8_t* mask_in;    // optional [B*H*T][T] keep mask to replay
+  uint8_t* mask_out;         // optional, written when dropout is live
+  const float* d_o;          // backward: gradient of o
+  float* dqkv;               // backward out, same layout as qkv
+  const uint8_t* mask;       // backward: the forward's keep mask (NULL: no dropout)
+  int B, H;
+  float scale, p_drop, keep_scale;
+  unsigned long long seed, offset;
+};
+
+// stage a [T][64] fp32 matrix (global row stride ld) into LDS rows of kStr floats
+template <int T>
+__device__ __forceinline__ void stage64(const float* __restrict__ src, long ld, float* dst) {
+  for (int idx = threadIdx.x; idx < T * 16; idx += 256) {
+    const int t = idx >> 4, c4 = (idx & 15) * 4;
+    *reinterpret_cast<float4*>(dst + t * kStr + c4) = *reinterpret_cast<const float4*>(src + (long)t * ld + c4);
+  }
+}
+
+// delta[q] = sum_d dO[q][d] * O[q][d]  (16 lanes per row, one float4 each)
+template <int T>
+__device__ __forceinline__ void row_dots(const float* __restrict__ a, long lda, const float* __restrict__ b, long ldb,
+                                         float* out) {
+  for (int idx = threadIdx.x; idx < T * 16; idx += 256) {
+    const int t = idx >> 4, c4 = (idx & 15) * 4;
+    const float4 x = *reinterpret_cast<const float4*>(a + (long)t * lda + c4);
+    const float4 y = *reinterpret_cast<const float4*>(b + (long)t * ldb + c4);
+    float s = x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+    if ((idx & 15) == 0) out[t] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int T>
+__global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const AttnArgs a) {
+  constexpr int NT = T / 16;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ks = smem;
+  float* Vs = Ks + T * kStr;
+  float* Qs = Vs + T * kStr;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
+  const float* base = a.qkv + (long)b * T * a.ld_qkv + h * kDh;
+  stage64<T>(base, a.ld_qkv, Qs);
+  stage64<T>(base + a.D, a.ld_qkv, Ks);
+  stage64<T>(base + 2 * a.D, a.ld_qkv, Vs);
+  __syncthreads();
+  const float c2 = a.scale * 1.44269504088896340736f;
+  const bool drop = a.p_drop > 0.f;
+
+  for (int qt = wv; qt < NT; qt += 4) {
+    const int q0 = qt * 16;
+    float4 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const float4*>(Qs + (q0 + j) * kStr + 16 * s + 4 * g);
+    // ---- S^T tiles: acc[kt][r] = score(key 16 kt + 4 g + r, query q0 + j); two tiles at a time (independent chains)
+    f32x4v acc[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) acc[kt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < NT; kt += 2) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float4 k0 = *reinterpret_cast<const float4*>(Ks + (16 * kt + j) * kStr + 16 * s + 4 * g);
+        const float4 k1 = *reinterpret_cast<const float4*>(Ks + (16 * kt + 16 + j) * kStr + 16 * s + 4 * g);
+        acc[kt] = mfma16(k0.x, qf[s].x, acc[kt]);         acc[kt + 1] = mfma16(k1.x, qf[s].x, acc[kt + 1]);
+        acc[kt] = mfma16(k0.y, qf[s].y, acc[kt]);         acc[kt + 1] = mfma16(k1.y, qf[s].y, acc[kt + 1]);
+        acc[kt] = mfma16(k0.z, qf[s].z, acc[kt]);         acc[kt + 1] = mfma16(k1.z, qf[s].z, acc[kt + 1]);
+        acc[kt] = mfma16(k0.w, qf[s].w, acc[kt]);         acc[kt + 1] = mfma16(k1.w, qf[s].w, acc[kt + 1]);
+      }
+    }
+    // ---- softmax over the query's 192 keys: 48 in this lane, the rest in lanes j + 16, j + 32, j + 48
+    float m = acc[0][0];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[kt][r]);
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __builtin_amdgcn_exp2f((acc[kt][r] - m) * c2);
+        acc[kt][r] = p;
+        sum += p;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    const long row = (long)bh * T + q0 + j;
+    if (g == 0) a.lse[row] = m * a.scale + logf(sum);
+    // ---- normalise (+ dropout: quad = 4 consecutive keys of one row, counter offset + row * T/4 + key/4)
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      if (drop) {
+        bool keep[4];
+        if (a.mask_in) {
+          const uchar4 mk = *reinterpret_cast<const uchar4*>(a.mask_in + row * T + 16 * kt + 4 * g);
+          keep[0] = mk.x; keep[1] = mk.y; keep[2] = mk.z; keep[3] = mk.w;
+        } else {
+          uint32_t rnd[4];
+          philox4(a.seed, a.offset + (unsigned long long)(row * (T / 4) + 4 * kt + g), rnd);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) keep[r] = pe_dropout_keep(rnd[r], a.p_drop);
+        }
+        if (a.mask_out)
+          *reinterpret_cast<uchar4*>(a.mask_out + row * T + 16 * kt + 4 * g) =
+              make_uchar4(keep[0], keep[1], keep[2], keep[3]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[kt][r] = keep[r] ? (acc[kt][r] * inv) * a.keep_scale : 0.f;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[kt][r] *= inv;
+      }
+    }
+    // ---- O^T[d][query] = sum_key V[key][d] Pd[key][query]; d-tile dt holds d = 4 i + dt (one float4 of V per lane)
+    f32x4v o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float4 vf = *reinterpret_cast<const float4*>(Vs + (16 * kt + 4 * g + r) * kStr + 4 * j);
+        o[0] = mfma16(vf.x, acc[kt][r], o[0]);
+        o[1] = mfma16(vf.y, acc[kt][r], o[1]);
+        o[2] = mfma16(vf.z, acc[kt][r], o[2]);
+        o[3] = mfma16(vf.w, acc[kt][r], o[3]);
+      }
+    // lane (j, g) holds d = 16 g + 4 r + dt of query q0 + j: 64 contiguous bytes
+    float* orow = a.o + ((long)b * T + q0 + j) * a.ld_o + h * kDh + 16 * g;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) *reinterpret_cast<float4*>(orow + 4 * r) = make_float4(o[0][r], o[1][r], o[2][r], o[3][r]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dK, dV
+// Wave owns key tiles; scores with QUERIES on the rows, keys on the lane.  K / V fragments of the key tile are
+// loaded from global into registers once; Q and dO (and lse, delta) sit in LDS.
+template <int T>
+__global__ __launch_bounds__(256, 1) void attn_bwd_kv_kernel(const AttnArgs a) {
+  constexpr int NT = T / 16;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Qs = smem;
+  float* Gs = Qs + T * kStr;             // dO
+  float* lse_s = Gs + T * kStr;          // [T]
+  float* dl_s = lse_s + T;               // [T] delta
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
+  const float* base = a.qkv + (long)b * T * a.ld_qkv + h * kDh;
+  const float* dob = a.d_o + (long)b * T * a.ld_o + h * kDh;
+  stage64<T>(base, a.ld_qkv, Qs);
+  stage64<T>(dob, a.ld_o, Gs);
+  row_dots<T>(dob, a.ld_o, a.o + (long)b * T * a.ld_o + h * kDh, a.ld_o, dl_s);
+  for (int t = tid; t < T; t += 256) lse_s[t] = a.lse[(long)bh * T + t];
+  __syncthreads();
+  const bool drop = a.mask != nullptr;
+
+  for (int kt = wv; kt < NT; kt += 4) {
+    const int k0 = kt * 16;
+    // B operands of this key tile: K[k0 + j][16 s + 4 g ..] and V[k0 + j][16 s + 4 g ..]
+    float4 kf[4], vf[4];
+    const float* krow = base + a.D + (long)(k0 + j) * a.ld_qkv + 4 * g;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      kf[s] = *reinterpret_cast<const float4*>(krow + 16 * s);
+      vf[s] = *reinterpret_cast<const float4*>(krow + a.D + 16 * s);
+    }
+    f32x4v dk[4], dv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dk[dt] = dv[dt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    for (int qt = 0; qt < NT; ++qt) {
+      const int q0 = qt * 16;
+      // S[query 4 g + r][key j] and dP = dO V^T in the same layout
+      f32x4v sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float4 qa = *reinterpret_cast<const float4*>(Qs + (q0 + j) * kStr + 16 * s + 4 * g);
+        const float4 ga = *reinterpret_cast<const float4*>(Gs + (q0 + j) * kStr + 16 * s + 4 * g);
+        sc = mfma16(qa.x, kf[s].x, sc); dp = mfma16(ga.x, vf[s].x, dp);
+        sc = mfma16(qa.y, kf[s].y, sc); dp = mfma16(ga.y, vf[s].y, dp);
+        sc = mfma16(qa.z, kf[s].z, sc); dp = mfma16(ga.z, vf[s].z, dp);
+        sc = mfma16(qa.w, kf[s].w, sc); dp = mfma16(ga.w, vf[s].w, dp);
+      }
+      f32x4v pd, ds;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int q = q0 + 4 * g + r;
+        const float p = __builtin_amdgcn_exp2f((sc[r] * a.scale - lse_s[q]) * 1.44269504088896340736f);
+        float keep = 1.0f;
+        if (drop) keep = a.mask[((long)bh * T + q) * T + k0 + j] ? a.keep_scale : 0.f;
+        pd[r] = p * keep;                                           // dropped-out, rescaled probability
+        ds[r] = p * (dp[r] * keep - dl_s[q]) * a.scale;             // gradient of the raw score
+      }
+      // dV^T[d][key] += dO[query][d] Pd[query][key];  dK^T[d][key] += Q[query][d] dS[query][key]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float4 gf = *reinterpret_cast<const float4*>(Gs + (q0 + 4 * g + r) * kStr + 4 * j);
+        const float4 qf = *reinterpret_cast<const float4*>(Qs + (q0 + 4 * g + r) * kStr + 4 * j);
+        dv[0] = mfma16(gf.x, pd[r], dv[0]); dk[0] = mfma16(qf.x, ds[r], dk[0]);
+        dv[1] = mfma16(gf.y, pd[r], dv[1]); dk[1] = mfma16(qf.y, ds[r], dk[1]);
+        dv[2] = mfma16(gf.z, pd[r], dv[2]); dk[2] = mfma16(qf.z, ds[r], dk[2]);
+        dv[3] = mfma16(gf.w, pd[r], dv[3]); dk[3] = mfma16(qf.w, ds[r], dk[3]);
+      }
+    }
+    float* drow = a.dqkv + ((long)b * T + k0 + j) * a.ld_qkv + a.D + h * kDh + 16 * g;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      *reinterpret_cast<float4*>(drow + 4 * r) = make_float4(dk[0][r], dk[1][r], dk[2][r], dk[3][r]);
+      *reinterpret_cast<float4*>(drow + a.D + 4 * r) = make_float4(dv[0][r], dv[1][r], dv[2][r], dv[3][r]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dQ
+// Wave owns query tiles; scores with KEYS on the rows, queries on the lane (the forward's orientation).
+template <int T>
+__global__ __launch_bounds__(256, 1) void attn_bwd_q_kernel(const AttnArgs a) {
+  constexpr int NT = T / 16;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ks = smem;
+  float* Vs = Ks + T * kStr;
+  float* dl_s = Vs + T * kStr;           // [T] delta
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
+  const float* base = a.qkv + (long)b * T * a.ld_qkv + h * kDh;
+  const float* dob = a.d_o + (long)b * T * a.ld_o + h * kDh;
+  stage64<T>(base + a.D, a.ld_qkv, Ks);
+  stage64<T>(base + 2 * a.D, a.ld_qkv, Vs);
+  row_dots<T>(dob, a.ld_o, a.o + (long)b * T * a.ld_o + h * kDh, a.ld_o, dl_s);
+  __syncthreads();
+  const bool drop = a.mask != nullptr;
+
+  for (int qt = wv; qt < NT; qt += 4) {
+    const int q0 = qt * 16;
+    const long row = (long)bh * T + q0 + j;
+    float4 qf[4], gf[4];
+    const float* qrow = base + (long)(q0 + j) * a.ld_qkv + 4 * g;
+    const float* grow = dob + (long)(q0 + j) * a.ld_o + 4 * g;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      qf[s] = *reinterpret_cast<const float4*>(qrow + 16 * s);
+      gf[s] = *reinterpret_cast<const float4*>(grow + 16 * s);
+    }
+    const float lse = a.lse[row], delta = dl_s[q0 + j];
+    f32x4v dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < NT; ++kt) {
+      const int k0 = kt * 16;
+      f32x4v sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float4 ka = *reinterpret_cast<const float4*>(Ks + (k0 + j) * kStr + 16 * s + 4 * g);
+        const float4 va = *reinterpret_cast<const float4*>(Vs + (k0 + j) * kStr + 16 * s + 4 * g);
+        sc = mfma16(ka.x, qf[s].x, sc); dp = mfma16(va.x, gf[s].x, dp);
+        sc = mfma16(ka.y, qf[s].y, sc); dp = mfma16(va.y, gf[s].y, dp);
+        sc = mfma16(ka.z, qf[s].z, sc); dp = mfma16(va.z, gf[s].z, dp);
+        sc = mfma16(ka.w, qf[s].w, sc); dp = mfma16(va.w, gf[s].w, dp);
+      }
+      float keep[4] = {1.f, 1.f, 1.f, 1.f};
+      if (drop) {
+        const uchar4 mk = *reinterpret_cast<const uchar4*>(a.mask + row * T + k0 + 4 * g);
+        keep[0] = mk.x ? a.keep_scale : 0.f; keep[1] = mk.y ? a.keep_scale : 0.f;
+        keep[2] = mk.z ? a.keep_scale : 0.f; keep[3] = mk.w ? a.keep_scale : 0.f;
+      }
+      f32x4v ds;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __builtin_amdgcn_exp2f((sc[r] * a.scale - lse) * 1.44269504088896340736f);   // key k0+4g+r, query q0+j
+        ds[r] = p * (dp[r] * keep[r] - delta) * a.scale;
+      }
+      // dQ^T[d][query] += K[key][d] dS^T[key][query]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float4 kf = *reinterpret_cast<const float4*>(Ks + (k0 + 4 * g + r) * kStr + 4 * j);
+        dq[0] = mfma16(kf.x, ds[r], dq[0]);
+        dq[1] = mfma16(kf.y, ds[r], dq[1]);
+        dq[2] = mfma16(kf.z, ds[r], dq[2]);
+        dq[3] = mfma16(kf.w, ds[r], dq[3]);
+      }
+    }
+    float* drow = a.dqkv + ((long)b * T + q0 + j) * a.ld_qkv + h * kDh + 16 * g;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) *reinterpret_cast<float4*>(drow + 4 * r) = make_float4(dq[0][r], dq[1][r], dq[2][r], dq[3][r]);
+  }
+}
+
+bool attn_shape_ok(int T, int dh) { return T == 192 && dh == kDh; }
+
+template <class K>
+int set_lds(K kernel, size_t bytes) {
+  return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)bytes);
+}
+
+}  // namespace
+
+extern "C" int pe_attn_supported(int T, int dh) { return attn_shape_ok(T, dh) ? 1 : 0; }
+
+extern "C" int pe_attn_fwd(const float* qkv, long ld_qkv, float* o, long ld_o, float* lse, const unsigned char* mask_in,
+                           unsigned char* mask_out, int B, int T, int H, int dh, float scale, float p_drop,
+                           unsigned long long seed, unsigned long long offset, void* stream) {
+  if (!qkv || !o || !lse || B <= 0 || H <= 0 || p_drop < 0.f || p_drop >= 1.f) return PE_E_ARG;
+  if (!attn_shape_ok(T, dh) || (ld_qkv & 3) || (ld_o & 3) || ld_qkv < 3L * H * dh || ld_o < (long)H * dh)
+    return PE_E_UNSUPPORTED;
+  AttnArgs a{};
+  a.qkv = qkv; a.ld_qkv = ld_qkv; a.D = H * dh; a.o = o; a.ld_o = ld_o; a.lse = lse;
+  a.mask_in = mask_in; a.mask_out = mask_out; a.B = B; a.H = H; a.scale = scale; a.p_drop = p_drop;
+  a.keep_scale = 1.0f / (1.0f - p_drop); a.seed = seed; a.offset = offset;
+  const size_t lds = (size_t)3 * 192 * kStr * sizeof(float);
+  static bool attr = false;
+  if (!attr) { PE_CHECK_HIP((hipError_t)set_lds(&attn_fwd_kernel<192>, lds)); attr = true; }
+  hipLaunchKernelGGL(attn_fwd_kernel<192>, dim3(B * H), dim3(256), lds, pe_stream(stream), a);
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+
+extern "C" int pe_attn_bwd(const float* qkv, long ld_qkv, const float* o, const float* d_o, long ld_o, const float* lse,
+                           const unsigned char* mask, float* dqkv, int B, int T, int H, int dh, float scale,
+                           float p_drop, void* stream) {
+  if (!qkv || !o || !d_o || !lse || !dqkv || B <= 0 || H <= 0 || p_drop < 0.f || p_drop >= 1.f) return PE_E_ARG;
+  if (p_drop > 0.f && !mask) return PE_E_ARG;
+  if (!attn_shape_ok(T, dh) || (ld_qkv & 3) || (ld_o & 3) || ld_qkv < 3L * H * dh || ld_o < (long)H * dh)
+    return PE_E_UNSUPPORTED;
+  AttnArgs a{};
+  a.qkv = qkv; a.ld_qkv = ld_qkv; a.D = H * dh; a.o = const_cast<float*>(o); a.ld_o = ld_o;
+  a.lse = const_cast<float*>(lse); a.d_o = d_o; a.dqkv = dqkv; a.mask = p_drop > 0.f ? mask : nullptr;
+  a.B = B; a.H = H; a.scale = scale; a.p_drop = p_drop; a.keep_scale = 1.0f / (1.0f - p_drop);
+  const size_t lds = (size_t)(2 * 192 * kStr + 2 * 192) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    PE_CHECK_HIP((hipError_t)set_lds(&attn_bwd_kv_kernel<192>, lds));
+    PE_CHECK_HIP((hipError_t)set_lds(&attn_bwd_q_kernel<192>, lds));
+    attr = true;
+  }
+  hipStream_t st = pe_stream(stream);
+  hipLaunchKernelGGL(attn_bwd_kv_kernel<192>, dim3(B * H), dim3(256), lds, st, a);
+  PE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(attn_bwd_q_kernel<192>, dim3(B * H), dim3(256), lds, st, a);
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}

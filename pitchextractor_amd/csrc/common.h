@@ -77,3 +77,28 @@ __device__ __forceinline__ float4 pe_ordered_slab_sum4(const float* __restrict__
   }
   return s;
 }
+
+// Philox4x32-10 (dropout masks): 4 random words for counter `ctr`; element quad i of a dropout call uses
+// ctr = offset + i, and keeps element k when (float)(word[k] >> 8) * 2^-24 >= p.
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+  const uint64_t p0 = (uint64_t)M0 * c[0], p1 = (uint64_t)M1 * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0];
+  const uint32_t n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1];
+  const uint32_t n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+  k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+}
+
+__device__ __forceinline__ void philox4(uint64_t seed, uint64_t ctr, uint32_t (&out)[4]) {
+  uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+  uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+  for (int i = 0; i < 10; ++i) philox_round(c, k);
+  out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+
+__device__ __forceinline__ bool pe_dropout_keep(uint32_t word, float p) {
+  return ((float)(word >> 8) * (1.0f / 16777216.0f)) >= p;
+}

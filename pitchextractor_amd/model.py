@@ -352,15 +352,21 @@ def _tf_forward(sm, x, train, need_grad, drop: _DropoutCfg):
         att = lyr.self_attn
         c.x = y
         c.qkv = ops.gemm_nt(y, att.in_proj_weight, bias0=att.in_proj_bias)               # [R, 3D]
-        qv, kv, vv = c.qkv[:, 0:D], c.qkv[:, D:2 * D], c.qkv[:, 2 * D:3 * D]
-        hview = (3 * D, T * 3 * D, dh)                                                     # (ld, per batch, per head)
-        c.P = torch.empty((B * H * T, T), dtype=torch.float32, device=x.device)
-        pview = (T, H * T * T, T * T)
-        ops.bgemm(0, qv, hview, kv, hview, c.P, pview, H, B * H, T, T, dh)
-        ops.softmax_fwd_(c.P, scale)
-        c.Pd, c.mask_p = _dropout(drop, c.P, p)
-        c.o = torch.empty((R, D), dtype=torch.float32, device=x.device)
-        ops.bgemm(1, c.Pd, pview, vv, hview, c.o, (D, T * D, dh), H, B * H, T, dh, T)
+        c.fused = ops.attn_supported(T, dh)
+        if c.fused:                      # one workgroup per (batch, head); scores never reach HBM
+            mask_in = next(drop.inject) if (p > 0.0 and drop.inject is not None) else None
+            off = drop.next_offset(B * H * T * (T // 4)) if (p > 0.0 and mask_in is None) else 0
+            c.o, c.lse, c.mask_p = ops.attn_fwd(c.qkv, B, T, H, scale, p, mask_in=mask_in, seed=drop.seed, offset=off)
+        else:
+            qv, kv, vv = c.qkv[:, 0:D], c.qkv[:, D:2 * D], c.qkv[:, 2 * D:3 * D]
+            hview = (3 * D, T * 3 * D, dh)                                                 # (ld, per batch, per head)
+            c.P = torch.empty((B * H * T, T), dtype=torch.float32, device=x.device)
+            pview = (T, H * T * T, T * T)
+            ops.bgemm(0, qv, hview, kv, hview, c.P, pview, H, B * H, T, T, dh)
+            ops.softmax_fwd_(c.P, scale)
+            c.Pd, c.mask_p = _dropout(drop, c.P, p)
+            c.o = torch.empty((R, D), dtype=torch.float32, device=x.device)
+            ops.bgemm(1, c.Pd, pview, vv, hview, c.o, (D, T * D, dh), H, B * H, T, dh, T)
         sa = ops.gemm_nt(c.o, att.out_proj.weight, bias0=att.out_proj.bias)
         sa, c.mask1 = _dropout(drop, sa, p)
         x1, c.ln1 = ops.layernorm_fwd(y, lyr.norm1.weight, lyr.norm1.bias, b2d=sa, eps=lyr.norm1.eps)
@@ -406,17 +412,20 @@ def _tf_backward(sm, saved, dy, g):
         ops.gemm_tn(dsa, c.o, out=g[att.out_proj.weight])
         ops.colsum(dsa, g[att.out_proj.bias])
         do = ops.gemm_nt(dsa, ops.transpose2d(att.out_proj.weight))                        # [R, D] merged heads
-        qv, kv, vv = c.qkv[:, 0:D], c.qkv[:, D:2 * D], c.qkv[:, 2 * D:3 * D]
-        dqkv = torch.empty_like(c.qkv)
-        dq, dk, dv = dqkv[:, 0:D], dqkv[:, D:2 * D], dqkv[:, 2 * D:3 * D]
-        oview = (D, T * D, dh)
-        ops.bgemm(2, c.Pd, pview, do, oview, dv, hview, H, B * H, T, dh, T)                # dV = Pd^T dO
-        dP = torch.empty_like(c.P)
-        ops.bgemm(0, do, oview, vv, hview, dP, pview, H, B * H, T, T, dh)                  # dPd = dO V^T
-        dP = _dropout_bwd(dP, p, c.mask_p)
-        ops.softmax_bwd_(c.P, dP, scale)                                                   # dP <- dS (incl. 1/sqrt(dh))
-        ops.bgemm(1, dP, pview, kv, hview, dq, hview, H, B * H, T, dh, T)                  # dQ = dS K
-        ops.bgemm(2, dP, pview, qv, hview, dk, hview, H, B * H, T, dh, T)                  # dK = dS^T Q
+        if c.fused:
+            dqkv = ops.attn_bwd(c.qkv, c.o, do, c.lse, c.mask_p, B, T, H, scale, p if c.mask_p is not None else 0.0)
+        else:
+            qv, kv, vv = c.qkv[:, 0:D], c.qkv[:, D:2 * D], c.qkv[:, 2 * D:3 * D]
+            dqkv = torch.empty_like(c.qkv)
+            dq, dk, dv = dqkv[:, 0:D], dqkv[:, D:2 * D], dqkv[:, 2 * D:3 * D]
+            oview = (D, T * D, dh)
+            ops.bgemm(2, c.Pd, pview, do, oview, dv, hview, H, B * H, T, dh, T)            # dV = Pd^T dO
+            dP = torch.empty_like(c.P)
+            ops.bgemm(0, do, oview, vv, hview, dP, pview, H, B * H, T, T, dh)              # dPd = dO V^T
+            dP = _dropout_bwd(dP, p, c.mask_p)
+            ops.softmax_bwd_(c.P, dP, scale)                                               # dP <- dS (incl. 1/sqrt(dh))
+            ops.bgemm(1, dP, pview, kv, hview, dq, hview, H, B * H, T, dh, T)              # dQ = dS K
+            ops.bgemm(2, dP, pview, qv, hview, dk, hview, H, B * H, T, dh, T)              # dK = dS^T Q
         ops.gemm_tn(dqkv, c.x, out=g[att.in_proj_weight])
         ops.colsum(dqkv, g[att.in_proj_bias])
         dy = ops.gemm_nt(dqkv, ops.transpose2d(att.in_proj_weight))

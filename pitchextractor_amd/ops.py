@@ -715,6 +715,53 @@ def bgemm(mode, A, a_view, B, b_view, C, c_view, inner, batch, M, N, K, alpha=1.
     return C
 
 
+FUSED_ATTENTION = os.environ.get("PE_FUSED_ATTENTION", "1") == "1"
+
+
+def attn_supported(T, dh):
+    return bool(FUSED_ATTENTION and _lib.load().pe_attn_supported(int(T), int(dh)))
+
+
+def attn_fwd(qkv, B, T, H, scale, p=0.0, mask_in=None, seed=0, offset=0):
+    """Fused softmax(Q K^T * scale) -> dropout(p) -> . V for packed projections qkv [B*T, 3*H*dh].
+    Returns (o [B*T, H*dh], lse [B*H*T], keep mask uint8 [B*H*T, T] or None)."""
+    qkv = _dense(qkv, "qkv")
+    R, D3 = qkv.shape
+    D = D3 // 3
+    dh = D // H
+    _chk(R == B * T and D3 == 3 * H * dh, "attn_fwd: qkv shape")
+    o = torch.empty((R, D), dtype=torch.float32, device=qkv.device)
+    lse = torch.empty((B * H * T,), dtype=torch.float32, device=qkv.device)
+    mask_out = None
+    if p > 0.0:
+        if mask_in is not None:
+            _chk(mask_in.is_cuda and mask_in.dtype == torch.uint8 and mask_in.is_contiguous()
+                 and mask_in.numel() == B * H * T * T, "attn_fwd: mask_in")
+        else:
+            mask_out = torch.empty((B * H * T, T), dtype=torch.uint8, device=qkv.device)
+    _call("pe_attn_fwd", qkv.data_ptr(), D3, o.data_ptr(), D, lse.data_ptr(), _lib.ptr(mask_in if p > 0.0 else None),
+          _lib.ptr(mask_out), B, T, H, dh, float(scale), float(p), int(seed), int(offset), _s(),
+          work=4.0 * B * H * T * T * dh)
+    return o, lse, (mask_in if (p > 0.0 and mask_in is not None) else mask_out)
+
+
+def attn_bwd(qkv, o, d_o, lse, mask, B, T, H, scale, p=0.0):
+    """Gradient of attn_fwd wrt the packed projections: dqkv [B*T, 3*H*dh]."""
+    qkv, o, d_o, lse = _dense(qkv, "qkv"), _dense(o, "o"), _dense(d_o, "d_o"), _dense(lse, "lse")
+    R, D3 = qkv.shape
+    D = D3 // 3
+    dh = D // H
+    _chk(o.shape == (R, D) and d_o.shape == (R, D) and lse.numel() == B * H * T, "attn_bwd: shapes")
+    if p > 0.0:
+        _chk(mask is not None and mask.is_cuda and mask.dtype == torch.uint8 and mask.numel() == B * H * T * T,
+             "attn_bwd: mask")
+    dqkv = torch.empty_like(qkv)
+    _call("pe_attn_bwd", qkv.data_ptr(), D3, o.data_ptr(), d_o.data_ptr(), D, lse.data_ptr(),
+          _lib.ptr(mask if p > 0.0 else None), dqkv.data_ptr(), B, T, H, dh, float(scale), float(p), _s(),
+          work=10.0 * B * H * T * T * dh)
+    return dqkv
+
+
 def softmax_fwd_(s2d, scale):
     rows, L, ld = _rows2d(s2d, "scores")
     _chk(ld == L, "softmax: dense rows")

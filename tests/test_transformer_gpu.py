@@ -216,3 +216,65 @@ def test_transformer_mixed_precision_curve_tracks_cpu_oracle_trainer(hip_device)
         got, ref = tr.run(batch), cpu.run(batch)
         assert abs(got["loss"] - ref["loss"]) <= 2e-2 * abs(ref["loss"]), (i, got, ref)
         assert abs(got["sil"] - ref["sil"]) <= 2e-2 * abs(ref["sil"]) + 2e-3, (i, got, ref)
+
+
+# ------------------------------------------------------------------ fused attention (T = 192, dh = 64)
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_fused_attention_fwd_bwd(hip_device, p):
+    """pe_attn_fwd / pe_attn_bwd against float64 softmax(QK^T/8) -> dropout(mask) -> V and its autograd gradient;
+    the dropout keep mask is the kernel's own (exported), as in the whole-model mask-replay tests; and the Philox
+    stream equals pe_dropout_fwd's on the (B*H*T) x T matrix, so fused and unfused paths draw identical masks."""
+    B, H, T, dh = 3, 8, 192, 64
+    D = H * dh
+    assert ops.attn_supported(T, dh)
+    qkv = (rnd(B * T, 3 * D, seed=1) * 1.5).to(hip_device)
+    o, lse, mask = ops.attn_fwd(qkv, B, T, H, 0.125, p, seed=11, offset=1000)
+    ref_in = qkv.cpu().double().requires_grad_(True)
+    q, k, v = (ref_in[:, i * D:(i + 1) * D].view(B, T, H, dh).transpose(1, 2) for i in range(3))    # (B,H,T,dh)
+    s = (q @ k.transpose(-1, -2)) * 0.125
+    P = torch.softmax(s, dim=-1)
+    if p > 0:
+        keep = mask.cpu().view(B, H, T, T).double()
+        assert abs(keep.mean().item() - (1 - p)) < 5e-3
+        probe = torch.ones(B * H * T, T, device=hip_device)
+        _, m2 = ops.dropout(probe, p, seed=11, offset=1000)
+        assert torch.equal(m2, mask)                                   # same Philox stream as the unfused dropout
+        P = P * keep / (1 - p)
+    else:
+        assert mask is None
+    ref_o = (P @ v).transpose(1, 2).reshape(B * T, D)
+    close(o, ref_o.detach(), 1e-5)
+    close(lse.view(B, H, T), torch.logsumexp(s, dim=-1).detach(), 1e-5)
+    d_o = rnd(B * T, D, seed=2)
+    ref_o.backward(d_o.double())
+    dqkv = ops.attn_bwd(qkv, o, d_o.to(hip_device), lse, mask, B, T, H, 0.125, p)
+    for i, name in enumerate("qkv"):
+        close(dqkv[:, i * D:(i + 1) * D], ref_in.grad[:, i * D:(i + 1) * D], 2e-5)
+    # replaying the exported mask reproduces the forward bit for bit
+    if p > 0:
+        o2, _, _ = ops.attn_fwd(qkv, B, T, H, 0.125, p, mask_in=mask)
+        assert torch.equal(o, o2)
+
+
+def test_fused_and_unfused_attention_agree_in_the_model(hip_device, monkeypatch):
+    """Whole Transformer-head JDCNet, train mode with live dropout: the fused attention path and the
+    pe_bgemm + pe_softmax path give the same logits and gradients (same masks: same Philox offsets)."""
+    state = model_ref.seeded_state(11, model_type="transformer", num_layers=2)
+    cfg = dict(TF_CFG, num_layers=2, dropout=0.1)
+    outs = {}
+    for fused in (True, False):
+        monkeypatch.setattr(ops, "FUSED_ATTENTION", fused)
+        net = JDCNet(num_class=1, sequence_model_config=dict(cfg))
+        net.load_state_dict(state)
+        net = net.to(hip_device).train()
+        net.dropout_cfg.seed = 5
+        f0, sil = (t.to(hip_device) for t in golden_targets(6))
+        cls, det = net(golden_input(6).to(hip_device))
+        out3, d_f0, d_sil = ops.f0_sil_loss(cls.detach().reshape(-1), f0.reshape(-1), det.detach().reshape(-1),
+                                            sil.reshape(-1), 0.1)
+        torch.autograd.backward([cls, det], [d_f0.view_as(cls), d_sil.view_as(det)])
+        outs[fused] = (cls.detach(), det.detach(), net.flat_gradients().clone(), net.dropout_cfg.offset)
+    assert outs[True][3] == outs[False][3]
+    assert _rel(outs[True][0], outs[False][0].cpu().numpy()) <= 2e-5 and _rel(outs[True][1], outs[False][1].cpu().numpy()) <= 2e-5
+    ga, gb = outs[True][2].double(), outs[False][2].double()
+    assert ((ga - gb).norm() / gb.norm()).item() <= 1e-4
