@@ -2,8 +2,8 @@
 // softmax(Q K^T / sqrt(dh)) -> dropout -> . V per head) for the geometry of this model: T = 192 frames, dh = 64.
 //
 // The unfused path materialises the (B*H*T) x T probability matrix in HBM (302 MB per layer and branch at B = 256)
-// and walks it five times forward and six times backward.  Here one workgroup owns one (batch, head): its Q / K / V
-// (48 KB each, fp32) sit in LDS or registers, scores never leave the register file, and what reaches HBM is O, the
+// and walks it five times forward and six times backward.  Here three workgroups share one (batch, head): Q / K / V
+// (48 KB each, fp32) pass through LDS or registers, scores never leave the register file, and what reaches HBM is O, the
 // per-row log-sum-exp (768 B per head) and, when dropout is live, the 1-byte keep mask the parity tests export.
 //
 // Arithmetic: exact fp32 on v_mfma_f32_16x16x4_f32 (attention is 3 % of the step's FLOPs; the operands change every
@@ -72,157 +72,190 @@ __device__ __forceinline__ void row_dots(const float* __restrict__ a, long lda, 
   }
 }
 
+// Work decomposition: a workgroup = (batch, head, third of the tiles): 4 waves, one 16-row tile each.  The rows it
+// sweeps (keys in the forward / dQ kernels, queries in the dK / dV kernel) pass through LDS in two halves of 96
+// rows, so a workgroup needs 52 KB and three of them share a CU: their MFMA, VALU (softmax, Philox) and load
+// phases overlap.  (A first version kept whole K / V per workgroup -- 157 KB, one workgroup and one wave per SIMD --
+// and ran at a third of this rate: nothing hid the LDS and exp latencies.)
+
 // ------------------------------------------------------------------------------------------------ forward
 template <int T>
-__global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const AttnArgs a) {
-  constexpr int NT = T / 16;
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs a) {
+  constexpr int NT = T / 16, HR = T / 2, NH = NT / 2;       // HR rows / NH tiles per half
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Ks = smem;
-  float* Vs = Ks + T * kStr;
-  float* Qs = Vs + T * kStr;
+  float* Ks = smem;                      // [HR][kStr]
+  float* Vs = Ks + HR * kStr;            // [HR][kStr]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
-  const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
+  const int bh = blockIdx.x / 3, part = blockIdx.x - bh * 3, b = bh / a.H, h = bh - b * a.H;
   const float* base = a.qkv + (long)b * T * a.ld_qkv + h * kDh;
-  stage64<T>(base, a.ld_qkv, Qs);
-  stage64<T>(base + a.D, a.ld_qkv, Ks);
-  stage64<T>(base + 2 * a.D, a.ld_qkv, Vs);
-  __syncthreads();
+  const int q0 = (part * 4 + wv) * 16;
+  const long row = (long)bh * T + q0 + j;
   const float c2 = a.scale * 1.44269504088896340736f;
   const bool drop = a.p_drop > 0.f;
 
-  for (int qt = wv; qt < NT; qt += 4) {
-    const int q0 = qt * 16;
-    float4 qf[4];
+  stage64<HR>(base + a.D, a.ld_qkv, Ks);
+  stage64<HR>(base + 2 * a.D, a.ld_qkv, Vs);
+  float4 qf[4];
+  {
+    const float* qrow = base + (long)(q0 + j) * a.ld_qkv + 4 * g;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const float4*>(Qs + (q0 + j) * kStr + 16 * s + 4 * g);
-    // ---- S^T tiles: acc[kt][r] = score(key 16 kt + 4 g + r, query q0 + j); two tiles at a time (independent chains)
-    f32x4v acc[NT];
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const float4*>(qrow + 16 * s);
+  }
+  __syncthreads();
+  // ---- S^T tiles: acc[kt][r] = score(key 16 kt + 4 g + r, query q0 + j); two tiles at a time (independent chains)
+  f32x4v acc[NT];
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt) acc[kt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  for (int kt = 0; kt < NT; ++kt) acc[kt] = f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kt = 0; kt < NT; kt += 2) {
+  for (int half = 0; half < 2; ++half) {
+    if (half == 1) {
+      __syncthreads();                                      // every wave is done with keys 0 .. HR-1
+      stage64<HR>(base + a.D + (long)HR * a.ld_qkv, a.ld_qkv, Ks);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int kl = 0; kl < NH; kl += 2) {
+      const int kt = half * NH + kl;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const float4 k0 = *reinterpret_cast<const float4*>(Ks + (16 * kt + j) * kStr + 16 * s + 4 * g);
-        const float4 k1 = *reinterpret_cast<const float4*>(Ks + (16 * kt + 16 + j) * kStr + 16 * s + 4 * g);
+        const float4 k0 = *reinterpret_cast<const float4*>(Ks + (16 * kl + j) * kStr + 16 * s + 4 * g);
+        const float4 k1 = *reinterpret_cast<const float4*>(Ks + (16 * kl + 16 + j) * kStr + 16 * s + 4 * g);
         acc[kt] = mfma16(k0.x, qf[s].x, acc[kt]);         acc[kt + 1] = mfma16(k1.x, qf[s].x, acc[kt + 1]);
         acc[kt] = mfma16(k0.y, qf[s].y, acc[kt]);         acc[kt + 1] = mfma16(k1.y, qf[s].y, acc[kt + 1]);
         acc[kt] = mfma16(k0.z, qf[s].z, acc[kt]);         acc[kt + 1] = mfma16(k1.z, qf[s].z, acc[kt + 1]);
         acc[kt] = mfma16(k0.w, qf[s].w, acc[kt]);         acc[kt + 1] = mfma16(k1.w, qf[s].w, acc[kt + 1]);
       }
     }
-    // ---- softmax over the query's 192 keys: 48 in this lane, the rest in lanes j + 16, j + 32, j + 48
-    float m = acc[0][0];
+  }
+  // ---- softmax over the query's 192 keys: 48 in this lane, the rest in lanes j + 16, j + 32, j + 48
+  float m = acc[0][0];
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
+  for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[kt][r]);
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float sum = 0.f;
+    for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[kt][r]);
+  m = fmaxf(m, __shfl_xor(m, 16, 64));
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float sum = 0.f;
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
+  for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = __builtin_amdgcn_exp2f((acc[kt][r] - m) * c2);
-        acc[kt][r] = p;
-        sum += p;
-      }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
-    const long row = (long)bh * T + q0 + j;
-    if (g == 0) a.lse[row] = m * a.scale + logf(sum);
-    // ---- normalise (+ dropout: quad = 4 consecutive keys of one row, counter offset + row * T/4 + key/4)
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt) {
-      if (drop) {
-        bool keep[4];
-        if (a.mask_in) {
-          const uchar4 mk = *reinterpret_cast<const uchar4*>(a.mask_in + row * T + 16 * kt + 4 * g);
-          keep[0] = mk.x; keep[1] = mk.y; keep[2] = mk.z; keep[3] = mk.w;
-        } else {
-          uint32_t rnd[4];
-          philox4(a.seed, a.offset + (unsigned long long)(row * (T / 4) + 4 * kt + g), rnd);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) keep[r] = pe_dropout_keep(rnd[r], a.p_drop);
-        }
-        if (a.mask_out)
-          *reinterpret_cast<uchar4*>(a.mask_out + row * T + 16 * kt + 4 * g) =
-              make_uchar4(keep[0], keep[1], keep[2], keep[3]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[kt][r] = keep[r] ? (acc[kt][r] * inv) * a.keep_scale : 0.f;
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[kt][r] *= inv;
-      }
+    for (int r = 0; r < 4; ++r) {
+      const float p = __builtin_amdgcn_exp2f((acc[kt][r] - m) * c2);
+      acc[kt][r] = p;
+      sum += p;
     }
-    // ---- O^T[d][query] = sum_key V[key][d] Pd[key][query]; d-tile dt holds d = 4 i + dt (one float4 of V per lane)
-    f32x4v o[4];
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
+  if (g == 0) a.lse[row] = m * a.scale + logf(sum);
+  // ---- normalise (+ dropout: quad = 4 consecutive keys of one row, counter offset + row * T/4 + key/4)
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  for (int kt = 0; kt < NT; ++kt) {
+    if (drop) {
+      bool keep[4];
+      if (a.mask_in) {
+        const uchar4 mk = *reinterpret_cast<const uchar4*>(a.mask_in + row * T + 16 * kt + 4 * g);
+        keep[0] = mk.x; keep[1] = mk.y; keep[2] = mk.z; keep[3] = mk.w;
+      } else {
+        uint32_t rnd[4];
+        philox4(a.seed, a.offset + (unsigned long long)(row * (T / 4) + 4 * kt + g), rnd);
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
+        for (int r = 0; r < 4; ++r) keep[r] = pe_dropout_keep(rnd[r], a.p_drop);
+      }
+      if (a.mask_out)
+        *reinterpret_cast<uchar4*>(a.mask_out + row * T + 16 * kt + 4 * g) =
+            make_uchar4(keep[0], keep[1], keep[2], keep[3]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[kt][r] = keep[r] ? (acc[kt][r] * inv) * a.keep_scale : 0.f;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[kt][r] *= inv;
+    }
+  }
+  // ---- O^T[d][query] = sum_key V[key][d] Pd[key][query]; d-tile dt holds d = 4 i + dt (one float4 of V per lane)
+  f32x4v o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (half == 1) {
+      __syncthreads();
+      stage64<HR>(base + 2 * a.D + (long)HR * a.ld_qkv, a.ld_qkv, Vs);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int kl = 0; kl < NH; ++kl) {
+      const int kt = half * NH + kl;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float4 vf = *reinterpret_cast<const float4*>(Vs + (16 * kt + 4 * g + r) * kStr + 4 * j);
+        const float4 vf = *reinterpret_cast<const float4*>(Vs + (16 * kl + 4 * g + r) * kStr + 4 * j);
         o[0] = mfma16(vf.x, acc[kt][r], o[0]);
         o[1] = mfma16(vf.y, acc[kt][r], o[1]);
         o[2] = mfma16(vf.z, acc[kt][r], o[2]);
         o[3] = mfma16(vf.w, acc[kt][r], o[3]);
       }
-    // lane (j, g) holds d = 16 g + 4 r + dt of query q0 + j: 64 contiguous bytes
-    float* orow = a.o + ((long)b * T + q0 + j) * a.ld_o + h * kDh + 16 * g;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) *reinterpret_cast<float4*>(orow + 4 * r) = make_float4(o[0][r], o[1][r], o[2][r], o[3][r]);
+    }
   }
+  // lane (j, g) holds d = 16 g + 4 r + dt of query q0 + j: 64 contiguous bytes
+  float* orow = a.o + ((long)b * T + q0 + j) * a.ld_o + h * kDh + 16 * g;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) *reinterpret_cast<float4*>(orow + 4 * r) = make_float4(o[0][r], o[1][r], o[2][r], o[3][r]);
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
-// Wave owns key tiles; scores with QUERIES on the rows, keys on the lane.  K / V fragments of the key tile are
-// loaded from global into registers once; Q and dO (and lse, delta) sit in LDS.
+// Wave owns one key tile; scores with QUERIES on the rows, keys on the lane.  The K / V fragments of the key tile are
+// loaded from global into registers once; Q and dO pass through LDS in two halves; lse / delta of all queries in LDS.
 template <int T>
-__global__ __launch_bounds__(256, 1) void attn_bwd_kv_kernel(const AttnArgs a) {
-  constexpr int NT = T / 16;
+__global__ __launch_bounds__(256, 3) void attn_bwd_kv_kernel(const AttnArgs a) {
+  constexpr int NT = T / 16, HR = T / 2, NH = NT / 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Qs = smem;
-  float* Gs = Qs + T * kStr;             // dO
-  float* lse_s = Gs + T * kStr;          // [T]
+  float* Qs = smem;                      // [HR][kStr]
+  float* Gs = Qs + HR * kStr;            // [HR][kStr] dO
+  float* lse_s = Gs + HR * kStr;         // [T]
   float* dl_s = lse_s + T;               // [T] delta
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
-  const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
+  const int bh = blockIdx.x / 3, part = blockIdx.x - bh * 3, b = bh / a.H, h = bh - b * a.H;
   const float* base = a.qkv + (long)b * T * a.ld_qkv + h * kDh;
   const float* dob = a.d_o + (long)b * T * a.ld_o + h * kDh;
-  stage64<T>(base, a.ld_qkv, Qs);
-  stage64<T>(dob, a.ld_o, Gs);
+  const int k0 = (part * 4 + wv) * 16;
+  stage64<HR>(base, a.ld_qkv, Qs);
+  stage64<HR>(dob, a.ld_o, Gs);
   row_dots<T>(dob, a.ld_o, a.o + (long)b * T * a.ld_o + h * kDh, a.ld_o, dl_s);
   for (int t = tid; t < T; t += 256) lse_s[t] = a.lse[(long)bh * T + t];
-  __syncthreads();
-  const bool drop = a.mask != nullptr;
-
-  for (int kt = wv; kt < NT; kt += 4) {
-    const int k0 = kt * 16;
-    // B operands of this key tile: K[k0 + j][16 s + 4 g ..] and V[k0 + j][16 s + 4 g ..]
-    float4 kf[4], vf[4];
+  // B operands of this key tile: K[k0 + j][16 s + 4 g ..] and V[k0 + j][16 s + 4 g ..]
+  float4 kf[4], vf[4];
+  {
     const float* krow = base + a.D + (long)(k0 + j) * a.ld_qkv + 4 * g;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       kf[s] = *reinterpret_cast<const float4*>(krow + 16 * s);
       vf[s] = *reinterpret_cast<const float4*>(krow + a.D + 16 * s);
     }
-    f32x4v dk[4], dv[4];
+  }
+  __syncthreads();
+  const bool drop = a.mask != nullptr;
+  f32x4v dk[4], dv[4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) dk[dt] = dv[dt] = f32x4v{0.f, 0.f, 0.f, 0.f};
-    for (int qt = 0; qt < NT; ++qt) {
-      const int q0 = qt * 16;
+  for (int dt = 0; dt < 4; ++dt) dk[dt] = dv[dt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    if (half == 1) {
+      __syncthreads();
+      stage64<HR>(base + (long)HR * a.ld_qkv, a.ld_qkv, Qs);
+      stage64<HR>(dob + (long)HR * a.ld_o, a.ld_o, Gs);
+      __syncthreads();
+    }
+#pragma unroll 2
+    for (int ql = 0; ql < NH; ++ql) {
+      const int qb = ql * 16, q0 = half * HR + qb;
       // S[query 4 g + r][key j] and dP = dO V^T in the same layout
       f32x4v sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const float4 qa = *reinterpret_cast<const float4*>(Qs + (q0 + j) * kStr + 16 * s + 4 * g);
-        const float4 ga = *reinterpret_cast<const float4*>(Gs + (q0 + j) * kStr + 16 * s + 4 * g);
+        const float4 qa = *reinterpret_cast<const float4*>(Qs + (qb + j) * kStr + 16 * s + 4 * g);
+        const float4 ga = *reinterpret_cast<const float4*>(Gs + (qb + j) * kStr + 16 * s + 4 * g);
         sc = mfma16(qa.x, kf[s].x, sc); dp = mfma16(ga.x, vf[s].x, dp);
         sc = mfma16(qa.y, kf[s].y, sc); dp = mfma16(ga.y, vf[s].y, dp);
         sc = mfma16(qa.z, kf[s].z, sc); dp = mfma16(ga.z, vf[s].z, dp);
@@ -241,65 +274,78 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_kernel(const AttnArgs a) {
       // dV^T[d][key] += dO[query][d] Pd[query][key];  dK^T[d][key] += Q[query][d] dS[query][key]
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float4 gf = *reinterpret_cast<const float4*>(Gs + (q0 + 4 * g + r) * kStr + 4 * j);
-        const float4 qf = *reinterpret_cast<const float4*>(Qs + (q0 + 4 * g + r) * kStr + 4 * j);
+        const float4 gf = *reinterpret_cast<const float4*>(Gs + (qb + 4 * g + r) * kStr + 4 * j);
+        const float4 qf = *reinterpret_cast<const float4*>(Qs + (qb + 4 * g + r) * kStr + 4 * j);
         dv[0] = mfma16(gf.x, pd[r], dv[0]); dk[0] = mfma16(qf.x, ds[r], dk[0]);
         dv[1] = mfma16(gf.y, pd[r], dv[1]); dk[1] = mfma16(qf.y, ds[r], dk[1]);
         dv[2] = mfma16(gf.z, pd[r], dv[2]); dk[2] = mfma16(qf.z, ds[r], dk[2]);
         dv[3] = mfma16(gf.w, pd[r], dv[3]); dk[3] = mfma16(qf.w, ds[r], dk[3]);
       }
     }
-    float* drow = a.dqkv + ((long)b * T + k0 + j) * a.ld_qkv + a.D + h * kDh + 16 * g;
+  }
+  float* drow = a.dqkv + ((long)b * T + k0 + j) * a.ld_qkv + a.D + h * kDh + 16 * g;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      *reinterpret_cast<float4*>(drow + 4 * r) = make_float4(dk[0][r], dk[1][r], dk[2][r], dk[3][r]);
-      *reinterpret_cast<float4*>(drow + a.D + 4 * r) = make_float4(dv[0][r], dv[1][r], dv[2][r], dv[3][r]);
-    }
+  for (int r = 0; r < 4; ++r) {
+    *reinterpret_cast<float4*>(drow + 4 * r) = make_float4(dk[0][r], dk[1][r], dk[2][r], dk[3][r]);
+    *reinterpret_cast<float4*>(drow + a.D + 4 * r) = make_float4(dv[0][r], dv[1][r], dv[2][r], dv[3][r]);
   }
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ
-// Wave owns query tiles; scores with KEYS on the rows, queries on the lane (the forward's orientation).
+// Wave owns one query tile; scores with KEYS on the rows, queries on the lane (the forward's orientation).
 template <int T>
-__global__ __launch_bounds__(256, 1) void attn_bwd_q_kernel(const AttnArgs a) {
-  constexpr int NT = T / 16;
+__global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const AttnArgs a) {
+  constexpr int NT = T / 16, HR = T / 2, NH = NT / 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Ks = smem;
-  float* Vs = Ks + T * kStr;
-  float* dl_s = Vs + T * kStr;           // [T] delta
+  float* Ks = smem;                      // [HR][kStr]
+  float* Vs = Ks + HR * kStr;            // [HR][kStr]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
-  const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
+  const int bh = blockIdx.x / 3, part = blockIdx.x - bh * 3, b = bh / a.H, h = bh - b * a.H;
   const float* base = a.qkv + (long)b * T * a.ld_qkv + h * kDh;
   const float* dob = a.d_o + (long)b * T * a.ld_o + h * kDh;
-  stage64<T>(base + a.D, a.ld_qkv, Ks);
-  stage64<T>(base + 2 * a.D, a.ld_qkv, Vs);
-  row_dots<T>(dob, a.ld_o, a.o + (long)b * T * a.ld_o + h * kDh, a.ld_o, dl_s);
-  __syncthreads();
-  const bool drop = a.mask != nullptr;
-
-  for (int qt = wv; qt < NT; qt += 4) {
-    const int q0 = qt * 16;
-    const long row = (long)bh * T + q0 + j;
-    float4 qf[4], gf[4];
+  const int q0 = (part * 4 + wv) * 16;
+  const long row = (long)bh * T + q0 + j;
+  stage64<HR>(base + a.D, a.ld_qkv, Ks);
+  stage64<HR>(base + 2 * a.D, a.ld_qkv, Vs);
+  float4 qf[4], gf[4];
+  float delta = 0.f;
+  {
     const float* qrow = base + (long)(q0 + j) * a.ld_qkv + 4 * g;
     const float* grow = dob + (long)(q0 + j) * a.ld_o + 4 * g;
+    const float* orow = a.o + ((long)b * T + q0 + j) * a.ld_o + h * kDh + 4 * g;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       qf[s] = *reinterpret_cast<const float4*>(qrow + 16 * s);
       gf[s] = *reinterpret_cast<const float4*>(grow + 16 * s);
+      const float4 ov = *reinterpret_cast<const float4*>(orow + 16 * s);
+      delta += gf[s].x * ov.x + gf[s].y * ov.y + gf[s].z * ov.z + gf[s].w * ov.w;
     }
-    const float lse = a.lse[row], delta = dl_s[q0 + j];
-    f32x4v dq[4];
+    delta += __shfl_xor(delta, 16, 64);                    // the row's 64 d are spread over the 4 lane groups
+    delta += __shfl_xor(delta, 32, 64);
+  }
+  const float lse = a.lse[row];
+  __syncthreads();
+  const bool drop = a.mask != nullptr;
+  f32x4v dq[4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4v{0.f, 0.f, 0.f, 0.f};
-    for (int kt = 0; kt < NT; ++kt) {
-      const int k0 = kt * 16;
+  for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    if (half == 1) {
+      __syncthreads();
+      stage64<HR>(base + a.D + (long)HR * a.ld_qkv, a.ld_qkv, Ks);
+      stage64<HR>(base + 2 * a.D + (long)HR * a.ld_qkv, a.ld_qkv, Vs);
+      __syncthreads();
+    }
+#pragma unroll 2
+    for (int kl = 0; kl < NH; ++kl) {
+      const int kb = kl * 16, k0 = half * HR + kb;
       f32x4v sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const float4 ka = *reinterpret_cast<const float4*>(Ks + (k0 + j) * kStr + 16 * s + 4 * g);
-        const float4 va = *reinterpret_cast<const float4*>(Vs + (k0 + j) * kStr + 16 * s + 4 * g);
+        const float4 ka = *reinterpret_cast<const float4*>(Ks + (kb + j) * kStr + 16 * s + 4 * g);
+        const float4 va = *reinterpret_cast<const float4*>(Vs + (kb + j) * kStr + 16 * s + 4 * g);
         sc = mfma16(ka.x, qf[s].x, sc); dp = mfma16(va.x, gf[s].x, dp);
         sc = mfma16(ka.y, qf[s].y, sc); dp = mfma16(va.y, gf[s].y, dp);
         sc = mfma16(ka.z, qf[s].z, sc); dp = mfma16(va.z, gf[s].z, dp);
@@ -320,17 +366,17 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_q_kernel(const AttnArgs a) {
       // dQ^T[d][query] += K[key][d] dS^T[key][query]
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float4 kf = *reinterpret_cast<const float4*>(Ks + (k0 + 4 * g + r) * kStr + 4 * j);
+        const float4 kf = *reinterpret_cast<const float4*>(Ks + (kb + 4 * g + r) * kStr + 4 * j);
         dq[0] = mfma16(kf.x, ds[r], dq[0]);
         dq[1] = mfma16(kf.y, ds[r], dq[1]);
         dq[2] = mfma16(kf.z, ds[r], dq[2]);
         dq[3] = mfma16(kf.w, ds[r], dq[3]);
       }
     }
-    float* drow = a.dqkv + ((long)b * T + q0 + j) * a.ld_qkv + h * kDh + 16 * g;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) *reinterpret_cast<float4*>(drow + 4 * r) = make_float4(dq[0][r], dq[1][r], dq[2][r], dq[3][r]);
   }
+  float* drow = a.dqkv + ((long)b * T + q0 + j) * a.ld_qkv + h * kDh + 16 * g;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) *reinterpret_cast<float4*>(drow + 4 * r) = make_float4(dq[0][r], dq[1][r], dq[2][r], dq[3][r]);
 }
 
 bool attn_shape_ok(int T, int dh) { return T == 192 && dh == kDh; }
@@ -355,10 +401,10 @@ extern "C" int pe_attn_fwd(const float* qkv, long ld_qkv, float* o, long ld_o, f
   a.qkv = qkv; a.ld_qkv = ld_qkv; a.D = H * dh; a.o = o; a.ld_o = ld_o; a.lse = lse;
   a.mask_in = mask_in; a.mask_out = mask_out; a.B = B; a.H = H; a.scale = scale; a.p_drop = p_drop;
   a.keep_scale = 1.0f / (1.0f - p_drop); a.seed = seed; a.offset = offset;
-  const size_t lds = (size_t)3 * 192 * kStr * sizeof(float);
+  const size_t lds = (size_t)2 * 96 * kStr * sizeof(float);
   static bool attr = false;
   if (!attr) { PE_CHECK_HIP((hipError_t)set_lds(&attn_fwd_kernel<192>, lds)); attr = true; }
-  hipLaunchKernelGGL(attn_fwd_kernel<192>, dim3(B * H), dim3(256), lds, pe_stream(stream), a);
+  hipLaunchKernelGGL(attn_fwd_kernel<192>, dim3(B * H * 3), dim3(256), lds, pe_stream(stream), a);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }
@@ -374,17 +420,17 @@ extern "C" int pe_attn_bwd(const float* qkv, long ld_qkv, const float* o, const 
   a.qkv = qkv; a.ld_qkv = ld_qkv; a.D = H * dh; a.o = const_cast<float*>(o); a.ld_o = ld_o;
   a.lse = const_cast<float*>(lse); a.d_o = d_o; a.dqkv = dqkv; a.mask = p_drop > 0.f ? mask : nullptr;
   a.B = B; a.H = H; a.scale = scale; a.p_drop = p_drop; a.keep_scale = 1.0f / (1.0f - p_drop);
-  const size_t lds = (size_t)(2 * 192 * kStr + 2 * 192) * sizeof(float);
+  const size_t lds_kv = (size_t)(2 * 96 * kStr + 2 * 192) * sizeof(float), lds_q = (size_t)2 * 96 * kStr * sizeof(float);
   static bool attr = false;
   if (!attr) {
-    PE_CHECK_HIP((hipError_t)set_lds(&attn_bwd_kv_kernel<192>, lds));
-    PE_CHECK_HIP((hipError_t)set_lds(&attn_bwd_q_kernel<192>, lds));
+    PE_CHECK_HIP((hipError_t)set_lds(&attn_bwd_kv_kernel<192>, lds_kv));
+    PE_CHECK_HIP((hipError_t)set_lds(&attn_bwd_q_kernel<192>, lds_q));
     attr = true;
   }
   hipStream_t st = pe_stream(stream);
-  hipLaunchKernelGGL(attn_bwd_kv_kernel<192>, dim3(B * H), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(attn_bwd_kv_kernel<192>, dim3(B * H * 3), dim3(256), lds_kv, st, a);
   PE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(attn_bwd_q_kernel<192>, dim3(B * H), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(attn_bwd_q_kernel<192>, dim3(B * H * 3), dim3(256), lds_q, st, a);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }
