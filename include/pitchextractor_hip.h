@@ -135,9 +135,13 @@ size_t pe_wfrag_bytes(int N, int K, int terms);
 int pe_wfrag_pack(const float* w, long ld, int N, int K, int terms, void* wfrag, void* stream);
 int pe_conv3x3_wf_supported(int F, int C, int N);
 int pe_conv3x3_fwd_wf_x3(const float* x, const void* wfrag, float* y, int B, int T, int F, int C, int N,
-                         int accumulate, void* stream);
+                         int accumulate, double* bn_partials, void* stream);
 int pe_conv3x3_fwd_wf_bf16(const float* x, const void* wfrag, float* y, int B, int T, int F, int C, int N,
-                           int accumulate, void* stream);
+                           int accumulate, double* bn_partials, void* stream);
+/* bn_partials (optional): [pe_conv3x3_wf_stat_parts(B,T,F)][2][N] doubles -- per pixel tile, the column sums and sums
+ * of squares of the FINAL outputs; pe_bn_finalize_stats turns them into the statistics of the BatchNorm that follows
+ * (no separate pass over the activation). */
+int pe_conv3x3_wf_stat_parts(int B, int T, int F);
 size_t pe_conv3x3_wgrad_workspace_bytes(int B, int T, int F, int Cin, int Cout);
 int pe_conv3x3_wgrad(const float* x, const float* dy, float* dw_oihw, int B, int T, int F, int Cin,
                      int Cout, float* workspace, size_t workspace_bytes, void* stream);
@@ -178,7 +182,7 @@ int pe_gemm_tn_f16(const float* A, long lda, const float* B, long ldb, float* C,
 int pe_conv3x3_fwd_f16(const float* x, const float* w_packed, float* y, int B, int T, int F, int C, int N,
                         int accumulate, void* stream);
 int pe_conv3x3_fwd_wf_f16(const float* x, const void* wfrag, float* y, int B, int T, int F, int C, int N,
-                           int accumulate, void* stream);
+                          int accumulate, double* bn_partials, void* stream);
 int pe_conv3x3_wgrad_f16(const float* x, const float* dy, float* dw_oihw, int B, int T, int F, int Cin,
                           int Cout, float* workspace, size_t workspace_bytes, void* stream);
 int pe_lstm_fwd_persistent_f16(int ncells, const float* const* whh, float* const* gates, float* const* y,
@@ -202,6 +206,9 @@ size_t pe_bn_workspace_bytes(int C);
 int pe_bn_train_stats(const float* x, long n_pix, int C, const float* gamma, const float* beta, float eps,
                       float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
                       float* scale, float* shift, void* workspace, size_t workspace_bytes, void* stream);
+int pe_bn_finalize_stats(const double* partials, int nparts, long n_pix, int C, const float* gamma, const float* beta,
+                         float eps, float momentum, float* running_mean, float* running_var, float* mean,
+                         float* invstd, float* scale, float* shift, void* stream);
 int pe_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
                       const float* running_var, float eps, int C, float* scale, float* shift, void* stream);
 int pe_bn_act_pool_fwd(const float* x, const float* scale, const float* shift, float slope, float* y,

@@ -57,8 +57,8 @@ PROTOTYPES = {
     "pe_wfrag_bytes": (_z, [_i, _i, _i]),
     "pe_wfrag_pack": (_i, [_p, _l, _i, _i, _i, _p, _p]),
     "pe_conv3x3_wf_supported": (_i, [_i, _i, _i]),
-    "pe_conv3x3_fwd_wf_x3": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
-    "pe_conv3x3_fwd_wf_bf16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "pe_conv3x3_fwd_wf_x3": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "pe_conv3x3_fwd_wf_bf16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "pe_conv3x3_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
     "pe_conv3x3_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
     "pe_conv3x3_wgrad_x3": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
@@ -67,6 +67,8 @@ PROTOTYPES = {
     "pe_conv3x3_c1_wgrad": (_i, [_p, _l, _l, _l, _p, _p, _i, _i, _i, _p, _z, _p]),
     "pe_bn_workspace_bytes": (_z, [_i]),
     "pe_bn_train_stats": (_i, [_p, _l, _i, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "pe_conv3x3_wf_stat_parts": (_i, [_i, _i, _i]),
+    "pe_bn_finalize_stats": (_i, [_p, _i, _l, _i, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p]),
     "pe_bn_eval_affine": (_i, [_p, _p, _p, _p, _f, _i, _p, _p, _p]),
     "pe_bn_act_pool_fwd": (_i, [_p, _p, _p, _f, _p, _l, _i, _i, _i, _l, _i, _p]),
     "pe_bn_act_pool_bwd": (_i, [_p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _l, _i, _i, _i, _l, _i, _p, _z, _p]),
@@ -117,7 +119,7 @@ PROTOTYPES = {
     "pe_gemm_nt_wf_f16": (_i, [_p, _l, _p, _p, _l, _i, _i, _i, _p, _p, _i, _p]),
     "pe_gemm_tn_f16": (_i, [_p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _p, _z, _p]),
     "pe_conv3x3_fwd_f16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
-    "pe_conv3x3_fwd_wf_f16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "pe_conv3x3_fwd_wf_f16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "pe_conv3x3_wgrad_f16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
     "pe_lstm_fwd_persistent_f16": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _p, _p]),
     "pe_lstm_bwd_persistent_f16": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _p, _p]),

@@ -41,6 +41,7 @@ __global__ void transpose2d_kernel(const float* __restrict__ in, float* __restri
 struct ConvEpi {
   float* Y;
   int rows, N, accumulate;
+  double* stats;          // optional [tiles_m][2][N]: per-tile column sums / sums of squares of the final outputs
   __device__ __forceinline__ void operator()(int row, int col, float v) const {
     if (row < rows && col < N) {
       float* d = Y + (long)row * N + col;
@@ -72,7 +73,7 @@ int launch_conv(const float* x, const float* wp, float* y, int B, int T, int F, 
   ConvLoader<TL::A_LOADS> al;
   al.p = x; al.T = T; al.F = F; al.C = C; al.rows = rows;
   RowLoader bl{wp, (long)K, N, K, 0};
-  ConvEpi ep{y, rows, N, accumulate};
+  ConvEpi ep{y, rows, N, accumulate, nullptr};
   const int tm = pe_cdiv(rows, TL::BM), tn = pe_cdiv(N, TL::BN);
   hipLaunchKernelGGL((conv3x3_kernel<TL, MODE>), dim3(tm * tn), dim3(256), 0, st, al, bl, ep, K, tm, tn);
   PE_LAUNCH_CHECK();
@@ -218,20 +219,60 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const float* __res
       }
     }
   }
+  // ---- epilogue.  With ep.stats the BatchNorm statistics of the layer that consumes this output (model.py:25,37,
+  // 150,159) are a by-product: per-column sum and sum of squares of the FINAL values (after the residual add) over
+  // this tile's 128 pixels, in double, written as one partial per (pixel tile, column) -- the separate 1 GB
+  // statistics pass over the activation disappears (pe_bn_finalize_stats sums the partials in a fixed order).
+  double s1[TN], s2[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) s1[j] = s2[j] = 0.0;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int g = 0; g < 16; ++g)
-        ep(p0 + wm * 64 + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * h, n0 + wn * WN + j * 32 + r, acc[i][j][g]);
+      for (int g = 0; g < 16; ++g) {
+        const int row = p0 + wm * 64 + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * h, col = n0 + wn * WN + j * 32 + r;
+        if (row < ep.rows && col < ep.N) {
+          float* d = ep.Y + (long)row * ep.N + col;
+          float v = acc[i][j][g];
+          if (ep.accumulate) v += *d;
+          *d = v;
+          s1[j] += (double)v;
+          s2[j] += (double)v * (double)v;
+        }
+      }
+  if (ep.stats) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      s1[j] += __shfl_xor(s1[j], 32, 64);                          // the two lane halves hold different rows
+      s2[j] += __shfl_xor(s2[j], 32, 64);
+    }
+    __syncthreads();                                               // the activation window is dead: reuse its space
+    double* red = reinterpret_cast<double*>(As);                   // [2 (wm)][BN][2]
+    if (h == 0) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        red[(wm * BN + wn * WN + j * 32 + r) * 2] = s1[j];
+        red[(wm * BN + wn * WN + j * 32 + r) * 2 + 1] = s2[j];
+      }
+    }
+    __syncthreads();
+    const long tile_m = tile / tiles_n;
+    for (int c = tid; c < BN; c += 256) {
+      if (n0 + c < ep.N) {
+        ep.stats[(tile_m * 2) * ep.N + n0 + c] = red[c * 2] + red[(BN + c) * 2];
+        ep.stats[(tile_m * 2 + 1) * ep.N + n0 + c] = red[c * 2 + 1] + red[(BN + c) * 2 + 1];
+      }
+    }
+  }
 }
 
 template <int BN, int MODE, int PASSES>
 int launch_conv_halo(const float* x, const float* wp, float* y, int B, int T, int F, int C, int N, int accumulate,
                      hipStream_t st) {
   const int P = B * T * F;
-  ConvEpi ep{y, P, N, accumulate};
+  ConvEpi ep{y, P, N, accumulate, nullptr};
   const int tm = pe_cdiv(P, 128), tn = pe_cdiv(N, BN);
   hipLaunchKernelGGL((conv3x3_halo_kernel<BN, MODE, PASSES>), dim3(tm * tn), dim3(256), 0, st, x, wp, ep, T, F, C, N, P, tm,
                      tn);
@@ -403,20 +444,60 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_wf_kernel(const float* __
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  // ---- epilogue.  With ep.stats the BatchNorm statistics of the layer that consumes this output (model.py:25,37,
+  // 150,159) are a by-product: per-column sum and sum of squares of the FINAL values (after the residual add) over
+  // this tile's 128 pixels, in double, written as one partial per (pixel tile, column) -- the separate 1 GB
+  // statistics pass over the activation disappears (pe_bn_finalize_stats sums the partials in a fixed order).
+  double s1[TN], s2[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) s1[j] = s2[j] = 0.0;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int g = 0; g < 16; ++g)
-        ep(p0 + wm * 64 + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * h, n0 + wn * WN + j * 32 + r, acc[i][j][g]);
+      for (int g = 0; g < 16; ++g) {
+        const int row = p0 + wm * 64 + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * h, col = n0 + wn * WN + j * 32 + r;
+        if (row < ep.rows && col < ep.N) {
+          float* d = ep.Y + (long)row * ep.N + col;
+          float v = acc[i][j][g];
+          if (ep.accumulate) v += *d;
+          *d = v;
+          s1[j] += (double)v;
+          s2[j] += (double)v * (double)v;
+        }
+      }
+  if (ep.stats) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      s1[j] += __shfl_xor(s1[j], 32, 64);                          // the two lane halves hold different rows
+      s2[j] += __shfl_xor(s2[j], 32, 64);
+    }
+    __syncthreads();                                               // the activation window is dead: reuse its space
+    double* red = reinterpret_cast<double*>(As);                   // [2 (wm)][BN][2]
+    if (h == 0) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        red[(wm * BN + wn * WN + j * 32 + r) * 2] = s1[j];
+        red[(wm * BN + wn * WN + j * 32 + r) * 2 + 1] = s2[j];
+      }
+    }
+    __syncthreads();
+    const long tile_m = tile / tiles_n;
+    for (int c = tid; c < BN; c += 256) {
+      if (n0 + c < ep.N) {
+        ep.stats[(tile_m * 2) * ep.N + n0 + c] = red[c * 2] + red[(BN + c) * 2];
+        ep.stats[(tile_m * 2 + 1) * ep.N + n0 + c] = red[c * 2 + 1] + red[(BN + c) * 2 + 1];
+      }
+    }
+  }
 }
 
 template <int BN, int MODE, int PASSES, int D, bool FA2>
 int launch_conv_halo_wf(const float* x, const void* wf, float* y, int B, int T, int F, int C, int N, int accumulate,
-                        hipStream_t st) {
+                        double* stats, hipStream_t st) {
   const int P = B * T * F;
-  ConvEpi ep{y, P, N, accumulate};
+  ConvEpi ep{y, P, N, accumulate, stats};
   const int tm = pe_cdiv(P, 128), tn = pe_cdiv(N, BN);
   hipLaunchKernelGGL((conv3x3_halo_wf_kernel<BN, MODE, PASSES, D, FA2>), dim3(tm * tn), dim3(256), 0, st, x,
                      reinterpret_cast<const uint4*>(wf), ep, T, F, C, N, P, tm, tn);
@@ -920,6 +1001,9 @@ extern "C" int pe_wfrag_pack(const float* w, long ld, int N, int K, int terms, v
 extern "C" int pe_conv3x3_wf_supported(int F, int C, int N) {
   return (C % 32) == 0 && conv_halo_passes(F, N) != 0 ? 1 : 0;
 }
+
+// number of per-tile BatchNorm partials pe_conv3x3_fwd_wf_* writes: bn_partials is [parts][2][N] doubles
+extern "C" int pe_conv3x3_wf_stat_parts(int B, int T, int F) { return pe_cdiv((long)B * T * F, 128); }
 #endif
 
 #ifdef PE_F16_BUILD
@@ -936,30 +1020,30 @@ extern "C" int pe_wfrag_pack_f16(const float* w, long ld, int N, int K, void* ou
 #endif
 template <int MODE>
 static int conv3x3_fwd_wf_impl(const float* x, const void* wfrag, float* y, int B, int T, int F, int C, int N,
-                               int accumulate, void* stream) {
+                               int accumulate, double* stats, void* stream) {
   if (!x || !wfrag || !y || B <= 0 || T <= 0 || F <= 0 || C <= 0 || N <= 0) return PE_E_ARG;
   if ((C % 32) != 0 || (long)B * T * F * (C > N ? C : N) >= (1L << 31)) return PE_E_UNSUPPORTED;
   hipStream_t st = pe_stream(stream);
   const int passes = conv_halo_passes(F, N);
-  if (passes == 10) return launch_conv_halo_wf<64, MODE, 10, 6, true>(x, wfrag, y, B, T, F, C, N, accumulate, st);
+  if (passes == 10) return launch_conv_halo_wf<64, MODE, 10, 6, true>(x, wfrag, y, B, T, F, C, N, accumulate, stats, st);
   if (passes == 7) {
     if (N % 192 == 0 && N % 128 != 0)
-      return launch_conv_halo_wf<192, MODE, 7, 3, false>(x, wfrag, y, B, T, F, C, N, accumulate, st);
-    return launch_conv_halo_wf<128, MODE, 7, 3, true>(x, wfrag, y, B, T, F, C, N, accumulate, st);
+      return launch_conv_halo_wf<192, MODE, 7, 3, false>(x, wfrag, y, B, T, F, C, N, accumulate, stats, st);
+    return launch_conv_halo_wf<128, MODE, 7, 3, true>(x, wfrag, y, B, T, F, C, N, accumulate, stats, st);
   }
   return PE_E_UNSUPPORTED;
 }
 
 #ifndef PE_F16_BUILD
 extern "C" int pe_conv3x3_fwd_wf_x3(const float* x, const void* wfrag, float* y, int B, int T, int F, int C, int N,
-                                    int accumulate, void* stream) {
-  return conv3x3_fwd_wf_impl<kSplit>(x, wfrag, y, B, T, F, C, N, accumulate, stream);
+                                    int accumulate, double* bn_partials, void* stream) {
+  return conv3x3_fwd_wf_impl<kSplit>(x, wfrag, y, B, T, F, C, N, accumulate, bn_partials, stream);
 }
 #endif
 
 extern "C" int PE_HALF(pe_conv3x3_fwd_wf)(const float* x, const void* wfrag, float* y, int B, int T, int F, int C, int N,
-                                      int accumulate, void* stream) {
-  return conv3x3_fwd_wf_impl<kBf16>(x, wfrag, y, B, T, F, C, N, accumulate, stream);
+                                      int accumulate, double* bn_partials, void* stream) {
+  return conv3x3_fwd_wf_impl<kBf16>(x, wfrag, y, B, T, F, C, N, accumulate, bn_partials, stream);
 }
 
 #ifndef PE_F16_BUILD

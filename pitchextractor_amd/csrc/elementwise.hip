@@ -523,6 +523,20 @@ extern "C" int pe_bn_train_stats(const float* x, long n_pix, int C, const float*
   return PE_OK;
 }
 
+// BatchNorm training statistics from partials a producer kernel left behind ([nparts][2][C] doubles: column sums
+// and sums of squares, e.g. pe_conv3x3_fwd_wf_*'s bn_partials): the finalize half of pe_bn_train_stats.
+extern "C" int pe_bn_finalize_stats(const double* partials, int nparts, long n_pix, int C, const float* gamma,
+                                    const float* beta, float eps, float momentum, float* running_mean,
+                                    float* running_var, float* mean, float* invstd, float* scale, float* shift,
+                                    void* stream) {
+  if (!partials || !gamma || !beta || !mean || !invstd || !scale || !shift || n_pix <= 0 || nparts <= 0) return PE_E_ARG;
+  if (!bn_channels_ok(C)) return PE_E_UNSUPPORTED;
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(pe_cdiv(C, 4)), dim3(256), 0, pe_stream(stream), partials, nparts,
+                     n_pix, C, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+
 extern "C" int pe_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
                                  const float* running_var, float eps, int C, float* scale, float* shift,
                                  void* stream) {

@@ -187,9 +187,11 @@ class _Ctx:
     """Tensors one forward pass leaves behind for its backward."""
 
 
-def _bn(mod: _BatchNorm, x, train: bool):
+def _bn(mod: _BatchNorm, x, train: bool, partials=None):
+    """``partials``: column sums the convolution that produced x left behind (no pass over x for the statistics)."""
     if train:
-        st = ops.bn_train_stats(x, mod.weight, mod.bias, mod.running_mean, mod.running_var, mod.eps, mod.momentum)
+        st = ops.bn_train_stats(x, mod.weight, mod.bias, mod.running_mean, mod.running_var, mod.eps, mod.momentum,
+                                partials=partials)
         mod.num_batches_tracked += 1
         return st
     return ops.bn_eval_affine(mod.weight, mod.bias, mod.running_mean, mod.running_var, mod.eps)
@@ -199,20 +201,20 @@ def _flat2(t):
     return t.view(-1, t.shape[-1])
 
 
-def _res_forward(blk: _ResBlock, x, pool, train, need_grad, slope):
-    """x [B,T,F,Cin] -> [B,T,F/pool,Cout]; returns (out, saved)."""
+def _res_forward(blk: _ResBlock, x, pool, train, need_grad, slope, x_stats=None):
+    """x [B,T,F,Cin] -> [B,T,F/pool,Cout]; returns (out, saved, BatchNorm partials of out or None)."""
     s = _Ctx()
     s.x = x
-    s.bn_pre = _bn(blk.pre_conv[0], x, train)
+    s.bn_pre = _bn(blk.pre_conv[0], x, train, x_stats)
     s.p = ops.bn_act_pool_fwd(x, s.bn_pre, pool=pool, slope=slope)
     out = ops.gemm_nt(_flat2(s.p), blk.conv1by1.weight.view(blk.cout, blk.cin)).view(*s.p.shape[:3], blk.cout)
     wf0, s.wd0 = ops.conv3x3_repack(blk.conv[0].weight, True, need_grad)
-    s.c = ops.conv3x3_fwd(s.p, wf0)
-    s.bn_mid = _bn(blk.conv[1], s.c, train)
+    s.c, c_stats = ops.conv3x3_fwd(s.p, wf0, bn_stats=train)
+    s.bn_mid = _bn(blk.conv[1], s.c, train, c_stats)
     s.a = ops.bn_act_pool_fwd(s.c, s.bn_mid, pool=1, slope=slope)
     wf3, s.wd3 = ops.conv3x3_repack(blk.conv[3].weight, True, need_grad)
-    ops.conv3x3_fwd(s.a, wf3, out=out, accumulate=True)      # conv(x) + conv1by1(x), model.py:171-172
-    return out, s
+    _, out_stats = ops.conv3x3_fwd(s.a, wf3, out=out, accumulate=True, bn_stats=train)   # conv(x) + conv1by1(x), model.py:171-172
+    return out, s, out_stats
 
 
 def _res_backward(blk: _ResBlock, s, d_out, pool, slope, grads):
@@ -610,16 +612,16 @@ class JDCNet(nn.Module):
         s.bn0 = _bn(cbk[1], s.y0, train)
         s.a0 = ops.bn_act_pool_fwd(s.y0, s.bn0, pool=1, slope=slope)
         wf, s.wd_cb = ops.conv3x3_repack(cbk[3].weight, True, need_grad)
-        s.cb = ops.conv3x3_fwd(s.a0, wf)                                            # convblock_out
-        s.rb1, s.r1 = _res_forward(self.res_block1, s.cb, 2, train, need_grad, slope)
-        s.rb2, s.r2 = _res_forward(self.res_block2, s.rb1, 2, train, need_grad, slope)
-        s.rb3, s.r3 = _res_forward(self.res_block3, s.rb2, 2, train, need_grad, slope)
+        s.cb, st_cb = ops.conv3x3_fwd(s.a0, wf, bn_stats=train)                      # convblock_out
+        s.rb1, s.r1, st1 = _res_forward(self.res_block1, s.cb, 2, train, need_grad, slope, st_cb)
+        s.rb2, s.r2, st2 = _res_forward(self.res_block2, s.rb1, 2, train, need_grad, slope, st1)
+        s.rb3, s.r3, st3 = _res_forward(self.res_block3, s.rb2, 2, train, need_grad, slope, st2)
 
         # pool_block -> channels [384, 640) of the detector concat (model.py:36-41,90,108)
         Fp = s.rb3.shape[2] // 4
         if Fp != 2:
             raise ValueError("JDCNet geometry expects 80 mel bins (F/40 == 2)")
-        s.bnp = _bn(self.pool_block[0], s.rb3, train)
+        s.bnp = _bn(self.pool_block[0], s.rb3, train, st3)
         pooled = ops.bn_act_pool_fwd(s.rb3, s.bnp, pool=4, slope=slope)            # [B,T,2,256]
         s.concat = torch.empty((B, T, 2, 640), dtype=torch.float32, device=x.device)
         p_blk = self.block_dropout if train else 0.0

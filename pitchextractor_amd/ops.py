@@ -276,8 +276,10 @@ def conv3x3_repack(w, want_fwd=True, want_dgrad=True):
     return out[0], out[1]
 
 
-def conv3x3_fwd(x, w_packed, out=None, accumulate=False):
-    """x [B,T,F,C], w_packed [N, 9*C] (tensor or PackedWeight) -> y [B,T,F,N] (+= when accumulate)."""
+def conv3x3_fwd(x, w_packed, out=None, accumulate=False, bn_stats=False):
+    """x [B,T,F,C], w_packed [N, 9*C] (tensor or PackedWeight) -> y [B,T,F,N] (+= when accumulate).
+    ``bn_stats=True`` returns (y, partials): the fragment-fed kernel leaves the BatchNorm column sums of its final
+    outputs behind ([tiles, 2, N] float64, for ``bn_train_stats(..., partials=)``); None when another kernel ran."""
     x = _dense(x, "x")
     pw = w_packed if isinstance(w_packed, PackedWeight) else PackedWeight(w_packed)
     w32 = _dense(pw.fp32, "w_packed")
@@ -292,12 +294,16 @@ def conv3x3_fwd(x, w_packed, out=None, accumulate=False):
     sfx = _nt_suffix()
     if (pw.frag is not None and pw.terms == _mode_terms() and CONV_WFRAG
             and (pw.terms != 1 or pw.half == HALF_DTYPE) and _lib.load().pe_conv3x3_wf_supported(F, Cc, N)):
+        parts = None
+        if bn_stats:
+            parts = torch.empty((_lib.load().pe_conv3x3_wf_stat_parts(B, T, F), 2, N), dtype=torch.float64,
+                                device=x.device)
         _call("pe_conv3x3_fwd_wf" + sfx, x.data_ptr(), pw.frag.data_ptr(), out.data_ptr(), B, T, F, Cc, N,
-              int(bool(accumulate)), _s(), work=2.0 * B * T * F * N * 9 * Cc)
-        return out
+              int(bool(accumulate)), _lib.ptr(parts), _s(), work=2.0 * B * T * F * N * 9 * Cc)
+        return (out, parts) if bn_stats else out
     _call("pe_conv3x3_fwd" + sfx, x.data_ptr(), w32.data_ptr(), out.data_ptr(), B, T, F, Cc, N,
           int(bool(accumulate)), _s(), work=2.0 * B * T * F * N * 9 * Cc)
-    return out
+    return (out, None) if bn_stats else out
 
 
 def conv3x3_wgrad(x, dy, dw):
@@ -355,7 +361,9 @@ class BnState:
         self.mean, self.invstd, self.scale, self.shift = buf[0], buf[1], buf[2], buf[3]
 
 
-def bn_train_stats(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1):
+def bn_train_stats(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1, partials=None):
+    """Train-mode BatchNorm statistics of x [.., C].  ``partials`` ([parts, 2, C] float64 column sums / sums of
+    squares left behind by the kernel that produced x) skips the pass over x."""
     x = _dense(x, "x")
     Cc = x.shape[-1]
     for t, n in ((gamma, "gamma"), (beta, "beta"), (running_mean, "running_mean"), (running_var, "running_var")):
@@ -363,6 +371,13 @@ def bn_train_stats(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum
             _chk(_dense(t, n).numel() == Cc, f"{n}: size")
     st = BnState(Cc, x.device)
     lib = _lib.load()
+    if partials is not None:
+        _chk(partials.is_cuda and partials.dtype == torch.float64 and partials.is_contiguous() and partials.dim() == 3
+             and partials.shape[1:] == (2, Cc), "bn_train_stats: partials [parts, 2, C] float64")
+        _call("pe_bn_finalize_stats", partials.data_ptr(), partials.shape[0], x.numel() // Cc, Cc, gamma.data_ptr(),
+              beta.data_ptr(), eps, momentum, _lib.ptr(running_mean), _lib.ptr(running_var), st.mean.data_ptr(),
+              st.invstd.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), _s())
+        return st
     ws = workspace(lib.pe_bn_workspace_bytes(Cc), x.device)
     _call("pe_bn_train_stats", x.data_ptr(), x.numel() // Cc, Cc, gamma.data_ptr(), beta.data_ptr(), eps, momentum,
           _lib.ptr(running_mean), _lib.ptr(running_var), st.mean.data_ptr(), st.invstd.data_ptr(),

@@ -233,6 +233,29 @@ def test_conv3x3_fragment_fed_kernel_is_bit_identical(hip_device, B, T, Fq, Ci, 
     assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
 
 
+@pytest.mark.parametrize("B,T,Fq,Ci,Co,acc", [(3, 16, 40, 128, 128, False), (2, 5, 20, 128, 192, True), (1, 3, 80, 64, 64, False),
+                                              (2, 9, 10, 192, 256, True)])
+def test_conv3x3_epilogue_bn_statistics(hip_device, B, T, Fq, Ci, Co, acc, monkeypatch):
+    """BatchNorm statistics as a by-product of the convolution epilogue (column sums of the FINAL outputs, incl. the
+    residual accumulate) == the separate statistics pass over the stored activation, incl. the running-stat update;
+    pixel counts that are not multiples of the 128-pixel tile."""
+    monkeypatch.setattr(ops, "FP32_MATMUL", "x3")
+    x = nhwc(rnd(B, Ci, T, Fq, seed=1)).to(hip_device)
+    w = rnd(Co, Ci, 3, 3, seed=2, scale=0.1).to(hip_device)
+    wf, _ = ops.conv3x3_repack(w, True, False)
+    out = rnd(B, T, Fq, Co, seed=3).to(hip_device) if acc else None
+    y, parts = ops.conv3x3_fwd(x, wf, out=out, accumulate=acc, bn_stats=True)
+    assert parts is not None and parts.shape[1:] == (2, Co)
+    gamma, beta = (rnd(Co, seed=4).abs() + 0.5).to(hip_device), rnd(Co, seed=5).to(hip_device)
+    rm_a, rv_a = rnd(Co, seed=6).to(hip_device), (rnd(Co, seed=7).abs() + 0.5).to(hip_device)
+    rm_b, rv_b = rm_a.clone(), rv_a.clone()
+    st_a = ops.bn_train_stats(y, gamma, beta, rm_a, rv_a)
+    st_b = ops.bn_train_stats(y, gamma, beta, rm_b, rv_b, partials=parts)
+    for u, v in ((st_a.mean, st_b.mean), (st_a.invstd, st_b.invstd), (st_a.scale, st_b.scale), (st_a.shift, st_b.shift),
+                 (rm_a, rm_b), (rv_a, rv_b)):
+        close(v, u.cpu(), 1e-6)
+
+
 def test_conv3x3_first_layer(hip_device):
     B, T, Fq = 3, 17, 80
     mel = rnd(B, 1, Fq, T, seed=1)                          # (B,1,80,T) as the loader yields it
