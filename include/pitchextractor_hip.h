@@ -208,7 +208,8 @@ int pe_bn_train_stats(const float* x, long n_pix, int C, const float* gamma, con
                       float* scale, float* shift, void* workspace, size_t workspace_bytes, void* stream);
 int pe_bn_finalize_stats(const double* partials, int nparts, long n_pix, int C, const float* gamma, const float* beta,
                          float eps, float momentum, float* running_mean, float* running_var, float* mean,
-                         float* invstd, float* scale, float* shift, void* stream);
+                         float* invstd, float* scale, float* shift, void* workspace, size_t workspace_bytes,
+                         void* stream);   /* workspace: pe_bn_workspace_bytes(C) */
 int pe_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
                       const float* running_var, float eps, int C, float* scale, float* shift, void* stream);
 int pe_bn_act_pool_fwd(const float* x, const float* scale, const float* shift, float slope, float* y,

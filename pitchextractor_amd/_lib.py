@@ -68,7 +68,7 @@ PROTOTYPES = {
     "pe_bn_workspace_bytes": (_z, [_i]),
     "pe_bn_train_stats": (_i, [_p, _l, _i, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _z, _p]),
     "pe_conv3x3_wf_stat_parts": (_i, [_i, _i, _i]),
-    "pe_bn_finalize_stats": (_i, [_p, _i, _l, _i, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p]),
+    "pe_bn_finalize_stats": (_i, [_p, _i, _l, _i, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _z, _p]),
     "pe_bn_eval_affine": (_i, [_p, _p, _p, _p, _f, _i, _p, _p, _p]),
     "pe_bn_act_pool_fwd": (_i, [_p, _p, _p, _f, _p, _l, _i, _i, _i, _l, _i, _p]),
     "pe_bn_act_pool_bwd": (_i, [_p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _l, _i, _i, _i, _l, _i, _p, _z, _p]),

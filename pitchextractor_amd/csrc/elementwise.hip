@@ -54,6 +54,17 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
       n_pix, C, partial);
 }
 
+// [nparts][2][C] -> [gridDim.x][2][C]: a thread owns one of the 2C columns, so every read is coalesced across the
+// block; part p goes to block p % gridDim.x and is added in increasing p (fixed order: deterministic)
+__global__ __launch_bounds__(256) void bn_partials_fold_kernel(const double* __restrict__ partial, int nparts, int C2,
+                                                               double* __restrict__ out) {
+  for (int col = threadIdx.x; col < C2; col += 256) {
+    double s = 0.0;
+    for (int p = blockIdx.x; p < nparts; p += gridDim.x) s += partial[(long)p * C2 + col];
+    out[(long)blockIdx.x * C2 + col] = s;
+  }
+}
+
 __global__ void bn_stats_finalize_kernel(const double* __restrict__ partial, int nparts, long n_pix, int C,
                                          const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                          float momentum, float* __restrict__ running_mean,
@@ -528,11 +539,22 @@ extern "C" int pe_bn_train_stats(const float* x, long n_pix, int C, const float*
 extern "C" int pe_bn_finalize_stats(const double* partials, int nparts, long n_pix, int C, const float* gamma,
                                     const float* beta, float eps, float momentum, float* running_mean,
                                     float* running_var, float* mean, float* invstd, float* scale, float* shift,
-                                    void* stream) {
+                                    void* workspace, size_t workspace_bytes, void* stream) {
   if (!partials || !gamma || !beta || !mean || !invstd || !scale || !shift || n_pix <= 0 || nparts <= 0) return PE_E_ARG;
   if (!bn_channels_ok(C)) return PE_E_UNSUPPORTED;
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(pe_cdiv(C, 4)), dim3(256), 0, pe_stream(stream), partials, nparts,
-                     n_pix, C, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+  hipStream_t st = pe_stream(stream);
+  const double* src = partials;
+  int n = nparts;
+  if (nparts > 256) {                    // fold tens of thousands of tile partials to 128 with coalesced reads first
+    if (!workspace || workspace_bytes < (size_t)128 * 2 * C * sizeof(double)) return PE_E_WORKSPACE;
+    double* folded = reinterpret_cast<double*>(workspace);
+    hipLaunchKernelGGL(bn_partials_fold_kernel, dim3(128), dim3(256), 0, st, partials, nparts, 2 * C, folded);
+    PE_LAUNCH_CHECK();
+    src = folded;
+    n = 128;
+  }
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(pe_cdiv(C, 4)), dim3(256), 0, st, src, n, n_pix, C, gamma, beta,
+                     eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }

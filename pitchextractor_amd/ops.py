@@ -276,10 +276,11 @@ def conv3x3_repack(w, want_fwd=True, want_dgrad=True):
     return out[0], out[1]
 
 
-def conv3x3_fwd(x, w_packed, out=None, accumulate=False, bn_stats=False):
+def conv3x3_fwd(x, w_packed, out=None, accumulate=False, bn_stats=None):
     """x [B,T,F,C], w_packed [N, 9*C] (tensor or PackedWeight) -> y [B,T,F,N] (+= when accumulate).
-    ``bn_stats=True`` returns (y, partials): the fragment-fed kernel leaves the BatchNorm column sums of its final
-    outputs behind ([tiles, 2, N] float64, for ``bn_train_stats(..., partials=)``); None when another kernel ran."""
+    ``bn_stats`` True / False (not None) returns (y, partials): with True the fragment-fed kernel leaves the BatchNorm
+    column sums of its final outputs behind ([tiles, 2, N] float64, for ``bn_train_stats(..., partials=)``);
+    partials is None when not asked for or when another kernel ran."""
     x = _dense(x, "x")
     pw = w_packed if isinstance(w_packed, PackedWeight) else PackedWeight(w_packed)
     w32 = _dense(pw.fp32, "w_packed")
@@ -300,10 +301,10 @@ def conv3x3_fwd(x, w_packed, out=None, accumulate=False, bn_stats=False):
                                 device=x.device)
         _call("pe_conv3x3_fwd_wf" + sfx, x.data_ptr(), pw.frag.data_ptr(), out.data_ptr(), B, T, F, Cc, N,
               int(bool(accumulate)), _lib.ptr(parts), _s(), work=2.0 * B * T * F * N * 9 * Cc)
-        return (out, parts) if bn_stats else out
+        return (out, parts) if bn_stats is not None else out
     _call("pe_conv3x3_fwd" + sfx, x.data_ptr(), w32.data_ptr(), out.data_ptr(), B, T, F, Cc, N,
           int(bool(accumulate)), _s(), work=2.0 * B * T * F * N * 9 * Cc)
-    return (out, None) if bn_stats else out
+    return (out, None) if bn_stats is not None else out
 
 
 def conv3x3_wgrad(x, dy, dw):
@@ -374,9 +375,10 @@ def bn_train_stats(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum
     if partials is not None:
         _chk(partials.is_cuda and partials.dtype == torch.float64 and partials.is_contiguous() and partials.dim() == 3
              and partials.shape[1:] == (2, Cc), "bn_train_stats: partials [parts, 2, C] float64")
+        ws = workspace(lib.pe_bn_workspace_bytes(Cc), x.device)
         _call("pe_bn_finalize_stats", partials.data_ptr(), partials.shape[0], x.numel() // Cc, Cc, gamma.data_ptr(),
               beta.data_ptr(), eps, momentum, _lib.ptr(running_mean), _lib.ptr(running_var), st.mean.data_ptr(),
-              st.invstd.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), _s())
+              st.invstd.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), ws.data_ptr(), ws.numel(), _s())
         return st
     ws = workspace(lib.pe_bn_workspace_bytes(Cc), x.device)
     _call("pe_bn_train_stats", x.data_ptr(), x.numel() // Cc, Cc, gamma.data_ptr(), beta.data_ptr(), eps, momentum,
