@@ -249,8 +249,9 @@ int pe_lstm_bwd(int ncells, const float* const* whh_t, float* const* gates, cons
                 int H, void* stream);
 /* Persistent variants: one launch for all T steps, W_hh slice resident in registers, group barriers
  * between steps (agent-scope release/acquire).  `sync` = pe_lstm_persistent_sync_bytes() of device
- * memory, zero-initialised once by the caller; word 0 is a sticky error flag (non-zero = a bounded
- * spin timed out: results invalid).  Only when pe_lstm_persistent_supported() returns 1. */
+ * memory, zero-initialised once by the caller: the group counters, then the backward kernel's exchange
+ * region (the step's gate gradients in MFMA fragment order, two slots per batch tile).  Word 0 is a
+ * sticky error flag (non-zero = a bounded spin timed out: results invalid).  Only when pe_lstm_persistent_supported() returns 1. */
 size_t pe_lstm_persistent_sync_bytes(int ncells, int B);
 int pe_lstm_persistent_supported(int ncells, int B, int H);
 int pe_lstm_fwd_persistent(int ncells, const float* const* whh, float* const* gates, float* const* y,

@@ -28,6 +28,7 @@
 // rows split per use -- 144 v_mfma_f32_32x32x16_bf16 per item and wave instead of 192 fp32 MFMAs of
 // twice the cycles.  Everything about the hand-off protocol is identical in both forms.
 #include <stdlib.h>
+#include <type_traits>
 #include "gemm_engine.h"
 
 namespace {
@@ -128,6 +129,27 @@ __device__ __forceinline__ void split8(const float4& p, const float4& q, bf16x8 
   out[0] = __builtin_bit_cast(bf16x8, a);
   out[1] = __builtin_bit_cast(bf16x8, b);
   out[2] = __builtin_bit_cast(bf16x8, c);
+}
+// four values -> three terms of 4 bf16 each (same truncating split as split8)
+__device__ __forceinline__ void split4(const float4& p, u32x2 (&out)[3]) {
+  const f32x2 v[2] = {{p.x, p.y}, {p.z, p.w}};
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const u32x2 u0 = __builtin_bit_cast(u32x2, v[i]);
+    const f32x2 r1 = v[i] - __builtin_bit_cast(f32x2, u0 & 0xffff0000u);
+    const u32x2 u1 = __builtin_bit_cast(u32x2, r1);
+    const f32x2 r2 = r1 - __builtin_bit_cast(f32x2, u1 & 0xffff0000u);
+    const u32x2 u2 = __builtin_bit_cast(u32x2, r2);
+    out[0][i] = __builtin_amdgcn_perm(u0[1], u0[0], 0x07060302u);
+    out[1][i] = __builtin_amdgcn_perm(u1[1], u1[0], 0x07060302u);
+    out[2][i] = __builtin_amdgcn_perm(u2[1], u2[0], 0x07060302u);
+  }
+}
+typedef pe_half_t half_x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x2 round4(const float4& p) {
+  half_x4 o;
+  o[0] = (pe_half_t)p.x; o[1] = (pe_half_t)p.y; o[2] = (pe_half_t)p.z; o[3] = (pe_half_t)p.w;
+  return __builtin_bit_cast(u32x2, o);
 }
 // (a term, b term) of the six products.  a_hi x W_lo goes last: W_lo may come from LDS, and its read then
 // completes under the five products that do not need it.
@@ -960,6 +982,280 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_kernel(const PBwdC
   }
 }
 
+// --------------------------------------------------------------------------------------- backward, k-split
+// dh_t = dY_t + dgates_{t+1} . W_hh.  The kernel above gives workgroup jt the 32 output columns j of dh and has it
+// read ALL 4H gate gradients of its 32 batch rows: 192 KB per item and workgroup through one CU's 64 B/clk L1 path,
+// twelve times over per group -- s_memtime stamps put ~16 k of an item's 20 k cycles on those loads (tools/
+// stamp_lstm.py), the 144 MFMAs need 4.6 k.  This kernel splits the product over k instead: workgroup jt PRODUCES
+// the 128 gate gradients of its own hidden slice, so it multiplies exactly those -- they never leave the CU (LDS) --
+// with the matching 128 rows of W_hh for ALL H output columns, and hands each of the NJ consumers a 32 x 32 fp32
+// partial tile.  Per item a workgroup stores 4 KB to and loads 4 KB from each peer: 48 KB each way at H = 384, a
+// quarter of the read volume, and every transfer is a full-line 1 KB instruction.  Same MFMA count, same registers
+// for W.  dh sums the NJ partial tiles in producer order (fixed, so runs are reproducible).
+//   exchange region: [cell][batch tile][half][slot = step & 1][consumer][producer][i = col / 8][32 rows][8 cols]
+//   (two slots: a producer can only write step s + 2 after every peer has arrived at s + 1, i.e. has consumed s).
+// The MFMA operands are swapped (A = W_hh^T block, B = gate gradients) so that a lane ends up with 4 consecutive
+// COLUMNS of one batch row -- the float4 the consumer's gate-gradient update wants -- instead of 4 rows.
+// Schedule per workgroup (M = product + hand-off of a half, E = gate-gradient update of a half):
+//   E(0,0) E(0,1) M(1,0) | M(s,1) E(s,0) M(s+1,0) E(s,1) | ...   the wait for the peers' tiles of one half sits in
+// the middle of the other half's M, the tile loads land under the rest of it.
+constexpr int kXchgWord = 8192;          // exchange region starts this many words into the sync buffer
+
+template <int H, int TERMS, int NBR_, bool STAMP = false>
+__global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_ks_kernel(const PBwdCells cells, int B, int T, long lddy,
+                                                                        unsigned g_bytes, unsigned* sync) {
+  static_assert(TERMS == 3 || TERMS == 1, "bf16-term pipelines only");
+  static_assert(H % 128 == 0, "each wave owns whole 32-column blocks of dh");
+  constexpr int NJ = H / 32, K = 4 * H;
+  constexpr int NBW = H / 128;                      // 32-column blocks of dh per wave
+  constexpr int NKB = 8;                            // 16-k MFMA blocks over the 128 local k
+  constexpr int NBK = NBW * NKB;                    // W blocks per lane
+  constexpr int NBR = TERMS == 3 ? NBR_ : NBK;
+  constexpr unsigned TILE = 1024;                   // floats per 32 x 32 partial tile
+  constexpr unsigned SLOT = NJ * NJ * TILE;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NT = TERMS == 3 ? 3 : 1;
+  constexpr int DGH = NT * NKB * 2 * 32;            // uint4 per half
+  uint4* dg = reinterpret_cast<uint4*>(smem);       // [2 halves][term][NKB][2][32 rows] x 8 bf16: this slice's
+                                                    // gate gradients, already split, in B-fragment order
+  uint4* wlo_lds = dg + 2 * DGH;                    // [NBK - NBR][256]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int nbt = (B + 63) / 64;
+  int jt, gidx;
+  group_of_block(NJ, jt, gidx);
+  const int bt = gidx % nbt, cell = gidx / nbt;
+  const int j0 = jt * 32, b0 = bt * 64;
+  const int rev = cells.reverse[cell];
+  float* gates = cells.gates[cell];
+  const float* cb = cells.c[cell];
+  const float* dy = cells.dy[cell];
+  unsigned* err = sync;
+  unsigned* ctr = sync + kCtrStride * (1 + (cell * nbt + bt) * 2);
+  float* xbase = reinterpret_cast<float*>(sync + kXchgWord) + (size_t)(cell * nbt + bt) * 4 * SLOT;
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(xbase, 0, 4u * SLOT * 4u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(gates, 0, g_bytes, 0x00020000);
+
+  // W block (nb, kb): column n = wv * H/4 + nb * 32 + r of dh, k = gate (kb >> 1), hidden j0 + (kb & 1) * 16 + hh * 8 ..
+  bf16x8 bwhm[NBK][TERMS == 3 ? 2 : 1], bwlo[NBR > 0 ? NBR : 1];
+#pragma unroll
+  for (int nb = 0; nb < NBW; ++nb) {
+    const float* src = cells.whh_t[cell] + (long)(wv * (H / 4) + nb * 32 + r) * K + j0 + hh * 8;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      const int b = nb * NKB + kb;
+      const float* sp = src + (kb >> 1) * H + (kb & 1) * 16;
+      const float4 w0 = *reinterpret_cast<const float4*>(sp);
+      const float4 w1 = *reinterpret_cast<const float4*>(sp + 4);
+      if constexpr (TERMS == 3) {
+        bf16x8 t3[3];
+        split8(w0, w1, t3);
+        bwhm[b][0] = t3[0];
+        bwhm[b][1] = t3[1];
+        if (b < NBR) bwlo[b < NBR ? b : 0] = t3[2];
+        else wlo_lds[(b - NBR) * 256 + tid] = __builtin_bit_cast(uint4, t3[2]);
+      } else {
+        bwhm[b][0] = round8(w0, w1);
+      }
+    }
+  }
+  const int prow = tid >> 3, pq = tid & 7;
+  const int j = j0 + 4 * pq;
+  float4 dcar[2];
+  dcar[0] = dcar[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;
+
+  // inputs of one gate-gradient update (single set: issued after the previous update has consumed its own)
+  float4 in_dy, in_c, in_cp, in_g[4], part[NJ];
+  auto issue_inputs = [&](int step, int hf) {
+    const int t = rev ? step : T - 1 - step;
+    const int tp = rev ? t + 1 : t - 1;
+    const int pb = b0 + 32 * hf + prow;
+    const long prow_i = (long)pb * T + t;
+    in_dy = make_float4(0.f, 0.f, 0.f, 0.f);
+    in_c = in_cp = in_dy;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) in_g[g] = in_dy;
+    const bool has_prev = rev ? (tp < T) : (tp >= 0);
+    if (pb < B) {
+      in_dy = *reinterpret_cast<const float4*>(dy + prow_i * lddy + j);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) in_g[g] = *reinterpret_cast<const float4*>(gates + prow_i * K + g * H + j);
+      in_c = *reinterpret_cast<const float4*>(cb + prow_i * H + j);
+      if (has_prev) in_cp = *reinterpret_cast<const float4*>(cb + ((long)pb * T + tp) * H + j);
+    }
+  };
+  // wait until every peer has handed off its tiles of (step, hf), then fetch the NJ tiles addressed to this workgroup
+  auto issue_partials = [&](int step, int hf) {
+    group_wait(ctr + kCtrStride * hf, (unsigned)(4 * NJ * step), err);           // four waves per peer and step
+    const unsigned base = (((unsigned)(hf * 2 + (step & 1)) * NJ * NJ + (unsigned)jt * NJ) * TILE +
+                           (unsigned)(pq >> 1) * 256u + (unsigned)prow * 8u + (unsigned)(pq & 1) * 4u) * 4u;
+#pragma unroll
+    for (int p = 0; p < NJ; ++p) part[p] = load_sc1(xrs, base + (unsigned)p * TILE * 4u);
+  };
+
+  // E: gate gradients of (step, hf) from dh = dY + sum of the peers' partial tiles
+  auto gate_update = [&](int step, auto HF, bool with_part) {
+    constexpr int hf = decltype(HF)::value;
+    const int t = rev ? step : T - 1 - step;
+    const int pb = b0 + 32 * hf + prow;
+    const long prow_i = (long)pb * T + t;
+    float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (with_part) {
+#pragma unroll
+      for (int p = 0; p < NJ; ++p) { s4.x += part[p].x; s4.y += part[p].y; s4.z += part[p].z; s4.w += part[p].w; }
+    }
+    const float dhv[4] = {in_dy.x + s4.x, in_dy.y + s4.y, in_dy.z + s4.z, in_dy.w + s4.w};
+    const float gi[4] = {in_g[0].x, in_g[0].y, in_g[0].z, in_g[0].w};
+    const float gf[4] = {in_g[1].x, in_g[1].y, in_g[1].z, in_g[1].w};
+    const float gg[4] = {in_g[2].x, in_g[2].y, in_g[2].z, in_g[2].w};
+    const float go[4] = {in_g[3].x, in_g[3].y, in_g[3].z, in_g[3].w};
+    const float cn[4] = {in_c.x, in_c.y, in_c.z, in_c.w};
+    const float cp[4] = {in_cp.x, in_cp.y, in_cp.z, in_cp.w};
+    float dcv[4] = {dcar[hf].x, dcar[hf].y, dcar[hf].z, dcar[hf].w};
+    float tc[4], oi[4], of[4], og[4], oo[4];
+    tanh_n<4>(cn, tc);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float dc = dhv[e] * go[e] * (1.f - tc[e] * tc[e]) + dcv[e];
+      oi[e] = dc * gg[e] * gi[e] * (1.f - gi[e]);
+      of[e] = dc * cp[e] * gf[e] * (1.f - gf[e]);
+      og[e] = dc * gi[e] * (1.f - gg[e] * gg[e]);
+      oo[e] = dhv[e] * tc[e] * go[e] * (1.f - go[e]);
+      dcv[e] = dc * gf[e];
+    }
+    dcar[hf] = make_float4(dcv[0], dcv[1], dcv[2], dcv[3]);
+    const float4 og4[4] = {make_float4(oi[0], oi[1], oi[2], oi[3]), make_float4(of[0], of[1], of[2], of[3]),
+                           make_float4(og[0], og[1], og[2], og[3]), make_float4(oo[0], oo[1], oo[2], oo[3])};
+    // local k = g * 32 + 4 pq + e  ->  block kb = 2 g + (pq >> 2), lane half (pq >> 1) & 1, position (pq & 1) * 4 + e;
+    // split here, once, instead of in each of the four product waves
+    unsigned char* dl = reinterpret_cast<unsigned char*>(dg + hf * DGH + ((pq >> 2) * 2 + ((pq >> 1) & 1)) * 32 + prow) +
+                        (pq & 1) * 8;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if constexpr (TERMS == 3) {
+        u32x2 t3[3];
+        split4(og4[g], t3);
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+          *reinterpret_cast<u32x2*>(dl + (size_t)((t * NKB + 2 * g) * 2 * 32) * 16) = t3[t];
+      } else {
+        *reinterpret_cast<u32x2*>(dl + (size_t)(2 * g * 2 * 32) * 16) = round4(og4[g]);
+      }
+    }
+    // the gradient tensor itself (input of the dW / dX GEMMs): nobody in this launch waits for these stores
+    const unsigned goff = pb < B ? (unsigned)((prow_i * K + j) * 4) : 0xfffffff0u;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const u32x4 d = {__float_as_uint(og4[g].x), __float_as_uint(og4[g].y), __float_as_uint(og4[g].z),
+                       __float_as_uint(og4[g].w)};
+      __builtin_amdgcn_raw_buffer_store_b128(d, grs, goff, (unsigned)(g * H * 4), 0);
+    }
+    __syncthreads();                                  // dg[hf] complete before the next product reads it
+  };
+
+  // M: partial tiles of (step, hf) = this slice's gate gradients of step - 1 times its 128 rows of W_hh, handed off.
+  // Half way through, the inputs and peer tiles of the pending update (pre_step, pre_hf) are requested.
+  auto product = [&](int step, auto HF, int pre_step, int pre_hf, bool pre, bool pre_part) {
+    constexpr int hf = decltype(HF)::value;
+    const uint4* ap = dg + hf * DGH + hh * 32 + r;
+    if (pre) issue_inputs(pre_step, pre_hf);
+    PE_STAMP(9)
+    // lane (r, hh) ends up with, of batch row r, columns 8 i + 4 hh .. + 3 of consumer block wv * NBW + nb
+    const unsigned xo = (((unsigned)(hf * 2 + (step & 1)) * NJ * NJ + (unsigned)jt) * TILE + (unsigned)r * 8u +
+                         (unsigned)hh * 4u) * 4u;
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) {
+      f32x16 acc, acc2;                               // even / odd k blocks
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] = acc2[q] = 0.f;
+      // operands of block kb + 1 are requested before block kb multiplies; the scheduling barriers keep hipcc from
+      // sinking those reads down to their use (it does, and every product then waits out an LDS round trip)
+      uint4 fn[NT], wn = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) fn[t] = ap[t * NKB * 64];
+      if constexpr (TERMS == 3) {
+        if (nb * NKB >= NBR) wn = wlo_lds[(nb * NKB - NBR) * 256 + tid];
+      }
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        const int b = nb * NKB + kb;
+        bf16x8 fa[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) fa[t] = __builtin_bit_cast(bf16x8, fn[t]);
+        const bf16x8 wl = b < NBR ? bwlo[b < NBR ? b : 0] : __builtin_bit_cast(bf16x8, wn);
+        if (nb == NBW / 2 && kb == NKB / 2) {
+          PE_STAMP(0)                                           // first half of the product
+          if (pre && pre_part) issue_partials(pre_step, pre_hf);
+          PE_STAMP(1)                                           // poll + barrier + tile fetch issue
+        }
+        if (kb + 1 < NKB) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) fn[t] = ap[(t * NKB + kb + 1) * 64];
+          if constexpr (TERMS == 3) {
+            if (b + 1 >= NBR) wn = wlo_lds[(b + 1 - NBR) * 256 + tid];
+          }
+        }
+        if (nb == 0 && kb == 0) { PE_STAMP(6) }                 // input issue + first operand reads issued
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (TERMS == 3) {
+#pragma unroll
+          for (int t6 = 0; t6 < 6; ++t6) {
+            const bf16x8 wt = kTb[t6] == 2 ? wl : bwhm[b][kTb[t6]];
+            if (t6 & 1) acc2 = mfma_bf16(wt, fa[kTa[t6]], acc2);
+            else acc = mfma_bf16(wt, fa[kTa[t6]], acc);
+          }
+        } else {
+          if (kb & 1) acc2 = mfma_bf16(bwhm[b][0], fa[0], acc2);
+          else acc = mfma_bf16(bwhm[b][0], fa[0], acc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (nb == 0) { PE_STAMP(7) }                              // first column block multiplied
+      // this block's tile goes out while the next block multiplies
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        store_sc1(xrs, xo + ((unsigned)((wv * NBW + nb) * NJ) * TILE + (unsigned)i * 256u) * 4u,
+                  make_float4(acc[4 * i] + acc2[4 * i], acc[4 * i + 1] + acc2[4 * i + 1], acc[4 * i + 2] + acc2[4 * i + 2],
+                              acc[4 * i + 3] + acc2[4 * i + 3]));
+      if (nb == 0) { PE_STAMP(8) }                              // its tile stores issued
+    }
+    PE_STAMP(2)                                                   // second half of the product, tile stores issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PE_STAMP(3)                                                   // ... drained
+    // each wave hands off its own tiles: no workgroup barrier (the next writer of dg[hf] sits behind the barrier of
+    // the tile wait in the other half's product)
+    if (lane == 0) __hip_atomic_fetch_add(ctr + kCtrStride * hf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    PE_STAMP(4)                                                   // arrive
+  };
+
+  using H0 = std::integral_constant<int, 0>;
+  using H1 = std::integral_constant<int, 1>;
+  issue_inputs(0, 0);
+  gate_update(0, H0{}, false);
+  issue_inputs(0, 1);
+  gate_update(0, H1{}, false);
+  if constexpr (STAMP) st_last = stamp_now();
+  if (T > 1) product(1, H0{}, 0, 0, false, false);
+  for (int step = 1; step < T; ++step) {
+    product(step, H1{}, step, 0, true, true);
+    gate_update(step, H0{}, true);
+    PE_STAMP(5)                                                   // gate-gradient update + barrier
+    if (step + 1 < T) {
+      product(step + 1, H0{}, step, 1, true, true);
+    } else {
+      issue_inputs(step, 1);
+      issue_partials(step, 1);
+    }
+    gate_update(step, H1{}, true);
+    PE_STAMP(5)
+  }
+  if constexpr (STAMP) {
+    if (tid == 0)
+      for (int k = 0; k < 10; ++k) sync[2048 + 16 * blockIdx.x + k] = (unsigned)(st_acc[k] >> 4);
+  }
+}
+
 int device_cus() {
   static int cus = -1;
   if (cus < 0) {
@@ -1027,6 +1323,28 @@ int launch_fwd_v2(const PFwdCells& cells, int grid, int B, int T, long ldy, unsi
   return PE_OK;
 }
 
+template <int H, int TERMS, int NBR>
+constexpr size_t bwd_v2_lds() {
+  constexpr int NBK = (H / 128) * 8, NBL = TERMS == 3 ? NBK - NBR : 0;
+  return (size_t)(2 * (TERMS == 3 ? 3 : 1) * 8 * 2 * 32) * 16 + (size_t)NBL * 256 * 16;
+}
+
+template <int H, int TERMS, int NBR, bool STAMP = false>
+int launch_bwd_v2(const PBwdCells& cells, int grid, int B, int T, long lddy, unsigned* sync, hipStream_t st) {
+  static_assert(bwd_v2_lds<H, TERMS, NBR>() <= 160 * 1024, "LDS budget");
+  static bool attr = false;
+  if (!attr) {
+    PE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_persistent_ks_kernel<H, TERMS, NBR, STAMP>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_v2_lds<H, TERMS, NBR>()));
+    attr = true;
+  }
+  const unsigned g_bytes = (unsigned)((size_t)B * T * 4 * H * sizeof(float));
+  hipLaunchKernelGGL((lstm_bwd_persistent_ks_kernel<H, TERMS, NBR, STAMP>), dim3(grid), dim3(256),
+                     (bwd_v2_lds<H, TERMS, NBR>()), st, cells, B, T, lddy, g_bytes, sync);
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+
 // PE_LSTM_V1=1 selects the non-overlapped kernels (A/B timing, tools/bench_lstm.py)
 bool lstm_use_v2() {
   static const bool v2 = !(getenv("PE_LSTM_V1") && getenv("PE_LSTM_V1")[0] == '1');
@@ -1050,11 +1368,17 @@ int launch_bwd(const PBwdCells& cells, int grid, int B, int T, long lddy, unsign
 
 int sync_words(int ncells, int B) { return kCtrStride * (1 + 2 * ncells * ((B + 63) / 64)); }
 
+// exchange region of the k-split backward kernel (partial dh tiles), sized for H <= 384
+size_t xchg_bytes(int ncells, int B) { return (size_t)ncells * ((B + 63) / 64) * 4 * (12 * 12 * 1024) * sizeof(float); }
+
 }  // namespace
 
 #ifndef PE_F16_BUILD
+// Bytes of the zero-initialised buffer every persistent launch takes as `sync`: [error word + group counters | pad to
+// kXchgWord words | the backward kernel's exchange region].  Only the counters are reset per launch.
 extern "C" size_t pe_lstm_persistent_sync_bytes(int ncells, int B) {
-  return (size_t)sync_words(ncells, B) * sizeof(unsigned);
+  if (sync_words(ncells, B) > kXchgWord) return 0;
+  return (size_t)kXchgWord * sizeof(unsigned) + xchg_bytes(ncells, B);
 }
 #endif
 
@@ -1083,7 +1407,7 @@ static int lstm_fwd_persistent_impl(int terms, int ncells, const float* const* w
   }
   hipStream_t st = pe_stream(stream);
   // word 0 is the sticky error flag (cleared only by the owner of the buffer); counters start at line 1
-  PE_CHECK_HIP(hipMemsetAsync(sync + kCtrStride, 0, pe_lstm_persistent_sync_bytes(ncells, B) - kCtrStride * 4, st));
+  PE_CHECK_HIP(hipMemsetAsync(sync + kCtrStride, 0, (size_t)(sync_words(ncells, B) - kCtrStride) * 4, st));
   const int grid = ncells * ((B + 63) / 64) * (H / 32);
   if (lstm_use_v2() && terms != 0 && (size_t)B * T * 4 * H * sizeof(float) < (1ull << 31) &&
       (size_t)B * T * ldy * sizeof(float) < (1ull << 31)) {
@@ -1135,8 +1459,16 @@ static int lstm_bwd_persistent_impl(int terms, int ncells, const float* const* w
     cells.reverse[i] = reverse[i];
   }
   hipStream_t st = pe_stream(stream);
-  PE_CHECK_HIP(hipMemsetAsync(sync + kCtrStride, 0, pe_lstm_persistent_sync_bytes(ncells, B) - kCtrStride * 4, st));
+  PE_CHECK_HIP(hipMemsetAsync(sync + kCtrStride, 0, (size_t)(sync_words(ncells, B) - kCtrStride) * 4, st));
   const int grid = ncells * ((B + 63) / 64) * (H / 32);
+  if (lstm_use_v2() && terms != 0 && sync_words(ncells, B) <= kXchgWord) {
+    if (H == 128) return terms == 3 ? launch_bwd_v2<128, 3, 8>(cells, grid, B, T, lddy, sync, st)
+                                    : launch_bwd_v2<128, 1, 8>(cells, grid, B, T, lddy, sync, st);
+    static const bool stamp = getenv("PE_LSTM_STAMP") && getenv("PE_LSTM_STAMP")[0] == '1';
+    if (H == 384 && terms == 3 && stamp && grid <= 128) return launch_bwd_v2<384, 3, 8, true>(cells, grid, B, T, lddy, sync, st);
+    if (H == 384) return terms == 3 ? launch_bwd_v2<384, 3, 8>(cells, grid, B, T, lddy, sync, st)
+                                    : launch_bwd_v2<384, 1, 24>(cells, grid, B, T, lddy, sync, st);
+  }
   switch (H) {
     case 32: return launch_bwd<32, 0>(cells, grid, B, T, lddy, sync, st);
     case 64: return terms == 3 ? launch_bwd<64, 3>(cells, grid, B, T, lddy, sync, st)

@@ -523,7 +523,7 @@ USE_PERSISTENT_LSTM = True
 def _lstm_sync(ncells, B, device):
     """Zero-initialised barrier words for the persistent LSTM kernels (word 0 = sticky error flag)."""
     lib = _lib.load()
-    need = lib.pe_lstm_persistent_sync_bytes(4, max(B, 1024)) // 4
+    need = lib.pe_lstm_persistent_sync_bytes(4, max(B, 256)) // 4
     key = torch.device(device)
     buf = _SYNC.get(key)
     if buf is None or buf.numel() < need:

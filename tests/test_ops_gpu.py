@@ -372,7 +372,7 @@ def test_seq_relayout(hip_device):
 
 # ------------------------------------------------------------------ LSTM
 @pytest.mark.parametrize("persistent", [False, True])
-@pytest.mark.parametrize("B,T,In,H", [(5, 7, 96, 64), (70, 4, 64, 32), (3, 11, 128, 96), (130, 9, 64, 384)])
+@pytest.mark.parametrize("B,T,In,H", [(5, 7, 96, 64), (70, 4, 64, 32), (3, 11, 128, 96), (130, 9, 64, 384), (66, 6, 64, 128)])
 def test_lstm_layer_bidirectional(hip_device, B, T, In, H, persistent, monkeypatch):
     monkeypatch.setattr(ops, "USE_PERSISTENT_LSTM", persistent)
     torch.manual_seed(0)
@@ -417,7 +417,7 @@ def test_lstm_layer_bidirectional(hip_device, B, T, In, H, persistent, monkeypat
     assert not ops.persistent_lstm_error(dev)
 
 
-@pytest.mark.parametrize("B,T,H", [(130, 9, 384), (5, 7, 64)])
+@pytest.mark.parametrize("B,T,H", [(130, 9, 384), (5, 7, 64), (66, 6, 128)])
 def test_lstm_recurrence_mixed_precision(hip_device, B, T, H):
     """training.mixed_precision also rounds W_hh and the h / dgates rows of the persistent recurrences to bf16
     (fp32 accumulate and cell state): forward output and the recurrent data gradient stay within bf16-level
@@ -437,7 +437,8 @@ def test_lstm_recurrence_mixed_precision(hip_device, B, T, H):
     with ops.matmul_bf16(True):
         ops.lstm_fwd([P["weight_hh_l0"]], [g], [yd], [cb], [0], B, T, H)
         close(yd, y, 2e-2)
-        assert (yd.cpu().double() - y.detach()).abs().max() > 1e-6          # the bf16 path really ran
+        if H in (64, 384):                                                  # forward bf16 kernels exist for these
+            assert (yd.cpu().double() - y.detach()).abs().max() > 1e-6      # the bf16 path really ran
         dcar = [torch.empty(B, H, device=dev)]
         ops.lstm_bwd([ops.transpose2d(P["weight_hh_l0"])], [g], [cb], [dy.float().to(dev)], dcar, [0], B, T, H)
     dx = ops.gemm_nt(g.view(-1, 4 * H), ops.transpose2d(P["weight_ih_l0"]))

@@ -37,3 +37,30 @@ for k, n in enumerate(names):
     print(f"{n:42s} {v:8.0f} cycles/item   (min {st[:, k].min().item():.0f} max {st[:, k].max().item():.0f})")
 print(f"{'sum':42s} {tot:8.0f} cycles/item")
 print("error flag:", ops.persistent_lstm_error(dev))
+
+# ---- backward (exchange-buffer kernel): regions of an item
+whh_t = [ops.transpose2d(w) for w in whh]
+for _ in range(2):
+    g2 = [torch.rand(B, T, 4 * H, device=dev) for _ in range(NC)]
+    cb2 = [torch.randn(B, T, H, device=dev) for _ in range(NC)]
+    dys = torch.randn(B, T, 2 * H, device=dev)
+    dsl = [dys[:, :, (i % 2) * H:(i % 2 + 1) * H] for i in range(NC)]
+    dc = [torch.empty(B, H, device=dev) for _ in range(NC)]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    ops.lstm_bwd(whh_t, g2, cb2, dsl, dc, [0, 1][:NC], B, T, H)
+    e1.record()
+    torch.cuda.synchronize()
+print("bwd ms/layer(2 cells)", e0.elapsed_time(e1), "us/step", e0.elapsed_time(e1) / T * 1e3)
+sync = ops._SYNC[dev].cpu()
+st = sync[2048:2048 + 16 * grid].view(grid, 16)[:, :10].double() * 16 / (2 * (T - 1))
+names = ["product, first half (+ input issue, tile stores)", "poll + barrier + tile fetch issue",
+         "product, second half (+ tile stores)", "tile store drain vmcnt(0)", "arrive", "gate-gradient update + barrier",
+         "  input issue + first reads", "  first column block (48 MFMA)", "  its tile stores", "  input issue only"]
+tot = 0.0
+for k, n in enumerate(names):
+    v = st[:, k].median().item()
+    tot += v
+    print(f"{n:42s} {v:8.0f} cycles/item   (min {st[:, k].min().item():.0f} max {st[:, k].max().item():.0f})")
+print(f"{'sum':42s} {tot:8.0f} cycles/item")
+print("error flag:", ops.persistent_lstm_error(dev))
