@@ -206,6 +206,49 @@ __device__ __forceinline__ void group_wait(unsigned* ctr, unsigned target, unsig
   __syncthreads();
 }
 
+// The same wait without the workgroup barrier: lane 0 of EVERY wave polls (four sc1 loads of one line instead of
+// one), the waves stay decoupled.  For kernels whose LDS hazards are ordered by other barriers.
+__device__ __forceinline__ void wave_wait(unsigned* ctr, unsigned target, unsigned* err) {
+  if ((threadIdx.x & 63) == 0) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 63u) == 0u) {
+        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+        if (spins > kSpinLimit) {
+          __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Hand-off by FLAGS instead of a counter: every producer wave owns one word of the group's flag block and stores the
+// step it has completed (plain sc1 store behind its drained payload); a consumer wave reads all n words with one
+// load and waits until none is behind.  Same-address atomics serialise in the L2 (48 arrivals on one counter cost
+// more than the payload); stores to distinct words of a line do not.
+__device__ __forceinline__ unsigned flags_peek(const unsigned* flags, int n) {
+  const int l = threadIdx.x & 63;
+  return l < n ? __hip_atomic_load(flags + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+}
+__device__ __forceinline__ void flags_wait(const unsigned* flags, int n, unsigned target, unsigned seen, unsigned* err) {
+  unsigned spins = 0;
+  while (__ballot(seen < target) != 0ull) {
+    __builtin_amdgcn_s_sleep(1);
+    if ((++spins & 63u) == 0u) {
+      if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+      if (spins > kSpinLimit) {
+        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+    seen = flags_peek(flags, n);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Workgroup -> (group, member).  A group's NJ workgroups all read the same operand rows (h_{t-1} forward,
 // dgates_{t+1} backward) and hand each other their results, so they are placed on ONE XCD (hardware
 // dispatches workgroup b to XCD b % 8): the 12-fold re-read then hits that XCD's L2 instead of crossing
@@ -999,7 +1042,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_kernel(const PBwdC
 // Schedule per workgroup (M = product + hand-off of a half, E = gate-gradient update of a half):
 //   E(0,0) E(0,1) M(1,0) | M(s,1) E(s,0) M(s+1,0) E(s,1) | ...   the wait for the peers' tiles of one half sits in
 // the middle of the other half's M, the tile loads land under the rest of it.
-constexpr int kXchgWord = 8192;          // exchange region starts this many words into the sync buffer
+constexpr int kXchgWord = 8192;          // flag blocks start this many words into the sync buffer ...
+constexpr int kFlagWords = 16384;        // ... [cell][batch tile][half][64 words]; the partial tiles follow
 
 template <int H, int TERMS, int NBR_, bool STAMP = false>
 __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_ks_kernel(const PBwdCells cells, int B, int T, long lddy,
@@ -1031,8 +1075,9 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_ks_kernel(const PB
   const float* cb = cells.c[cell];
   const float* dy = cells.dy[cell];
   unsigned* err = sync;
-  unsigned* ctr = sync + kCtrStride * (1 + (cell * nbt + bt) * 2);
-  float* xbase = reinterpret_cast<float*>(sync + kXchgWord) + (size_t)(cell * nbt + bt) * 4 * SLOT;
+  static_assert(4 * NJ <= 64, "one flag word per producer wave, one load per consumer wave");
+  unsigned* flags = sync + kXchgWord + (cell * nbt + bt) * 128;        // [half][64]
+  float* xbase = reinterpret_cast<float*>(sync + kXchgWord + kFlagWords) + (size_t)(cell * nbt + bt) * 4 * SLOT;
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(xbase, 0, 4u * SLOT * 4u, 0x00020000);
   const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(gates, 0, g_bytes, 0x00020000);
 
@@ -1065,41 +1110,60 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_ks_kernel(const PB
   dcar[0] = dcar[1] = make_float4(0.f, 0.f, 0.f, 0.f);
   unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;
 
-  // inputs of one gate-gradient update (single set: issued after the previous update has consumed its own)
-  float4 in_dy, in_c, in_cp, in_g[4], part[NJ];
-  auto issue_inputs = [&](int step, int hf) {
+  // Inputs of one gate-gradient update (single set: requested after the previous update has consumed its own).
+  // Every request is ONE buffer instruction with a per-thread offset computed once and a scalar offset per step: at
+  // one wave per SIMD a burst of loads with 64-bit address arithmetic in front stalls the wave on the texture
+  // addresser's queue (s_memtime: ~2 000 cycles per item), so the product below also spreads these requests
+  // between its MFMA groups.  Rows past B point out of the descriptors' range and read as zero.
+  constexpr unsigned kOob = 0x80000000u;            // host: every tensor of a cell is smaller than 2 GiB
+  const __amdgpu_buffer_rsrc_t crs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cb), 0, (unsigned)B * T * H * 4u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(dy), 0, (unsigned)(((long)B * T - 1) * lddy + H) * 4u, 0x00020000);
+  unsigned vg[2], vc[2], vd[2];
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) {
+    const int pb = b0 + 32 * hf + prow;
+    const bool ok = pb < B;
+    vg[hf] = ok ? ((unsigned)(pb * T) * K + j) * 4u : kOob;
+    vc[hf] = ok ? ((unsigned)(pb * T) * H + j) * 4u : kOob;
+    vd[hf] = ok ? ((unsigned)(pb * T) * (unsigned)lddy + j) * 4u : kOob;
+  }
+  float4 in_dy, in_c, in_cp, in_g[4], part[NJ], ccar[2];
+  auto ld4 = [&](__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    const u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    return make_float4(__uint_as_float(d.x), __uint_as_float(d.y), __uint_as_float(d.z), __uint_as_float(d.w));
+  };
+  constexpr int kInputs = 6;                        // dY, four gates, c of the previous time step
+  auto issue_input = [&](int which, int step, int hf) {
     const int t = rev ? step : T - 1 - step;
     const int tp = rev ? t + 1 : t - 1;
-    const int pb = b0 + 32 * hf + prow;
-    const long prow_i = (long)pb * T + t;
-    in_dy = make_float4(0.f, 0.f, 0.f, 0.f);
-    in_c = in_cp = in_dy;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) in_g[g] = in_dy;
     const bool has_prev = rev ? (tp < T) : (tp >= 0);
-    if (pb < B) {
-      in_dy = *reinterpret_cast<const float4*>(dy + prow_i * lddy + j);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) in_g[g] = *reinterpret_cast<const float4*>(gates + prow_i * K + g * H + j);
-      in_c = *reinterpret_cast<const float4*>(cb + prow_i * H + j);
-      if (has_prev) in_cp = *reinterpret_cast<const float4*>(cb + ((long)pb * T + tp) * H + j);
-    }
+    if (which == 0) in_dy = ld4(drs, vd[hf], (unsigned)t * (unsigned)lddy * 4u);
+    else if (which <= 4) in_g[which - 1] = ld4(grs, vg[hf], ((unsigned)t * K + (unsigned)(which - 1) * H) * 4u);
+    else in_cp = ld4(crs, has_prev ? vc[hf] : kOob, (unsigned)(has_prev ? tp : 0) * H * 4u);
   };
-  // wait until every peer has handed off its tiles of (step, hf), then fetch the NJ tiles addressed to this workgroup
-  auto issue_partials = [&](int step, int hf) {
-    group_wait(ctr + kCtrStride * hf, (unsigned)(4 * NJ * step), err);           // four waves per peer and step
-    const unsigned base = (((unsigned)(hf * 2 + (step & 1)) * NJ * NJ + (unsigned)jt * NJ) * TILE +
-                           (unsigned)(pq >> 1) * 256u + (unsigned)prow * 8u + (unsigned)(pq & 1) * 4u) * 4u;
+  // c_t of a step is c_{t-1} of the step before it: only step 0 fetches it, later steps inherit (ccar)
+  auto issue_inputs_all = [&](int step, int hf) {
 #pragma unroll
-    for (int p = 0; p < NJ; ++p) part[p] = load_sc1(xrs, base + (unsigned)p * TILE * 4u);
+    for (int w = 0; w < kInputs; ++w) issue_input(w, step, hf);
+    if (step == 0) in_c = ld4(crs, vc[hf], (unsigned)(rev ? 0 : T - 1) * H * 4u);
+  };
+  // the NJ tiles addressed to this workgroup: tile p of (step, hf); group_wait(step, hf) must have returned
+  auto tile_base = [&](int step, int hf) {
+    return (((unsigned)(hf * 2 + (step & 1)) * NJ * NJ + (unsigned)jt * NJ) * TILE + (unsigned)(pq >> 1) * 256u +
+            (unsigned)prow * 8u + (unsigned)(pq & 1) * 4u) * 4u;
+  };
+  auto wait_peers = [&](int step, int hf, unsigned seen) {
+    // No workgroup barrier: this slice's dg[hf] is protected by the barrier that ends the gate update between the
+    // product that read it and this wait.
+    flags_wait(flags + 64 * hf, 4 * NJ, (unsigned)step, seen, err);
   };
 
   // E: gate gradients of (step, hf) from dh = dY + sum of the peers' partial tiles
-  auto gate_update = [&](int step, auto HF, bool with_part) {
+  auto gate_update = [&](int step, auto HF, bool with_part, auto&& handoff) {
     constexpr int hf = decltype(HF)::value;
     const int t = rev ? step : T - 1 - step;
-    const int pb = b0 + 32 * hf + prow;
-    const long prow_i = (long)pb * T + t;
     float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (with_part) {
 #pragma unroll
@@ -1110,7 +1174,9 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_ks_kernel(const PB
     const float gf[4] = {in_g[1].x, in_g[1].y, in_g[1].z, in_g[1].w};
     const float gg[4] = {in_g[2].x, in_g[2].y, in_g[2].z, in_g[2].w};
     const float go[4] = {in_g[3].x, in_g[3].y, in_g[3].z, in_g[3].w};
-    const float cn[4] = {in_c.x, in_c.y, in_c.z, in_c.w};
+    const float4 c_now = step == 0 ? in_c : ccar[hf];
+    ccar[hf] = in_cp;
+    const float cn[4] = {c_now.x, c_now.y, c_now.z, c_now.w};
     const float cp[4] = {in_cp.x, in_cp.y, in_cp.z, in_cp.w};
     float dcv[4] = {dcar[hf].x, dcar[hf].y, dcar[hf].z, dcar[hf].w};
     float tc[4], oi[4], of[4], og[4], oo[4];
@@ -1144,32 +1210,40 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_ks_kernel(const PB
       }
     }
     // the gradient tensor itself (input of the dW / dX GEMMs): nobody in this launch waits for these stores
-    const unsigned goff = pb < B ? (unsigned)((prow_i * K + j) * 4) : 0xfffffff0u;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const u32x4 d = {__float_as_uint(og4[g].x), __float_as_uint(og4[g].y), __float_as_uint(og4[g].z),
                        __float_as_uint(og4[g].w)};
-      __builtin_amdgcn_raw_buffer_store_b128(d, grs, goff, (unsigned)(g * H * 4), 0);
+      __builtin_amdgcn_raw_buffer_store_b128(d, grs, vg[hf], ((unsigned)t * K + (unsigned)g * H) * 4u, 0);
     }
+    handoff();                                        // the preceding product's tiles (four younger stores above)
     __syncthreads();                                  // dg[hf] complete before the next product reads it
   };
 
   // M: partial tiles of (step, hf) = this slice's gate gradients of step - 1 times its 128 rows of W_hh, handed off.
-  // Half way through, the inputs and peer tiles of the pending update (pre_step, pre_hf) are requested.
+  // The requests of the pending update (pre_step, pre_hf) ride between the MFMA groups, one or two per group: its
+  // inputs from the start, the wait for the peers in the middle, their tiles right behind it -- early enough that
+  // they have landed when the last tile store is drained.  A column block's tile stores likewise go out one per
+  // group of the next block.
+  constexpr int LPOLL = NBW >= 3 ? (2 * NBK) / 3 : (NBW / 2) * NKB + NKB / 2;   // MFMA group in front of which the wait sits
+  constexpr int LPEEK = LPOLL >= 4 ? LPOLL - 4 : 0;
+  constexpr int LSPAN = (NBK - LPOLL) / 2 > 0 ? (NBK - LPOLL) / 2 : 1;  // groups that carry tile requests
+  constexpr int LPER = (NJ + LSPAN - 1) / LSPAN;                        // tile requests per group
   auto product = [&](int step, auto HF, int pre_step, int pre_hf, bool pre, bool pre_part) {
     constexpr int hf = decltype(HF)::value;
     const uint4* ap = dg + hf * DGH + hh * 32 + r;
-    if (pre) issue_inputs(pre_step, pre_hf);
-    PE_STAMP(9)
     // lane (r, hh) ends up with, of batch row r, columns 8 i + 4 hh .. + 3 of consumer block wv * NBW + nb
     const unsigned xo = (((unsigned)(hf * 2 + (step & 1)) * NJ * NJ + (unsigned)jt) * TILE + (unsigned)r * 8u +
                          (unsigned)hh * 4u) * 4u;
+    const unsigned tb = tile_base(pre_step, pre_hf);
+    float4 pend[4];                                   // finished tile of the previous column block
+    unsigned seen = 0xffffffffu;
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
-      f32x16 acc, acc2;                               // even / odd k blocks
+      f32x16 acc, acc2;
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[q] = acc2[q] = 0.f;
-      // operands of block kb + 1 are requested before block kb multiplies; the scheduling barriers keep hipcc from
+      // operands of group kb + 1 are requested before group kb multiplies; the scheduling barriers keep hipcc from
       // sinking those reads down to their use (it does, and every product then waits out an LDS round trip)
       uint4 fn[NT], wn = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
@@ -1184,10 +1258,19 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_ks_kernel(const PB
 #pragma unroll
         for (int t = 0; t < NT; ++t) fa[t] = __builtin_bit_cast(bf16x8, fn[t]);
         const bf16x8 wl = b < NBR ? bwlo[b < NBR ? b : 0] : __builtin_bit_cast(bf16x8, wn);
-        if (nb == NBW / 2 && kb == NKB / 2) {
+        // a poll is an L2 round trip (~700 cycles) even when the peers have long arrived: the first one is sent
+        // four groups early and only looked at here
+        if (b == LPEEK && pre && pre_part) seen = flags_peek(flags + 64 * pre_hf, 4 * NJ);
+        if (b == LPOLL) {
           PE_STAMP(0)                                           // first half of the product
-          if (pre && pre_part) issue_partials(pre_step, pre_hf);
-          PE_STAMP(1)                                           // poll + barrier + tile fetch issue
+          if constexpr (STAMP) {
+            if (pre_step == 100 && pre_hf == 0 && tid == 0) sync[2048 + 16 * blockIdx.x + 11] = (unsigned)__builtin_amdgcn_s_memrealtime();
+          }
+          if (pre && pre_part) wait_peers(pre_step, pre_hf, seen);
+          if constexpr (STAMP) {
+            if (pre_step == 100 && pre_hf == 0 && tid == 0) sync[2048 + 16 * blockIdx.x + 12] = (unsigned)__builtin_amdgcn_s_memrealtime();
+          }
+          PE_STAMP(1)                                           // poll
         }
         if (kb + 1 < NKB) {
 #pragma unroll
@@ -1196,7 +1279,16 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_ks_kernel(const PB
             if (b + 1 >= NBR) wn = wlo_lds[(b + 1 - NBR) * 256 + tid];
           }
         }
-        if (nb == 0 && kb == 0) { PE_STAMP(6) }                 // input issue + first operand reads issued
+        if (pre && b < kInputs) issue_input(b, pre_step, pre_hf);
+        if (pre && pre_part && b >= LPOLL) {
+#pragma unroll
+          for (int u = 0; u < LPER; ++u) {
+            const int p = (b - LPOLL) * LPER + u;
+            if (p < NJ) part[p < NJ ? p : 0] = load_sc1(xrs, tb + (unsigned)p * TILE * 4u);
+          }
+        }
+        if (nb > 0 && kb < 4)
+          store_sc1(xrs, xo + ((unsigned)((wv * NBW + nb - 1) * NJ) * TILE + (unsigned)kb * 256u) * 4u, pend[kb]);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (TERMS == 3) {
 #pragma unroll
@@ -1211,43 +1303,62 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_ks_kernel(const PB
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (nb == 0) { PE_STAMP(7) }                              // first column block multiplied
-      // this block's tile goes out while the next block multiplies
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        store_sc1(xrs, xo + ((unsigned)((wv * NBW + nb) * NJ) * TILE + (unsigned)i * 256u) * 4u,
-                  make_float4(acc[4 * i] + acc2[4 * i], acc[4 * i + 1] + acc2[4 * i + 1], acc[4 * i + 2] + acc2[4 * i + 2],
-                              acc[4 * i + 3] + acc2[4 * i + 3]));
-      if (nb == 0) { PE_STAMP(8) }                              // its tile stores issued
+        pend[i] = make_float4(acc[4 * i] + acc2[4 * i], acc[4 * i + 1] + acc2[4 * i + 1], acc[4 * i + 2] + acc2[4 * i + 2],
+                              acc[4 * i + 3] + acc2[4 * i + 3]);
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      store_sc1(xrs, xo + ((unsigned)((wv * NBW + NBW - 1) * NJ) * TILE + (unsigned)i * 256u) * 4u, pend[i]);
     PE_STAMP(2)                                                   // second half of the product, tile stores issued
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    PE_STAMP(3)                                                   // ... drained
-    // each wave hands off its own tiles: no workgroup barrier (the next writer of dg[hf] sits behind the barrier of
-    // the tile wait in the other half's product)
-    if (lane == 0) __hip_atomic_fetch_add(ctr + kCtrStride * hf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  // Hand-off of a product's tiles: each wave drains its own stores and arrives (no workgroup barrier: the next writer
+  // of dg[hf] sits behind the barrier that ends this very gate update).  Called at the END of the gate
+  // update that follows the product -- the peers need these tiles a whole product later, and by then the stores
+  // have long completed, so the wave does not idle on the drain; `younger` = VMEM instructions issued since.
+  auto arrive = [&](int step, int hf, auto YOUNGER) {
+    constexpr int younger = decltype(YOUNGER)::value;
+    if constexpr (younger == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PE_STAMP(3)                                                   // tile store drain
+    if (lane == 0)
+      __hip_atomic_store(flags + 64 * hf + 4 * jt + wv, (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if constexpr (STAMP) {
+      if (step == 100 && hf == 0 && tid == 0) sync[2048 + 16 * blockIdx.x + 10] = (unsigned)__builtin_readcyclecounter();
+      if (step == 100 && hf == 0 && tid == 0) sync[2048 + 16 * blockIdx.x + 13] = (unsigned)__builtin_amdgcn_s_memrealtime();
+    }
     PE_STAMP(4)                                                   // arrive
   };
 
   using H0 = std::integral_constant<int, 0>;
   using H1 = std::integral_constant<int, 1>;
-  issue_inputs(0, 0);
-  gate_update(0, H0{}, false);
-  issue_inputs(0, 1);
-  gate_update(0, H1{}, false);
+  using Y0 = std::integral_constant<int, 0>;
+  using Y4 = std::integral_constant<int, 4>;
+  auto none = [] {};
+  issue_inputs_all(0, 0);
+  gate_update(0, H0{}, false, none);
+  issue_inputs_all(0, 1);
+  gate_update(0, H1{}, false, none);
   if constexpr (STAMP) st_last = stamp_now();
-  if (T > 1) product(1, H0{}, 0, 0, false, false);
+  if (T > 1) {
+    product(1, H0{}, 0, 0, false, false);
+    arrive(1, 0, Y0{});
+  }
   for (int step = 1; step < T; ++step) {
     product(step, H1{}, step, 0, true, true);
-    gate_update(step, H0{}, true);
+    gate_update(step, H0{}, true, [&] { arrive(step, 1, Y4{}); });
     PE_STAMP(5)                                                   // gate-gradient update + barrier
     if (step + 1 < T) {
       product(step + 1, H0{}, step, 1, true, true);
+      gate_update(step, H1{}, true, [&] { arrive(step + 1, 0, Y4{}); });
     } else {
-      issue_inputs(step, 1);
-      issue_partials(step, 1);
+      issue_inputs_all(step, 1);
+      wait_peers(step, 1, flags_peek(flags + 64, 4 * NJ));
+#pragma unroll
+      for (int p = 0; p < NJ; ++p) part[p] = load_sc1(xrs, tile_base(step, 1) + (unsigned)p * TILE * 4u);
+      gate_update(step, H1{}, true, none);
     }
-    gate_update(step, H1{}, true);
     PE_STAMP(5)
   }
   if constexpr (STAMP) {
@@ -1375,10 +1486,12 @@ size_t xchg_bytes(int ncells, int B) { return (size_t)ncells * ((B + 63) / 64) *
 
 #ifndef PE_F16_BUILD
 // Bytes of the zero-initialised buffer every persistent launch takes as `sync`: [error word + group counters | pad to
-// kXchgWord words | the backward kernel's exchange region].  Only the counters are reset per launch.
+// kXchgWord words | the k-split backward kernel's flag blocks | its partial tiles].  Counters and flags are reset per
+// launch.
 extern "C" size_t pe_lstm_persistent_sync_bytes(int ncells, int B) {
   if (sync_words(ncells, B) > kXchgWord) return 0;
-  return (size_t)kXchgWord * sizeof(unsigned) + xchg_bytes(ncells, B);
+  if (ncells * ((B + 63) / 64) * 128 > kFlagWords) return 0;
+  return (size_t)(kXchgWord + kFlagWords) * sizeof(unsigned) + xchg_bytes(ncells, B);
 }
 #endif
 
@@ -1461,7 +1574,12 @@ static int lstm_bwd_persistent_impl(int terms, int ncells, const float* const* w
   hipStream_t st = pe_stream(stream);
   PE_CHECK_HIP(hipMemsetAsync(sync + kCtrStride, 0, (size_t)(sync_words(ncells, B) - kCtrStride) * 4, st));
   const int grid = ncells * ((B + 63) / 64) * (H / 32);
-  if (lstm_use_v2() && terms != 0 && sync_words(ncells, B) <= kXchgWord) {
+  // the k-split kernel addresses every tensor of a cell with 32-bit offsets below 2 GiB
+  const bool small = (size_t)B * T * 4 * H * sizeof(float) < (1ull << 31) &&
+                     ((size_t)B * T * (size_t)lddy) * sizeof(float) < (1ull << 31);
+  if (lstm_use_v2() && terms != 0 && small && sync_words(ncells, B) <= kXchgWord &&
+      ncells * ((B + 63) / 64) * 128 <= kFlagWords && (H == 128 || H == 384)) {
+    PE_CHECK_HIP(hipMemsetAsync(sync + kXchgWord, 0, (size_t)ncells * ((B + 63) / 64) * 128 * sizeof(unsigned), st));
     if (H == 128) return terms == 3 ? launch_bwd_v2<128, 3, 8>(cells, grid, B, T, lddy, sync, st)
                                     : launch_bwd_v2<128, 1, 8>(cells, grid, B, T, lddy, sync, st);
     static const bool stamp = getenv("PE_LSTM_STAMP") && getenv("PE_LSTM_STAMP")[0] == '1';

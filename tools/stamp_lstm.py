@@ -54,9 +54,9 @@ for _ in range(2):
 print("bwd ms/layer(2 cells)", e0.elapsed_time(e1), "us/step", e0.elapsed_time(e1) / T * 1e3)
 sync = ops._SYNC[dev].cpu()
 st = sync[2048:2048 + 16 * grid].view(grid, 16)[:, :10].double() * 16 / (2 * (T - 1))
-names = ["product, first half (+ input issue, tile stores)", "poll + barrier + tile fetch issue",
-         "product, second half (+ tile stores)", "tile store drain vmcnt(0)", "arrive", "gate-gradient update + barrier",
-         "  input issue + first reads", "  first column block (48 MFMA)", "  its tile stores", "  input issue only"]
+names = ["product, first half (+ input / tile-store issue)", "poll (per wave)",
+         "product, second half (+ tile fetch / store issue)", "gate-gradient update, then tile store drain", "arrive",
+         "barrier"]
 tot = 0.0
 for k, n in enumerate(names):
     v = st[:, k].median().item()
@@ -64,3 +64,15 @@ for k, n in enumerate(names):
     print(f"{n:42s} {v:8.0f} cycles/item   (min {st[:, k].min().item():.0f} max {st[:, k].max().item():.0f})")
 print(f"{'sum':42s} {tot:8.0f} cycles/item")
 print("error flag:", ops.persistent_lstm_error(dev))
+
+# absolute times (100 MHz s_memrealtime) of step 100, half 0: flag store, wait entered, wait left -- per group
+raw = sync[2048:2048 + 16 * grid].view(grid, 16).long()
+NJ = H // 32
+ngroups = grid // NJ
+blocks = torch.arange(grid)
+gidx = torch.where(torch.tensor((ngroups & 7) == 0), (blocks & 7) * (ngroups >> 3) + (blocks >> 3) // NJ, blocks // NJ)
+for g in range(min(ngroups, 4)):
+    m = gidx == g
+    arr, w0, w1 = raw[m, 13], raw[m, 11], raw[m, 12]
+    base = arr.min()
+    print(f"group {g}: flag stores at {sorted((arr - base).tolist())} x10ns; wait entered {sorted((w0 - base).tolist())}; left {sorted((w1 - base).tolist())}")
