@@ -5,6 +5,7 @@
 //                   channels-last (model.py:53,167), transposed-weight dgrad products.
 //   pe_gemm_tn:  C[M][N] = sum_k A[k][m] . B[k][n]  (k = rows), split over k across workgroups
 //                -> weight gradients (dW = dY^T X), deterministic slab + ordered reduce.
+#include <stdlib.h>
 #include "gemm_engine.h"
 
 namespace {
@@ -42,11 +43,59 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(RowLoader al, RowLoader bl
   for_each_acc<TL>(acc, [&](int r, int c, float v) { ep(m0 + r, n0 + c, v); });
 }
 
+// The same product with the operand roles swapped inside the tile engine (the NT main loop is symmetric in its two
+// operands): the accumulators then hold the TRANSPOSED 32 x 32 blocks, i.e. a lane owns four consecutive output
+// columns of one row instead of four rows of one column, and the epilogue writes 16-byte pieces (a quarter of the
+// store instructions, bias fetched once per column quad).  Bit-identical sums.  Needs N % 4 == 0 and a 16-byte
+// aligned C with ldc % 4 == 0 (checked by the host).
+template <class TL, int MODE>
+__global__ __launch_bounds__(256) void gemm_nt_t_kernel(RowLoader al, RowLoader bl, StoreEpi ep, int K, int tiles_m,
+                                                        int tiles_n) {
+  using TT = Tile<TL::BN, TL::BM, TL::WAVES_N, TL::WAVES_M>;
+  __shared__ __attribute__((aligned(16))) float As[TL::BM * nt_row_floats<MODE>()];
+  __shared__ __attribute__((aligned(16))) float Bs[TL::BN * nt_row_floats<MODE>()];
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (tile / tiles_n) * TL::BM, n0 = (tile % tiles_n) * TL::BN;
+  al.init(m0);
+  bl.init(n0);
+  f32x16 acc[TT::TM][TT::TN];
+  zero_acc<TT>(acc);
+  nt_mainloop_mode<TT, MODE, true>(bl, al, K, Bs, As, acc);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wn = wv / TT::WAVES_N, wm = wv % TT::WAVES_N;          // TT's "rows" are output columns
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < TT::TM; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int col = n0 + wn * TT::WM + i * 32 + 8 * q + 4 * h;
+      if (col >= ep.N) continue;
+      float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;        // (acc + bias0) + bias1, as the scalar epilogue
+      if (ep.bias0) b0 = make_float4(ep.bias0[col], ep.bias0[col + 1], ep.bias0[col + 2], ep.bias0[col + 3]);
+      if (ep.bias1) b1 = make_float4(ep.bias1[col], ep.bias1[col + 1], ep.bias1[col + 2], ep.bias1[col + 3]);
+#pragma unroll
+      for (int j = 0; j < TT::TN; ++j) {
+        const int row = m0 + wm * TT::WN + j * 32 + r;
+        if (row >= ep.M) continue;
+        float4* dst = reinterpret_cast<float4*>(ep.C + (long)row * ep.ldc + col);
+        float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+        if (ep.bias0) { v.x += b0.x; v.y += b0.y; v.z += b0.z; v.w += b0.w; }
+        if (ep.bias1) { v.x += b1.x; v.y += b1.y; v.z += b1.z; v.w += b1.w; }
+        if (ep.accumulate) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        *dst = v;
+      }
+    }
+}
+
 template <class TL, int MODE>
 int launch_nt(const RowLoader& al, const RowLoader& bl, const StoreEpi& ep, int M, int N, int K,
               hipStream_t st) {
   const int tm = pe_cdiv(M, TL::BM), tn = pe_cdiv(N, TL::BN);
-  hipLaunchKernelGGL((gemm_nt_kernel<TL, MODE>), dim3(tm * tn), dim3(256), 0, st, al, bl, ep, K, tm, tn);
+  static const bool off = getenv("PE_GEMM_NT_SCALAR_EPILOGUE") != nullptr;     // A/B switch (tools/ab_gemm.py)
+  const bool vec = !off && MODE != kNative && (N & 3) == 0 && (ep.ldc & 3) == 0 &&
+                   (reinterpret_cast<uintptr_t>(ep.C) & 15) == 0;
+  if (vec) hipLaunchKernelGGL((gemm_nt_t_kernel<TL, MODE>), dim3(tm * tn), dim3(256), 0, st, al, bl, ep, K, tm, tn);
+  else hipLaunchKernelGGL((gemm_nt_kernel<TL, MODE>), dim3(tm * tn), dim3(256), 0, st, al, bl, ep, K, tm, tn);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }

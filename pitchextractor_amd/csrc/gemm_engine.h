@@ -283,6 +283,17 @@ __device__ __forceinline__ f32x16 mfma_split(const bf16x8 (&a)[3], const bf16x8 
   return c;
 }
 
+// the same six products in the same order when the caller has swapped the roles of its two operands
+__device__ __forceinline__ f32x16 mfma_split_swapped(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 c) {
+  c = mfma_bf16(a[0], b[2], c);
+  c = mfma_bf16(a[2], b[0], c);
+  c = mfma_bf16(a[1], b[1], c);
+  c = mfma_bf16(a[0], b[1], c);
+  c = mfma_bf16(a[1], b[0], c);
+  c = mfma_bf16(a[0], b[0], c);
+  return c;
+}
+
 // bf16-term images [row][32 k] with NO padding: 16-byte chunk c of a row sits at chunk c ^ ((row >> 2) & 3), which
 // keeps ds_read_b128 fragment reads (32 consecutive rows at any row offset) and the ds_write_b64 staging stores
 // conflict-free (MI355X_MICROARCH.md, LDS lane groups).
@@ -304,7 +315,7 @@ __device__ __forceinline__ void halo_store(__bf16* img, int img_elems, int row, 
   }
 }
 
-template <class TL, class AL, class BL>
+template <class TL, bool SW = false, class AL, class BL>
 __device__ __forceinline__ void nt_mainloop_split(AL& al, BL& bl, int K, float* As_f, float* Bs_f,
                                                   f32x16 (&acc)[TL::TM][TL::TN]) {
   constexpr int A_IMG = TL::BM * kLdsStrideH, B_IMG = TL::BN * kLdsStrideH;   // bf16 elements per image
@@ -365,18 +376,19 @@ __device__ __forceinline__ void nt_mainloop_split(AL& al, BL& bl, int K, float* 
 #pragma unroll
       for (int i = 0; i < TL::TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TL::TN; ++j) acc[i][j] = mfma_split(fa[i], fb[j], acc[i][j]);
+        for (int j = 0; j < TL::TN; ++j)
+          acc[i][j] = SW ? mfma_split_swapped(fa[i], fb[j], acc[i][j]) : mfma_split(fa[i], fb[j], acc[i][j]);
     }
   }
 }
 
 template <int MODE> constexpr int nt_row_floats() { return MODE == kSplit ? kSplitRowFloats : kLdsStride; }
 
-template <class TL, int MODE, class AL, class BL>
+template <class TL, int MODE, bool SW = false, class AL, class BL>
 __device__ __forceinline__ void nt_mainloop_mode(AL& al, BL& bl, int K, float* As, float* Bs,
                                                  f32x16 (&acc)[TL::TM][TL::TN]) {
   if constexpr (MODE == kBf16) nt_mainloop_bf16<TL>(al, bl, K, As, Bs, acc);
-  else if constexpr (MODE == kSplit) nt_mainloop_split<TL>(al, bl, K, As, Bs, acc);
+  else if constexpr (MODE == kSplit) nt_mainloop_split<TL, SW>(al, bl, K, As, Bs, acc);
   else nt_mainloop<TL>(al, bl, K, As, Bs, acc);
 }
 
