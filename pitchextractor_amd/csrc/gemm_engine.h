@@ -249,7 +249,7 @@ __device__ __forceinline__ void nt_mainloop_bf16(AL& al, BL& bl, int K, float* A
 // smallest (mid*lo, lo*mid, lo*lo <= 2^-23 |a*b|, below the rounding of an fp32 product) are dropped and
 // the other six are accumulated in fp32 by v_mfma_f32_32x32x16_bf16, small terms first.
 // LDS: three [row][40] bf16 images per operand.
-constexpr int kSplitRowFloats = 3 * kLdsStrideH / 2;     // floats of LDS per tile row (240 B)
+constexpr int kSplitRowFloats = 3 * kBK / 2;             // floats of LDS per tile row (three 64-byte term rows)
 
 struct Split3 { uint2 hi, mid, lo; };                    // 4 consecutive k of one row, packed bf16 pairs
 
@@ -318,7 +318,9 @@ __device__ __forceinline__ void halo_store(__bf16* img, int img_elems, int row, 
 template <class TL, bool SW = false, class AL, class BL>
 __device__ __forceinline__ void nt_mainloop_split(AL& al, BL& bl, int K, float* As_f, float* Bs_f,
                                                   f32x16 (&acc)[TL::TM][TL::TN]) {
-  constexpr int A_IMG = TL::BM * kLdsStrideH, B_IMG = TL::BN * kLdsStrideH;   // bf16 elements per image
+  // unpadded, XOR-swizzled term images (swz_off): 64 B per row and term, so a 128 x 128 tile takes 48 KB and three
+  // workgroups share a CU (the padded 80-byte rows allowed two)
+  constexpr int A_IMG = TL::BM * kBK, B_IMG = TL::BN * kBK;   // bf16 elements per image
   __bf16* As = reinterpret_cast<__bf16*>(As_f);
   __bf16* Bs = reinterpret_cast<__bf16*>(Bs_f);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -330,29 +332,14 @@ __device__ __forceinline__ void nt_mainloop_split(AL& al, BL& bl, int K, float* 
   for (int i = 0; i < TL::A_LOADS; ++i) ra[i] = al.load(i, 0);
 #pragma unroll
   for (int i = 0; i < TL::B_LOADS; ++i) rb[i] = bl.load(i, 0);
-
-  const int st_off = (tid >> 3) * kLdsStrideH + (tid & 7) * 4;
-  const __bf16* a_rd = As + (wm * TL::WM + r) * kLdsStrideH + h * 8;
-  const __bf16* b_rd = Bs + (wn * TL::WN + r) * kLdsStrideH + h * 8;
+  const int srow = tid >> 3, piece = tid & 7;
 
   for (int kt = 0; kt < nk; ++kt) {
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < TL::A_LOADS; ++i) {
-      const Split3 sp = split3(ra[i]);
-      __bf16* d = As + st_off + i * 32 * kLdsStrideH;
-      *reinterpret_cast<uint2*>(d) = sp.hi;
-      *reinterpret_cast<uint2*>(d + A_IMG) = sp.mid;
-      *reinterpret_cast<uint2*>(d + 2 * A_IMG) = sp.lo;
-    }
+    for (int i = 0; i < TL::A_LOADS; ++i) halo_store<3>(As, A_IMG, srow + 32 * i, piece, ra[i]);
 #pragma unroll
-    for (int i = 0; i < TL::B_LOADS; ++i) {
-      const Split3 sp = split3(rb[i]);
-      __bf16* d = Bs + st_off + i * 32 * kLdsStrideH;
-      *reinterpret_cast<uint2*>(d) = sp.hi;
-      *reinterpret_cast<uint2*>(d + B_IMG) = sp.mid;
-      *reinterpret_cast<uint2*>(d + 2 * B_IMG) = sp.lo;
-    }
+    for (int i = 0; i < TL::B_LOADS; ++i) halo_store<3>(Bs, B_IMG, srow + 32 * i, piece, rb[i]);
     __syncthreads();
     if (kt + 1 < nk) {
 #pragma unroll
@@ -367,12 +354,12 @@ __device__ __forceinline__ void nt_mainloop_split(AL& al, BL& bl, int K, float* 
       for (int i = 0; i < TL::TM; ++i)
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-          fa[i][c] = *reinterpret_cast<const bf16x8*>(a_rd + c * A_IMG + i * 32 * kLdsStrideH + kk * 16);
+          fa[i][c] = *reinterpret_cast<const bf16x8*>(As + c * A_IMG + swz_off(wm * TL::WM + i * 32 + r, kk * 2 + h));
 #pragma unroll
       for (int j = 0; j < TL::TN; ++j)
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-          fb[j][c] = *reinterpret_cast<const bf16x8*>(b_rd + c * B_IMG + j * 32 * kLdsStrideH + kk * 16);
+          fb[j][c] = *reinterpret_cast<const bf16x8*>(Bs + c * B_IMG + swz_off(wn * TL::WN + j * 32 + r, kk * 2 + h));
 #pragma unroll
       for (int i = 0; i < TL::TM; ++i)
 #pragma unroll
