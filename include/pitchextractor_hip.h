@@ -103,6 +103,10 @@ int pe_gemm_nt_wf_bf16(const float* A, long lda, const void* wfrag, float* C, lo
  * the output is meaningless for mask != 0. */
 int pe_gemm_nt_wf_ablate(int mask, const float* A, long lda, const void* wfrag, float* C, long ldc, int M, int N,
                          int K, void* stream);
+/* pe_gemm_nt_x3 variant selection: 1 routes eligible shapes (N % 128 == 0, K % 32 == 0, K >= 256, M >= 256) to the
+ * software-pipelined 256 x 128 kernel (one workgroup per CU; bit-identical results), 0 keeps the two-workgroup
+ * kernels.  Default 0 unless PE_GEMM_NT_PIPE=1 is in the environment.  Returns the previous setting. */
+int pe_gemm_nt_pipeline(int enable);
 size_t pe_gemm_tn_workspace_bytes(int M, int N, int K);
 int pe_gemm_tn(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
                int K, int accumulate, float* workspace, size_t workspace_bytes, void* stream);
@@ -190,7 +194,7 @@ int pe_lstm_fwd_persistent_f16(int ncells, const float* const* whh, float* const
                            unsigned* sync, void* stream);
 int pe_lstm_bwd_persistent_f16(int ncells, const float* const* whh_t, float* const* gates,
                            const float* const* cbuf, const float* const* dy, const int* reverse, long lddy,
-                           int B, int T, int H, unsigned* sync, void* stream);
+                           int B, int T, int H, float* const* dbias_rows, unsigned* sync, void* stream);
 int pe_lstm_whh_grad_f16(const float* dgates, const float* y, long ldy, float* dwhh, int B, int T, int H,
                      int reverse, float* workspace, size_t workspace_bytes, void* stream);
 int pe_wfrag_pack_f16(const float* w, long ld, int N, int K, void* wfrag, void* stream);
@@ -259,7 +263,12 @@ int pe_lstm_fwd_persistent(int ncells, const float* const* whh, float* const* ga
                            unsigned* sync, void* stream);
 int pe_lstm_bwd_persistent(int ncells, const float* const* whh_t, float* const* gates,
                            const float* const* cbuf, const float* const* dy, const int* reverse, long lddy,
-                           int B, int T, int H, unsigned* sync, void* stream);
+                           int B, int T, int H, float* const* dbias_rows, unsigned* sync, void* stream);
+/* dbias_rows (nullable): per cell a [pe_lstm_bwd_persistent_dbias_rows()][4H] buffer that receives the per-batch-tile
+ * column sums of the gate gradients (their row sum is dL/db_ih = dL/db_hh), replacing a pe_colsum pass over the
+ * [B*T][4H] gradient tensor.  Written only when the query below returns non-zero for the configuration
+ * (terms: 0 pe_lstm_bwd_persistent, 3 _x3, 1 _bf16 / _f16). */
+int pe_lstm_bwd_persistent_dbias_rows(int terms, int ncells, int B, int T, int H, long lddy);
 /* same recurrences with the recurrent products as the exact three-term bf16 split (H % 64 == 0; other
  * hidden sizes run the native fp32 MFMA form) */
 int pe_lstm_fwd_persistent_x3(int ncells, const float* const* whh, float* const* gates, float* const* y,
@@ -267,14 +276,14 @@ int pe_lstm_fwd_persistent_x3(int ncells, const float* const* whh, float* const*
                            unsigned* sync, void* stream);
 int pe_lstm_bwd_persistent_x3(int ncells, const float* const* whh_t, float* const* gates,
                            const float* const* cbuf, const float* const* dy, const int* reverse, long lddy,
-                           int B, int T, int H, unsigned* sync, void* stream);
+                           int B, int T, int H, float* const* dbias_rows, unsigned* sync, void* stream);
 /* mixed precision: W_hh and the h / dgates rows rounded to bf16, fp32 accumulate and cell state */
 int pe_lstm_fwd_persistent_bf16(int ncells, const float* const* whh, float* const* gates, float* const* y,
                            float* const* cbuf, const int* reverse, long ldy, int B, int T, int H,
                            unsigned* sync, void* stream);
 int pe_lstm_bwd_persistent_bf16(int ncells, const float* const* whh_t, float* const* gates,
                            const float* const* cbuf, const float* const* dy, const int* reverse, long lddy,
-                           int B, int T, int H, unsigned* sync, void* stream);
+                           int B, int T, int H, float* const* dbias_rows, unsigned* sync, void* stream);
 size_t pe_lstm_whh_grad_workspace_bytes(int B, int T, int H);
 int pe_lstm_whh_grad(const float* dgates, const float* y, long ldy, float* dwhh, int B, int T, int H,
                      int reverse, float* workspace, size_t workspace_bytes, void* stream);

@@ -45,6 +45,7 @@ PROTOTYPES = {
     "pe_gemm_nt_wf_x3": (_i, [_p, _l, _p, _p, _l, _i, _i, _i, _p, _p, _i, _p]),
     "pe_gemm_nt_wf_bf16": (_i, [_p, _l, _p, _p, _l, _i, _i, _i, _p, _p, _i, _p]),
     "pe_gemm_nt_wf_ablate": (_i, [_i, _p, _l, _p, _p, _l, _i, _i, _i, _p]),
+    "pe_gemm_nt_pipeline": (_i, [_i]),
     "pe_gemm_tn_workspace_bytes": (_z, [_i, _i, _i]),
     "pe_gemm_tn": (_i, [_p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _p, _z, _p]),
     "pe_gemm_tn_x3": (_i, [_p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _p, _z, _p]),
@@ -83,11 +84,12 @@ PROTOTYPES = {
     "pe_lstm_persistent_sync_bytes": (_z, [_i, _i]),
     "pe_lstm_persistent_supported": (_i, [_i, _i, _i]),
     "pe_lstm_fwd_persistent": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _p, _p]),
-    "pe_lstm_bwd_persistent": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _p, _p]),
+    "pe_lstm_bwd_persistent": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _pp, _p, _p]),
     "pe_lstm_fwd_persistent_x3": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _p, _p]),
-    "pe_lstm_bwd_persistent_x3": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _p, _p]),
+    "pe_lstm_bwd_persistent_dbias_rows": (_i, [_i, _i, _i, _i, _i, _l]),
+    "pe_lstm_bwd_persistent_x3": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _pp, _p, _p]),
     "pe_lstm_fwd_persistent_bf16": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _p, _p]),
-    "pe_lstm_bwd_persistent_bf16": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _p, _p]),
+    "pe_lstm_bwd_persistent_bf16": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _pp, _p, _p]),
     "pe_lstm_whh_grad_workspace_bytes": (_z, [_i, _i, _i]),
     "pe_lstm_whh_grad": (_i, [_p, _p, _l, _p, _i, _i, _i, _i, _p, _z, _p]),
     "pe_lstm_whh_grad_x3": (_i, [_p, _p, _l, _p, _i, _i, _i, _i, _p, _z, _p]),
@@ -122,7 +124,7 @@ PROTOTYPES = {
     "pe_conv3x3_fwd_wf_f16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "pe_conv3x3_wgrad_f16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
     "pe_lstm_fwd_persistent_f16": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _p, _p]),
-    "pe_lstm_bwd_persistent_f16": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _p, _p]),
+    "pe_lstm_bwd_persistent_f16": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _pp, _p, _p]),
     "pe_lstm_whh_grad_f16": (_i, [_p, _p, _l, _p, _i, _i, _i, _i, _p, _z, _p]),
     "pe_wfrag_pack_f16": (_i, [_p, _l, _i, _i, _p, _p]),
     "pe_nonfinite_flag": (_i, [_p, _l, _p, _p]),

@@ -507,6 +507,16 @@ int launch_tn(const float* A, long lda, const float* B, long ldb, float* C, long
 
 }  // namespace
 
+static bool g_nt_pipeline = getenv("PE_GEMM_NT_PIPE") != nullptr && getenv("PE_GEMM_NT_PIPE")[0] == '1';
+
+#ifndef PE_F16_BUILD
+extern "C" int pe_gemm_nt_pipeline(int enable) {
+  const int old = g_nt_pipeline ? 1 : 0;
+  g_nt_pipeline = enable != 0;
+  return old;
+}
+#endif
+
 template <int MODE>
 static int gemm_nt_impl(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
                         int K, const float* bias0, const float* bias1, int accumulate, void* stream) {
@@ -520,7 +530,7 @@ static int gemm_nt_impl(const float* A, long lda, const float* B, long ldb, floa
   if constexpr (MODE == kSplit) {
     // opt-in (PE_GEMM_NT_PIPE=1): measured at par with the two-workgroup kernels below on the step's shapes --
     // see the kernel's comment and DESIGN.md for the breakdown
-    static const bool pipe_off = getenv("PE_GEMM_NT_PIPE") == nullptr;
+    const bool pipe_off = !g_nt_pipeline;
     const bool fits32 = ((size_t)M * lda + K) * 4 < (1ull << 32) && ((size_t)N * ldb + K) * 4 < (1ull << 32);
     if (!pipe_off && N % 128 == 0 && K >= 256 && K % 32 == 0 && M >= 256 && (ldc & 3) == 0 && aligned16(C) && fits32)
       return launch_nt_pipe(al, bl, ep, M, N, K, st);

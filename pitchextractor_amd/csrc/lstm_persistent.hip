@@ -55,6 +55,7 @@ struct PBwdCells {
   float* gates[kMaxCells];
   const float* c[kMaxCells];
   const float* dy[kMaxCells];
+  float* dbias[kMaxCells];               // optional [batch tiles][4H] column sums of the gate gradients (k-split kernel)
   int reverse[kMaxCells];
 };
 
@@ -1107,6 +1108,11 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_ks_kernel(const PB
   const int prow = tid >> 3, pq = tid & 7;
   const int j = j0 + 4 * pq;
   float4 dcar[2];
+  // bias gradient = column sums of the gate gradients: every thread keeps the running sums of its 4 gates x 4
+  // columns over all steps and both halves; folded over the 32 rows of a half at the end of the kernel
+  float4 bsum[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) bsum[g] = make_float4(0.f, 0.f, 0.f, 0.f);
   dcar[0] = dcar[1] = make_float4(0.f, 0.f, 0.f, 0.f);
   unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;
 
@@ -1193,6 +1199,10 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_ks_kernel(const PB
     dcar[hf] = make_float4(dcv[0], dcv[1], dcv[2], dcv[3]);
     const float4 og4[4] = {make_float4(oi[0], oi[1], oi[2], oi[3]), make_float4(of[0], of[1], of[2], of[3]),
                            make_float4(og[0], og[1], og[2], og[3]), make_float4(oo[0], oo[1], oo[2], oo[3])};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bsum[g].x += og4[g].x; bsum[g].y += og4[g].y; bsum[g].z += og4[g].z; bsum[g].w += og4[g].w;
+    }
     // local k = g * 32 + 4 pq + e  ->  block kb = 2 g + (pq >> 2), lane half (pq >> 1) & 1, position (pq & 1) * 4 + e;
     // split here, once, instead of in each of the four product waves
     unsigned char* dl = reinterpret_cast<unsigned char*>(dg + hf * DGH + ((pq >> 2) * 2 + ((pq >> 1) & 1)) * 32 + prow) +
@@ -1360,6 +1370,20 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_ks_kernel(const PB
       gate_update(step, H1{}, true, none);
     }
     PE_STAMP(5)
+  }
+  if (cells.dbias[cell] != nullptr) {                // (every gate update ended with a barrier: dg is free)
+    float4* fold = reinterpret_cast<float4*>(smem);  // [32 rows][8 column quads][4 gates]
+#pragma unroll
+    for (int g = 0; g < 4; ++g) fold[(prow * 8 + pq) * 4 + g] = bsum[g];
+    __syncthreads();
+    if (tid < 128) {                                 // column quad tid >> 4, gate (tid >> 2) & 3, element tid & 3
+      const float* f = reinterpret_cast<const float*>(fold) + tid;
+      float sum = 0.f;
+#pragma unroll 8
+      for (int row = 0; row < 32; ++row) sum += f[row * 128];
+      const int g = (tid >> 2) & 3;
+      cells.dbias[cell][(long)bt * K + g * H + j0 + 4 * (tid >> 4) + (tid & 3)] = sum;
+    }
   }
   if constexpr (STAMP) {
     if (tid == 0)
@@ -1559,9 +1583,17 @@ extern "C" int pe_lstm_fwd_persistent_x3(int ncells, const float* const* whh, fl
 }
 #endif
 
+// does this configuration run the k-split backward kernel (the one that can also emit the bias-gradient rows)?
+static bool bwd_ks_eligible(int terms, int ncells, int B, int T, int H, long lddy) {
+  const bool small = (size_t)B * T * 4 * H * sizeof(float) < (1ull << 31) &&
+                     ((size_t)B * T * (size_t)lddy) * sizeof(float) < (1ull << 31);
+  return lstm_use_v2() && terms != 0 && small && sync_words(ncells, B) <= kXchgWord &&
+         ncells * ((B + 63) / 64) * 128 <= kFlagWords && H == 384;
+}
+
 static int lstm_bwd_persistent_impl(int terms, int ncells, const float* const* whh_t, float* const* gates,
                                     const float* const* cbuf, const float* const* dy, const int* reverse, long lddy,
-                                    int B, int T, int H, unsigned* sync, void* stream) {
+                                    int B, int T, int H, float* const* dbias_rows, unsigned* sync, void* stream) {
   if (!whh_t || !gates || !cbuf || !dy || !reverse || !sync || T <= 0) return PE_E_ARG;
   if (!pe_lstm_persistent_supported(ncells, B, H) || (lddy & 3)) return PE_E_UNSUPPORTED;
   if ((size_t)B * T * 4 * H * sizeof(float) >= (1ull << 32)) return PE_E_UNSUPPORTED;
@@ -1570,18 +1602,14 @@ static int lstm_bwd_persistent_impl(int terms, int ncells, const float* const* w
     if (!whh_t[i] || !gates[i] || !cbuf[i] || !dy[i]) return PE_E_ARG;
     cells.whh_t[i] = whh_t[i]; cells.gates[i] = gates[i]; cells.c[i] = cbuf[i]; cells.dy[i] = dy[i];
     cells.reverse[i] = reverse[i];
+    cells.dbias[i] = dbias_rows ? dbias_rows[i] : nullptr;
   }
   hipStream_t st = pe_stream(stream);
   PE_CHECK_HIP(hipMemsetAsync(sync + kCtrStride, 0, (size_t)(sync_words(ncells, B) - kCtrStride) * 4, st));
   const int grid = ncells * ((B + 63) / 64) * (H / 32);
-  // the k-split kernel addresses every tensor of a cell with 32-bit offsets below 2 GiB
-  const bool small = (size_t)B * T * 4 * H * sizeof(float) < (1ull << 31) &&
-                     ((size_t)B * T * (size_t)lddy) * sizeof(float) < (1ull << 31);
-  if (lstm_use_v2() && terms != 0 && small && sync_words(ncells, B) <= kXchgWord &&
-      ncells * ((B + 63) / 64) * 128 <= kFlagWords && (H == 128 || H == 384)) {
+  // (the k-split kernel addresses every tensor of a cell with 32-bit offsets below 2 GiB)
+  if (bwd_ks_eligible(terms, ncells, B, T, H, lddy)) {
     PE_CHECK_HIP(hipMemsetAsync(sync + kXchgWord, 0, (size_t)ncells * ((B + 63) / 64) * 128 * sizeof(unsigned), st));
-    if (H == 128) return terms == 3 ? launch_bwd_v2<128, 3, 8>(cells, grid, B, T, lddy, sync, st)
-                                    : launch_bwd_v2<128, 1, 8>(cells, grid, B, T, lddy, sync, st);
     static const bool stamp = getenv("PE_LSTM_STAMP") && getenv("PE_LSTM_STAMP")[0] == '1';
     if (H == 384 && terms == 3 && stamp && grid <= 128) return launch_bwd_v2<384, 3, 8, true>(cells, grid, B, T, lddy, sync, st);
     if (H == 384) return terms == 3 ? launch_bwd_v2<384, 3, 8>(cells, grid, B, T, lddy, sync, st)
@@ -1603,14 +1631,23 @@ static int lstm_bwd_persistent_impl(int terms, int ncells, const float* const* w
 #ifndef PE_F16_BUILD
 extern "C" int pe_lstm_bwd_persistent(int ncells, const float* const* whh_t, float* const* gates,
                                       const float* const* cbuf, const float* const* dy, const int* reverse,
-                                      long lddy, int B, int T, int H, unsigned* sync, void* stream) {
-  return lstm_bwd_persistent_impl(0, ncells, whh_t, gates, cbuf, dy, reverse, lddy, B, T, H, sync, stream);
+                                      long lddy, int B, int T, int H, float* const* dbias_rows, unsigned* sync,
+                                      void* stream) {
+  return lstm_bwd_persistent_impl(0, ncells, whh_t, gates, cbuf, dy, reverse, lddy, B, T, H, dbias_rows, sync, stream);
+}
+
+// Rows ([ceil(B / 64)][4H] per cell) that pe_lstm_bwd_persistent* (terms: 0 native, 3 split, 1 bf16 / fp16 operands)
+// writes into a non-null dbias_rows for this configuration; 0 = that kernel does not emit them (use pe_colsum).
+extern "C" int pe_lstm_bwd_persistent_dbias_rows(int terms, int ncells, int B, int T, int H, long lddy) {
+  if (!pe_lstm_persistent_supported(ncells, B, H) || (lddy & 3) || T <= 0) return 0;
+  return bwd_ks_eligible(terms, ncells, B, T, H, lddy) ? (B + 63) / 64 : 0;
 }
 
 extern "C" int pe_lstm_bwd_persistent_x3(int ncells, const float* const* whh_t, float* const* gates,
                                          const float* const* cbuf, const float* const* dy, const int* reverse,
-                                         long lddy, int B, int T, int H, unsigned* sync, void* stream) {
-  return lstm_bwd_persistent_impl(3, ncells, whh_t, gates, cbuf, dy, reverse, lddy, B, T, H, sync, stream);
+                                         long lddy, int B, int T, int H, float* const* dbias_rows, unsigned* sync,
+                                         void* stream) {
+  return lstm_bwd_persistent_impl(3, ncells, whh_t, gates, cbuf, dy, reverse, lddy, B, T, H, dbias_rows, sync, stream);
 }
 #endif
 
@@ -1622,6 +1659,7 @@ extern "C" int PE_HALF(pe_lstm_fwd_persistent)(int ncells, const float* const* w
 
 extern "C" int PE_HALF(pe_lstm_bwd_persistent)(int ncells, const float* const* whh_t, float* const* gates,
                                            const float* const* cbuf, const float* const* dy, const int* reverse,
-                                           long lddy, int B, int T, int H, unsigned* sync, void* stream) {
-  return lstm_bwd_persistent_impl(1, ncells, whh_t, gates, cbuf, dy, reverse, lddy, B, T, H, sync, stream);
+                                           long lddy, int B, int T, int H, float* const* dbias_rows, unsigned* sync,
+                                           void* stream) {
+  return lstm_bwd_persistent_impl(1, ncells, whh_t, gates, cbuf, dy, reverse, lddy, B, T, H, dbias_rows, sync, stream);
 }

@@ -318,7 +318,11 @@ def _lstm_backward(models, saved, dys, grads):
                 dsl.append(dys[mi][:, :, d * H:(d + 1) * H])
                 dcs.append(torch.empty((B, H), dtype=torch.float32, device=dev))
                 rev.append(d)
-        ops.lstm_bwd(whh_t, lay.gates, lay.cbuf, dsl, dcs, rev, B, T, H)      # gates now hold d(pre-activations)
+        # bias gradients come out of the recurrence kernel as per-batch-tile rows where it supports that
+        nrows = ops.lstm_bwd_dbias_rows(len(whh_t), B, T, H, dsl[0].stride(1), dev)
+        brows = [torch.empty((nrows, 4 * H), dtype=torch.float32, device=dev) for _ in whh_t] if nrows else None
+        have_db = ops.lstm_bwd(whh_t, lay.gates, lay.cbuf, dsl, dcs, rev, B, T, H,     # gates now hold d(pre-activations)
+                               dbias_rows=brows)
         dxs = []
         for mi, sm in enumerate(models):
             x2 = _flat2(lay.x[mi])
@@ -329,7 +333,7 @@ def _lstm_backward(models, saved, dys, grads):
                 dg2 = _flat2(dg)
                 ops.gemm_tn(dg2, x2, out=grads[w_ih])
                 ops.lstm_whh_grad(dg, lay.y[mi][:, :, d * H:(d + 1) * H], grads[w_hh], d, B, T, H)
-                ops.colsum(dg2, grads[b_ih], grads[b_hh])
+                ops.colsum(brows[mi * ND + d] if have_db else dg2, grads[b_ih], grads[b_hh])
                 ops.gemm_nt(dg2, ops.transpose2d(w_ih), out=_flat2(dx), accumulate=(d > 0))
             dxs.append(dx)
         dys = dxs

@@ -577,7 +577,10 @@ def lstm_fwd(whh, gates, y_slices, cbuf, reverse, B, T, H):
           _int_array(reverse), ldy, B, T, H, _s(), work=2.0 * n * B * (T - 1) * 4 * H * H)
 
 
-def lstm_bwd(whh_t, gates, cbuf, dy_slices, dcarry, reverse, B, T, H):
+def lstm_bwd(whh_t, gates, cbuf, dy_slices, dcarry, reverse, B, T, H, dbias_rows=None):
+    """Backward recurrences of len(whh_t) cells; gates become d(pre-activation gates) in place.  dbias_rows: optional
+    list of [lstm_bwd_dbias_rows(...)][4H] buffers, one per cell, that receive the per-batch-tile column sums of the
+    gate gradients (only pass it when that query is non-zero); returns True if they were written."""
     n = len(whh_t)
     _chk(1 <= n <= 4 and len(gates) == len(dy_slices) == len(cbuf) == len(reverse) == len(dcarry) == n,
          "lstm_bwd: cell lists")
@@ -594,12 +597,27 @@ def lstm_bwd(whh_t, gates, cbuf, dy_slices, dcarry, reverse, B, T, H):
     dev = gates[0].device
     if _persistent_ok(n, B, H, dev):
         sync = _lstm_sync(n, B, dev)
+        rows = lstm_bwd_dbias_rows(n, B, T, H, ld, dev) if dbias_rows is not None else 0
+        if rows:
+            _chk(len(dbias_rows) == n and all(_dense(d, "dbias_rows").shape == (rows, 4 * H) for d in dbias_rows),
+                 "lstm_bwd: dbias_rows shape")
         _call("pe_lstm_bwd_persistent" + _lstm_suffix("bwd"), n, _ptr_array(whh_t), _ptr_array(gates), _ptr_array(cbuf),
-              _ptr_array(dy_slices), _int_array(reverse), ld, B, T, H, sync.data_ptr(), _s(),
-              work=2.0 * n * B * (T - 1) * 4 * H * H)
-        return
+              _ptr_array(dy_slices), _int_array(reverse), ld, B, T, H, _ptr_array(dbias_rows) if rows else None,
+              sync.data_ptr(), _s(), work=2.0 * n * B * (T - 1) * 4 * H * H)
+        return bool(rows)
     _call("pe_lstm_bwd", n, _ptr_array(whh_t), _ptr_array(gates), _ptr_array(cbuf), _ptr_array(dy_slices),
           _ptr_array(dcarry), _int_array(reverse), ld, B, T, H, _s(), work=2.0 * n * B * (T - 1) * 4 * H * H)
+    return False
+
+
+def lstm_bwd_dbias_rows(n, B, T, H, ld, device) -> int:
+    """Rows of the per-cell [rows][4H] bias-gradient partials lstm_bwd can emit for this configuration (0: it cannot;
+    sum the gate gradients with colsum instead)."""
+    if not _persistent_ok(n, B, H, device):
+        return 0
+    sfx = _lstm_suffix("bwd")
+    terms = 3 if sfx == "_x3" else (1 if sfx in ("_bf16", "_f16") else 0)
+    return int(_lib.load().pe_lstm_bwd_persistent_dbias_rows(terms, n, B, T, H, ld))
 
 
 def lstm_whh_grad(dgates, y_slice, dwhh, reverse, B, T, H):

@@ -73,6 +73,26 @@ def test_gemm_nt_fragment_fed_kernel_is_bit_identical(hip_device, M, N, K, bf16,
         close(outs[True][0], A.cpu().double() @ B.cpu().double().T + b0.cpu().double())
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 1536, 384), (1024, 256, 640), (513, 128, 256)])
+def test_gemm_nt_pipelined_kernel_is_bit_identical(hip_device, M, N, K, monkeypatch):
+    """The opt-in one-workgroup-per-CU software-pipelined x3 kernel issues the same products in the same order as the
+    default kernels: equal outputs bit for bit (row tails, bias, accumulate)."""
+    from pitchextractor_amd import _lib
+    monkeypatch.setattr(ops, "FP32_MATMUL", "x3")
+    monkeypatch.setattr(ops, "GEMM_WFRAG", False)
+    A, B, b0 = rnd(M, K, seed=1).to(hip_device), rnd(N, K, seed=2).to(hip_device), rnd(N, seed=3).to(hip_device)
+    lib, outs = _lib.load(), {}
+    try:
+        for pipe in (1, 0):
+            lib.pe_gemm_nt_pipeline(pipe)
+            acc = rnd(M, N, seed=5).to(hip_device)
+            outs[pipe] = (ops.gemm_nt(A, B, bias0=b0), ops.gemm_nt(A, B, out=acc, accumulate=True))
+    finally:
+        lib.pe_gemm_nt_pipeline(0)
+    assert torch.equal(outs[1][0], outs[0][0]) and torch.equal(outs[1][1], outs[0][1])
+    close(outs[1][0], A.cpu().double() @ B.cpu().double().T + b0.cpu().double())
+
+
 def bf16r(t):      # what the bf16 kernels see: operands rounded to bf16 (RNE), products exact in fp32
     return t.to(torch.bfloat16).to(torch.float64)
 
@@ -399,7 +419,11 @@ def test_lstm_layer_bidirectional(hip_device, B, T, In, H, persistent, monkeypat
     whh_t = [ops.transpose2d(w) for w in whh]
     dsl = [dyd[:, :, d * H:(d + 1) * H] for d in range(2)]
     dcar = [torch.empty(B, H, device=dev) for _ in range(2)]
-    ops.lstm_bwd(whh_t, gates, cbuf, dsl, dcar, [0, 1], B, T, H)
+    # the k-split recurrence kernel also emits the bias gradients as per-batch-tile rows (H = 384, persistent)
+    nrows = ops.lstm_bwd_dbias_rows(2, B, T, H, dsl[0].stride(1), dev)
+    assert (nrows > 0) == (persistent and H == 384 and ops.FP32_MATMUL == "x3")
+    brows = [torch.full((nrows, 4 * H), float("nan"), device=dev) for _ in range(2)] if nrows else None
+    assert ops.lstm_bwd(whh_t, gates, cbuf, dsl, dcar, [0, 1], B, T, H, dbias_rows=brows) == (nrows > 0)
     dx = torch.empty(B, T, In, device=dev)
     for d, sfx in enumerate(("", "_reverse")):
         dg = gates[d].view(-1, 4 * H)
@@ -412,6 +436,10 @@ def test_lstm_layer_bidirectional(hip_device, B, T, In, H, persistent, monkeypat
         ops.colsum(dg, db0, db1)
         close(db0, dict(ref.named_parameters())["bias_ih_l0" + sfx].grad, 5e-5)
         assert torch.equal(db0, db1)
+        if nrows:
+            assert nrows == (B + 63) // 64
+            close(ops.colsum(brows[d], torch.empty(4 * H, device=dev)),
+                  dict(ref.named_parameters())["bias_ih_l0" + sfx].grad, 5e-5)
         ops.gemm_nt(dg, ops.transpose2d(P["weight_ih_l0" + sfx]), out=dx.view(-1, In), accumulate=(d > 0))
     close(dx, x.grad, 5e-5)
     assert not ops.persistent_lstm_error(dev)
