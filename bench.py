@@ -59,14 +59,19 @@ def host_cores():
 
 
 def pmc_traffic(conv_key="pe_conv3x3_fwd"):
-    """HBM bytes per conv3x3_kernel launch from the committed rocprofv3 --pmc passes (separate runs of
-    this same command; FETCH_SIZE doubled per the gfx950 correction) -- None when absent for this mode."""
-    entry = {"pe_conv3x3_fwd": "conv3x3_kernel_all_tiles", "pe_conv3x3_fwd_x3": "conv3x3_kernel_x3"}.get(conv_key)
+    """(HBM-side bytes per launch, MFMA-busy share) of the roofline kernel family from the committed rocprofv3 --pmc
+    passes of this same command (profiles/pmc_r02_summary.json, built by tools/prof_step.sh + tools/pmc_build.py:
+    FETCH_SIZE / WRITE_SIZE / SQ counters in separate passes, FETCH doubled per the gfx950 correction).  Launch-weighted
+    over the family's tile variants; (None, None) when the profile holds no entry for this mode."""
+    prefix = {"pe_conv3x3_fwd_x3": "conv3x3_halo_wf_kernel<", "pe_conv3x3_fwd_wf_x3": "conv3x3_halo_wf_kernel<"}.get(conv_key)
     try:
-        d = json.loads((ROOT / "profiles" / "pmc_r01_traffic.json").read_text())
-        return d[entry]["hbm_bytes_per_launch"]
+        d = json.loads((ROOT / "profiles" / "pmc_r02_summary.json").read_text())["kernels"]
+        rows = [v for k, v in d.items() if prefix and k.startswith(prefix) and ", 2, " in k and "hbm_bytes_per_launch" in v]
+        n = sum(v["calls"] for v in rows)
+        return (sum(v["hbm_bytes_per_launch"] * v["calls"] for v in rows) / n,
+                sum(v["mfma_busy"] * v["calls"] for v in rows) / n)
     except Exception:
-        return None
+        return None, None
 
 
 def cpu_baseline(n_steps=10, batch=4, n_warm=2):
@@ -311,7 +316,7 @@ def main():
                                                  "fwd + dgrad launches)" if wf_used else
                                                  "conv3x3_halo_kernel (halo-staged implicit-GEMM fwd + dgrad launches)")),
                     "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak,
-                    "peak_note": note, "traffic": pmc_traffic(conv_key),
+                    "peak_note": note, "traffic": pmc_traffic(conv_key)[0], "mfma_busy_pmc": pmc_traffic(conv_key)[1],
                     "avg_launch_ms": conv["avg_ms"], "launches_per_step": conv["calls"] / args.steps}
         mel = summ.get("pe_mel_forward")
         roof_mel = None
