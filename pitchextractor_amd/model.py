@@ -20,6 +20,7 @@ There is no eager/CPU path: running the module needs the HIP library and device 
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 from torch import nn
@@ -300,8 +301,20 @@ def _lstm_forward(models, xs, train, need_grad, drop: _DropoutCfg):
     return cur, saved
 
 
+OVERLAP_LSTM_WGRAD = os.environ.get("PE_OVERLAP_LSTM_WGRAD", "1") != "0"
+_SIDE_STREAMS: dict = {}
+
+
+def _side_stream(dev):
+    key = torch.device(dev)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
+    return _SIDE_STREAMS[key]
+
+
 def _lstm_backward(models, saved, dys, grads):
     """dys: list of [B,T,ND*H] grads of the top layer outputs.  Returns grads of the inputs."""
+    pending = []
     m0 = models[0].model
     H, L, ND = m0.hidden_size, m0.num_layers, m0.num_dirs
     B, T = dys[0].shape[:2]
@@ -323,20 +336,39 @@ def _lstm_backward(models, saved, dys, grads):
         brows = [torch.empty((nrows, 4 * H), dtype=torch.float32, device=dev) for _ in whh_t] if nrows else None
         have_db = ops.lstm_bwd(whh_t, lay.gates, lay.cbuf, dsl, dcs, rev, B, T, H,     # gates now hold d(pre-activations)
                                dbias_rows=brows)
+        # the data gradients first (the next layer's recurrence waits for them) ...
         dxs = []
         for mi, sm in enumerate(models):
-            x2 = _flat2(lay.x[mi])
             dx = torch.empty_like(lay.x[mi])
             for d in range(ND):
-                w_ih, w_hh, b_ih, b_hh = sm.model.cell(layer, d)
-                dg = lay.gates[mi * ND + d]
-                dg2 = _flat2(dg)
-                ops.gemm_tn(dg2, x2, out=grads[w_ih])
-                ops.lstm_whh_grad(dg, lay.y[mi][:, :, d * H:(d + 1) * H], grads[w_hh], d, B, T, H)
-                ops.colsum(brows[mi * ND + d] if have_db else dg2, grads[b_ih], grads[b_hh])
-                ops.gemm_nt(dg2, ops.transpose2d(w_ih), out=_flat2(dx), accumulate=(d > 0))
+                w_ih = sm.model.cell(layer, d)[0]
+                ops.gemm_nt(_flat2(lay.gates[mi * ND + d]), ops.transpose2d(w_ih), out=_flat2(dx), accumulate=(d > 0))
             dxs.append(dx)
+
+        # ... the weight / bias gradients need nothing downstream: on a side stream they fill the CUs the next
+        # layer's persistent recurrence leaves idle (192 of 256); joined before this function returns
+        def weight_grads(layer=layer, lay=lay, brows=brows, have_db=have_db):
+            for mi, sm in enumerate(models):
+                x2 = _flat2(lay.x[mi])
+                for d in range(ND):
+                    w_ih, w_hh, b_ih, b_hh = sm.model.cell(layer, d)
+                    dg = lay.gates[mi * ND + d]
+                    dg2 = _flat2(dg)
+                    ops.gemm_tn(dg2, x2, out=grads[w_ih])
+                    ops.lstm_whh_grad(dg, lay.y[mi][:, :, d * H:(d + 1) * H], grads[w_hh], d, B, T, H)
+                    ops.colsum(brows[mi * ND + d] if have_db else dg2, grads[b_ih], grads[b_hh])
+
+        if OVERLAP_LSTM_WGRAD and layer > 0:
+            side = _side_stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                weight_grads()
+            pending.append((side, brows))             # (keeps the bias rows alive until the side stream has read them)
+        else:
+            weight_grads()
         dys = dxs
+    for side, _ in pending:
+        torch.cuda.current_stream(dev).wait_stream(side)
     return dys
 
 

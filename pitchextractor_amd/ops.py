@@ -44,13 +44,13 @@ def _rows2d(t: torch.Tensor, name: str):
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
-    """Grow-only per-device scratch buffer (bytes).  Consumers on one stream run in order, so
-    a single buffer is shared by all ops."""
-    key = torch.device(device)
+    """Grow-only scratch buffer (bytes) per device AND current stream.  Consumers on one stream run in order, so
+    a single buffer serves all ops launched there; work on a side stream gets its own."""
+    key = (torch.device(device), _lib.stream_ptr())
     buf = _WS.get(key)
     nbytes = max(int(nbytes), 1 << 20)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=key)
+        buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=key[0])
         _WS[key] = buf
     return buf
 
