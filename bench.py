@@ -125,8 +125,9 @@ def _family_table(summ, steps, step_ms):
                 row.update(bound="hbm", achieved_gbps=rate / 1e9, frac_of_peak=rate / 1e9 / HBM_PEAK_GBPS)
             else:
                 # the entry point's suffix names the pipe its products ran on
-                peak = (MFMA_BF16_PEAK_TFLOPS if name.endswith("_bf16") else
-                        MFMA_BF16_PEAK_TFLOPS / 6.0 if name.endswith("_x3") else MFMA_F32_PEAK_TFLOPS)
+                base = name.split("#")[0]           # "#tag": ops.timer_tag (e.g. the overlapped dgrad launches)
+                peak = (MFMA_BF16_PEAK_TFLOPS if base.endswith("_bf16") else
+                        MFMA_BF16_PEAK_TFLOPS / 6.0 if base.endswith("_x3") else MFMA_F32_PEAK_TFLOPS)
                 row.update(bound="mfma", achieved_tflops=rate / 1e12, peak_tflops=peak, frac_of_peak=rate / 1e12 / peak)
         rows[name] = row
     return rows
@@ -239,14 +240,22 @@ def main():
     # (a) family table: events around every C-ABI call for a few extra steps (N = 1 only)
     fam_summ, fam_ms = (timer.summary(), ms) if args.family_timing else (None, None)
     if world == 1 and not args.family_timing and args.family_steps > 0:
-        ops.TIMER = ops.KernelTimer(None)
-        torch.cuda.synchronize(dev)
-        t_f = time.perf_counter()
-        for _ in range(args.family_steps):
-            tr.run(batch)
-        torch.cuda.synchronize(dev)
-        fam_ms = (time.perf_counter() - t_f) / args.family_steps * 1e3
-        fam_summ, ops.TIMER = ops.TIMER.summary(), None
+        # with the side-stream overlaps OFF: an event pair around a launch then times that kernel alone (concurrent
+        # kernels would each be charged the shared wall time), and the rows add up to a serialised step
+        from pitchextractor_amd import model as pe_model
+        saved_ov = (pe_model.OVERLAP_CONV_WGRAD, pe_model.OVERLAP_LSTM_WGRAD, pe_model.OVERLAP_TF_WGRAD)
+        pe_model.OVERLAP_CONV_WGRAD = pe_model.OVERLAP_LSTM_WGRAD = pe_model.OVERLAP_TF_WGRAD = False
+        try:
+            ops.TIMER = ops.KernelTimer(None)
+            torch.cuda.synchronize(dev)
+            t_f = time.perf_counter()
+            for _ in range(args.family_steps):
+                tr.run(batch)
+            torch.cuda.synchronize(dev)
+            fam_ms = (time.perf_counter() - t_f) / args.family_steps * 1e3
+            fam_summ, ops.TIMER = ops.TIMER.summary(), None
+        finally:
+            pe_model.OVERLAP_CONV_WGRAD, pe_model.OVERLAP_LSTM_WGRAD, pe_model.OVERLAP_TF_WGRAD = saved_ov
 
     # (b) SURVEY 8(d)'s step: from pinned host audio, the next batch's H2D (49 MB) in flight on a side stream
     from_host = None
@@ -293,12 +302,22 @@ def main():
     if rank == 0:
         frames = args.batch * world * FRAMES * args.steps
         summ = timer.summary()
-        parts = [summ[k] for k in conv_keys if k in summ]
-        conv = None
-        if parts:
-            conv = {"calls": sum(p["calls"] for p in parts), "total_ms": sum(p["total_ms"] for p in parts),
-                    "work": sum(p["work"] for p in parts)}
-            conv["avg_ms"] = conv["total_ms"] / conv["calls"]
+        from pitchextractor_amd import model as pe_model
+        overlapped = pe_model.OVERLAP_CONV_WGRAD      # dgrad launches then share the GPU with side-stream wgrad kernels
+
+        def fold(keys):
+            parts = [summ[k] for k in keys if k in summ]
+            if not parts:
+                return None
+            c = {"calls": sum(p["calls"] for p in parts), "total_ms": sum(p["total_ms"] for p in parts),
+                 "work": sum(p["work"] for p in parts)}
+            c["avg_ms"] = c["total_ms"] / c["calls"]
+            return c
+
+        fwd_only, dgrad = fold(conv_keys), fold({k + "#dgrad" for k in conv_keys})
+        # the roofline is taken over launches that run ALONE: forward + dgrad when nothing overlaps them, forward only
+        # when the dgrad launches share the GPU with the side-stream weight-gradient kernels
+        conv = fwd_only if (overlapped or dgrad is None) else fold(conv_keys | {k + "#dgrad" for k in conv_keys})
         wf_used = ("pe_conv3x3_fwd_wf" + sfx) in summ
         roof = None
         if conv:
@@ -311,13 +330,21 @@ def main():
                                                            f"native fp32 MFMA peak is {MFMA_F32_PEAK_TFLOPS} TFLOP/s")
             else:
                 peak, note = MFMA_F32_PEAK_TFLOPS, "fp32 MFMA (32x32x2) peak"
-            roof = {"bound": "mfma", "kernel": ("conv3x3_kernel (implicit-GEMM fwd + dgrad launches)" if not (bf16 or x3) else
+            which = ("forward launches, which run alone; the same kernel's dgrad launches share the GPU with side-stream "
+                     "weight-gradient kernels: dgrad_overlapped" if (overlapped and dgrad) else "fwd + dgrad launches")
+            roof = {"bound": "mfma", "kernel": ("conv3x3_kernel (implicit-GEMM; " + which + ")" if not (bf16 or x3) else
                                                 ("conv3x3_halo_wf_kernel (halo-staged activations, weight fragments from L2; "
-                                                 "fwd + dgrad launches)" if wf_used else
-                                                 "conv3x3_halo_kernel (halo-staged implicit-GEMM fwd + dgrad launches)")),
+                                                 + which + ")" if wf_used else
+                                                 "conv3x3_halo_kernel (halo-staged implicit GEMM; " + which + ")")),
                     "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak,
                     "peak_note": note, "traffic": pmc_traffic(conv_key)[0], "mfma_busy_pmc": pmc_traffic(conv_key)[1],
                     "avg_launch_ms": conv["avg_ms"], "launches_per_step": conv["calls"] / args.steps}
+            if overlapped and dgrad:
+                roof["dgrad_overlapped"] = {"avg_launch_ms": dgrad["avg_ms"], "launches_per_step": dgrad["calls"] / args.steps,
+                                            "achieved": dgrad["work"] / (dgrad["total_ms"] * 1e-3) / 1e12,
+                                            "note": "HIP-event time of a launch that runs concurrently with "
+                                                    "conv3x3_wgrad9 / gemm_tn on a side stream (PE_OVERLAP_CONV_WGRAD=0 "
+                                                    "serialises them)"}
         mel = summ.get("pe_mel_forward")
         roof_mel = None
         if mel:
@@ -345,6 +372,9 @@ def main():
         if fam_summ is not None:
             line["kernel_families"] = {"steps": args.steps if args.family_timing else args.family_steps,
                                        "ms_per_step_with_events": fam_ms,
+                                       "note": ("extra steps with the side-stream weight-gradient overlaps off: every row "
+                                                "is a kernel family timed alone") if not args.family_timing else
+                                               "events inside the timed region (concurrent kernels share wall time)",
                                        "rows": _family_table(fam_summ, args.steps if args.family_timing else args.family_steps,
                                                              fam_ms)}
         if native_ref is not None:

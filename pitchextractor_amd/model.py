@@ -218,15 +218,19 @@ def _res_forward(blk: _ResBlock, x, pool, train, need_grad, slope, x_stats=None)
     return out, s, out_stats
 
 
-def _res_backward(blk: _ResBlock, s, d_out, pool, slope, grads):
-    """d_out: grad of the block output.  Returns grad wrt the block input (dense, overwritten)."""
-    ops.conv3x3_wgrad(s.a, d_out, grads[blk.conv[3].weight])
-    d_a = ops.conv3x3_fwd(d_out, s.wd3)
+def _res_backward(blk: _ResBlock, s, d_out, pool, slope, grads, side):
+    """d_out: grad of the block output.  Returns grad wrt the block input (dense, overwritten).  The three weight
+    gradients go through `side` (_SideWork)."""
+    side.run(lambda: (ops.conv3x3_wgrad(s.a, d_out, grads[blk.conv[3].weight]),
+                      ops.gemm_tn(_flat2(d_out), _flat2(s.p), out=grads[blk.conv1by1.weight].view(blk.cout, blk.cin))),
+             d_out)
+    with ops.timer_tag("dgrad"):
+        d_a = ops.conv3x3_fwd(d_out, s.wd3)
     d_c = ops.bn_act_pool_bwd(s.c, d_a, s.bn_mid, grads[blk.conv[1].weight], grads[blk.conv[1].bias], pool=1,
                               slope=slope, dx=d_a)
-    ops.conv3x3_wgrad(s.p, d_c, grads[blk.conv[0].weight])
-    d_p = ops.conv3x3_fwd(d_c, s.wd0)
-    ops.gemm_tn(_flat2(d_out), _flat2(s.p), out=grads[blk.conv1by1.weight].view(blk.cout, blk.cin))
+    side.run(lambda: ops.conv3x3_wgrad(s.p, d_c, grads[blk.conv[0].weight]), d_c)
+    with ops.timer_tag("dgrad"):
+        d_p = ops.conv3x3_fwd(d_c, s.wd0)
     w1t = ops.transpose2d(blk.conv1by1.weight.view(blk.cout, blk.cin))
     ops.gemm_nt(_flat2(d_out), w1t, out=_flat2(d_p), accumulate=True)
     return ops.bn_act_pool_bwd(s.x, d_p, s.bn_pre, grads[blk.pre_conv[0].weight], grads[blk.pre_conv[0].bias],
@@ -310,6 +314,38 @@ def _side_stream(dev):
     if key not in _SIDE_STREAMS:
         _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
     return _SIDE_STREAMS[key]
+
+
+class _SideWork:
+    """Weight-gradient kernels need nothing downstream in the same backward pass, and they are MFMA-bound where the
+    data-gradient chain between them is largely HBM-bound (BatchNorm / pooling backward): launched on a side stream
+    they fill what the main chain leaves idle.  `run(fn, *keep)` orders fn behind everything already queued on the
+    main stream and keeps the tensors it reads alive (the allocator recycles a freed block for the stream it was
+    allocated on without waiting for other streams); `join()` makes the main stream wait for all of it."""
+
+    def __init__(self, dev, enabled):
+        self.dev, self.enabled, self.keep, self.used = dev, enabled, [], False
+
+    def run(self, fn, *keep):
+        if not self.enabled:
+            fn()
+            return
+        side = _side_stream(self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):
+            fn()
+        self.keep.append(keep)
+        self.used = True
+
+    def join(self):
+        if self.used:
+            torch.cuda.current_stream(self.dev).wait_stream(_side_stream(self.dev))
+        self.keep.clear()
+        self.used = False
+
+
+OVERLAP_CONV_WGRAD = os.environ.get("PE_OVERLAP_CONV_WGRAD", "1") != "0"
+OVERLAP_TF_WGRAD = os.environ.get("PE_OVERLAP_TF_WGRAD", "1") != "0"
 
 
 def _lstm_backward(models, saved, dys, grads):
@@ -420,7 +456,8 @@ def _tf_forward(sm, x, train, need_grad, drop: _DropoutCfg):
     return y.view(B, T, D), (saved if need_grad else None)
 
 
-def _tf_backward(sm, saved, dy, g):
+def _tf_backward(sm, saved, dy, g, side):
+    """Backward of one Transformer branch; the weight / bias gradients go through `side` (_SideWork)."""
     B, T, D = saved.shape
     H = sm.nhead
     dh = D // H
@@ -435,20 +472,17 @@ def _tf_backward(sm, saved, dy, g):
         # y = LN2(x1 + dropout2(ff))
         dsum = ops.layernorm_bwd(dy, c.ln2, lyr.norm2.weight, g[lyr.norm2.weight], g[lyr.norm2.bias])
         dff = _dropout_bwd(dsum, p, c.mask2)
-        ops.gemm_tn(dff, c.a, out=g[lyr.linear2.weight])
-        ops.colsum(dff, g[lyr.linear2.bias])
+        side.run(lambda: (ops.gemm_tn(dff, c.a, out=g[lyr.linear2.weight]), ops.colsum(dff, g[lyr.linear2.bias])), dff)
         da = ops.gemm_nt(dff, ops.transpose2d(lyr.linear2.weight))
         da = _dropout_bwd(da, p, c.mask_f)
         dh_ = ops.gelu_bwd(c.h, da, out=da)
-        ops.gemm_tn(dh_, c.x1, out=g[lyr.linear1.weight])
-        ops.colsum(dh_, g[lyr.linear1.bias])
+        side.run(lambda: (ops.gemm_tn(dh_, c.x1, out=g[lyr.linear1.weight]), ops.colsum(dh_, g[lyr.linear1.bias])), dh_)
         dx1 = ops.gemm_nt(dh_, ops.transpose2d(lyr.linear1.weight))
         ops.copy2d(dsum, dx1, accumulate=True)                                             # residual branch
         # x1 = LN1(x + dropout1(sa))
         dsum1 = ops.layernorm_bwd(dx1, c.ln1, lyr.norm1.weight, g[lyr.norm1.weight], g[lyr.norm1.bias])
         dsa = _dropout_bwd(dsum1, p, c.mask1)
-        ops.gemm_tn(dsa, c.o, out=g[att.out_proj.weight])
-        ops.colsum(dsa, g[att.out_proj.bias])
+        side.run(lambda: (ops.gemm_tn(dsa, c.o, out=g[att.out_proj.weight]), ops.colsum(dsa, g[att.out_proj.bias])), dsa)
         do = ops.gemm_nt(dsa, ops.transpose2d(att.out_proj.weight))                        # [R, D] merged heads
         if c.fused:
             dqkv = ops.attn_bwd(c.qkv, c.o, do, c.lse, c.mask_p, B, T, H, scale, p if c.mask_p is not None else 0.0)
@@ -464,8 +498,8 @@ def _tf_backward(sm, saved, dy, g):
             ops.softmax_bwd_(c.P, dP, scale)                                               # dP <- dS (incl. 1/sqrt(dh))
             ops.bgemm(1, dP, pview, kv, hview, dq, hview, H, B * H, T, dh, T)              # dQ = dS K
             ops.bgemm(2, dP, pview, qv, hview, dk, hview, H, B * H, T, dh, T)              # dK = dS^T Q
-        ops.gemm_tn(dqkv, c.x, out=g[att.in_proj_weight])
-        ops.colsum(dqkv, g[att.in_proj_bias])
+        side.run(lambda: (ops.gemm_tn(dqkv, c.x, out=g[att.in_proj_weight]), ops.colsum(dqkv, g[att.in_proj_bias])),
+                 dqkv)
         dy = ops.gemm_nt(dqkv, ops.transpose2d(att.in_proj_weight))
         ops.copy2d(dsum1, dy, accumulate=True)
     dx = ops.layernorm_bwd(dy, saved.ln0, sm.layer_norm.weight, g[sm.layer_norm.weight], g[sm.layer_norm.bias])
@@ -718,8 +752,10 @@ class JDCNet(nn.Module):
         if models[0].model_type == "bilstm":
             dseq_c, dseq_d = _lstm_backward(models, s.lstm, [dyc.view(B, T, D), dyd.view(B, T, D)], g)
         else:
-            dseq_d = _tf_backward(models[1], s.tf_d, dyd.view(B, T, D), g)
-            dseq_c = _tf_backward(models[0], s.tf_c, dyc.view(B, T, D), g)
+            tf_side = _SideWork(dev, OVERLAP_TF_WGRAD)
+            dseq_d = _tf_backward(models[1], s.tf_d, dyd.view(B, T, D), g, tf_side)
+            dseq_c = _tf_backward(models[0], s.tf_c, dyc.view(B, T, D), g, tf_side)
+            tf_side.join()
 
         if self._dp is not None:            # temporal heads + output heads are final: start their all-reduce
             self._dp.reduce_range(self._seq_offset(), self._grad_flat.numel())
@@ -732,7 +768,8 @@ class JDCNet(nn.Module):
         bn1 = self.detector_conv[1]
         d_dconv = ops.bn_act_pool_bwd(s.dconv, d_dact, s.bnd, g[bn1.weight], g[bn1.bias], pool=1, slope=slope)
         wdet = self.detector_conv[0].weight
-        ops.gemm_tn(_flat2(d_dconv), s.concat.view(-1, 640), out=g[wdet].view(256, 640))
+        side = _SideWork(dev, OVERLAP_CONV_WGRAD)
+        side.run(lambda: ops.gemm_tn(_flat2(d_dconv), s.concat.view(-1, 640), out=g[wdet].view(256, 640)), d_dconv)
         d_concat = ops.gemm_nt(_flat2(d_dconv), ops.transpose2d(wdet.view(256, 640))).view(B, T, 2, 640)
         # classifier branch joins at the pool_block output (channels 384..639 of the concat)
         ops.seq_to_nhwc(dseq_c, d_concat, 256, coff=384, accumulate=True)
@@ -742,17 +779,19 @@ class JDCNet(nn.Module):
         bnp = self.pool_block[0]
         d_rb3 = ops.bn_act_pool_bwd(s.rb3, d_pool, s.bnp, g[bnp.weight], g[bnp.bias], pool=4, slope=slope)
 
-        d_rb2 = _res_backward(self.res_block3, s.r3, d_rb3, 2, slope, g)
+        d_rb2 = _res_backward(self.res_block3, s.r3, d_rb3, 2, slope, g, side)
         ops.maxpool_bwd_add(s.rb2, d_concat, d_rb2, 10, coff=192)
-        d_rb1 = _res_backward(self.res_block2, s.r2, d_rb2, 2, slope, g)
+        d_rb1 = _res_backward(self.res_block2, s.r2, d_rb2, 2, slope, g, side)
         ops.maxpool_bwd_add(s.rb1, d_concat, d_rb1, 20, coff=64)
-        d_cb = _res_backward(self.res_block1, s.r1, d_rb1, 2, slope, g)
+        d_cb = _res_backward(self.res_block1, s.r1, d_rb1, 2, slope, g, side)
         ops.maxpool_bwd_add(s.cb, d_concat, d_cb, 40, coff=0)
 
         cbk = self.conv_block
-        ops.conv3x3_wgrad(s.a0, d_cb, g[cbk[3].weight])
-        d_a0 = ops.conv3x3_fwd(d_cb, s.wd_cb)
+        side.run(lambda: ops.conv3x3_wgrad(s.a0, d_cb, g[cbk[3].weight]), d_cb)
+        with ops.timer_tag("dgrad"):
+            d_a0 = ops.conv3x3_fwd(d_cb, s.wd_cb)
         d_y0 = ops.bn_act_pool_bwd(s.y0, d_a0, s.bn0, g[cbk[1].weight], g[cbk[1].bias], pool=1, slope=slope, dx=d_a0)
         ops.conv3x3_c1_wgrad(s.x_btf, d_y0, g[cbk[0].weight])
+        side.join()                             # every weight gradient is final from here on
         if self._dp is not None:
             self._dp.reduce_range(0, self._seq_offset())

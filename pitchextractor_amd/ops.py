@@ -78,6 +78,25 @@ class KernelTimer:
 TIMER: KernelTimer | None = None
 
 
+TIMER_TAG = ""            # appended as "#tag" to the timer key of the calls made inside `timer_tag(tag)`
+
+
+class timer_tag:
+    """Label the timed C-ABI calls of a region (bench.py separates the data-gradient launches of the conv kernel,
+    which share the GPU with side-stream weight-gradient kernels, from its forward launches, which run alone)."""
+
+    def __init__(self, tag):
+        self.tag, self.prev = tag, ""
+
+    def __enter__(self):
+        global TIMER_TAG
+        self.prev, TIMER_TAG = TIMER_TAG, self.tag
+
+    def __exit__(self, *exc):
+        global TIMER_TAG
+        TIMER_TAG = self.prev
+
+
 def _call(name, *args, work=0.0):
     lib = _lib.load()
     if TIMER is None or (TIMER.only is not None and name not in TIMER.only):
@@ -87,7 +106,7 @@ def _call(name, *args, work=0.0):
     a.record()
     _lib.check(getattr(lib, name)(*args), name)
     b.record()
-    TIMER.add(name, a, b, work)
+    TIMER.add(name + ("#" + TIMER_TAG if TIMER_TAG else ""), a, b, work)
 
 
 def _s():
