@@ -298,6 +298,27 @@ def test_full_size_training_step_matches_oracle_by_tiling(hip_device, oracle_b8,
     assert not bad, bad
 
 
+def test_side_stream_weight_gradients_change_nothing(hip_device, oracle_b8, monkeypatch):
+    """model._SideWork / the LSTM side stream only move WHERE the weight-gradient kernels run: at B = 256 (full
+    persistent-LSTM grid, every overlap live) the loss and every gradient are bit-identical to the serialised
+    backward, twice in a row (a cross-stream lifetime or ordering bug shows up as a differing element)."""
+    from pitchextractor_amd import model as pe_model
+    state, x8, f0, sil, _ = oracle_b8
+    x, f0, sil = x8.repeat(32, 1, 1, 1), f0.repeat(32, 1), sil.repeat(32, 1)
+    runs = {}
+    for on in (False, True, True):
+        for flag in ("OVERLAP_LSTM_WGRAD", "OVERLAP_CONV_WGRAD", "OVERLAP_TF_WGRAD"):
+            monkeypatch.setattr(pe_model, flag, on)
+        _, _, loss, g = _hip_step_grads(state, x, f0, sil, hip_device)
+        runs.setdefault(on, []).append((loss, g))
+    assert not ops.persistent_lstm_error(hip_device)
+    (loss0, g0), = runs[False]
+    for loss1, g1 in runs[True]:
+        assert loss1 == loss0
+        for name in g0:
+            assert torch.equal(g0[name], g1[name]), name
+
+
 def test_cpu_input_fails_loudly():
     net = JDCNet(num_class=1, sequence_model_config=dict(SEQ_CFG))
     with pytest.raises(RuntimeError):

@@ -278,3 +278,28 @@ def test_fused_and_unfused_attention_agree_in_the_model(hip_device, monkeypatch)
     assert _rel(outs[True][0], outs[False][0].cpu().numpy()) <= 2e-5 and _rel(outs[True][1], outs[False][1].cpu().numpy()) <= 2e-5
     ga, gb = outs[True][2].double(), outs[False][2].double()
     assert ((ga - gb).norm() / gb.norm()).item() <= 1e-4
+
+
+def test_side_stream_weight_gradients_change_nothing_transformer(hip_device, monkeypatch):
+    """Transformer-head JDCNet, train mode with live dropout, B = 16: with the weight-gradient kernels on the side
+    stream the logits and the flat gradient buffer are bit-identical to the serialised backward."""
+    from pitchextractor_amd import model as pe_model
+    state = model_ref.seeded_state(11, model_type="transformer", num_layers=2)
+    cfg = dict(TF_CFG, num_layers=2, dropout=0.1)
+    x = golden_input(6).repeat(8, 1, 1, 1)
+    f0, sil = (t.repeat(8, 1).to(hip_device) for t in golden_targets(6))
+    outs = []
+    for on in (False, True, True):
+        for flag in ("OVERLAP_LSTM_WGRAD", "OVERLAP_CONV_WGRAD", "OVERLAP_TF_WGRAD"):
+            monkeypatch.setattr(pe_model, flag, on)
+        net = JDCNet(num_class=1, sequence_model_config=dict(cfg))
+        net.load_state_dict(state)
+        net = net.to(hip_device).train()
+        net.dropout_cfg.seed = 5
+        cls, det = net(x.to(hip_device))
+        out3, d_f0, d_sil = ops.f0_sil_loss(cls.detach().reshape(-1), f0.reshape(-1), det.detach().reshape(-1),
+                                            sil.reshape(-1), 0.1)
+        torch.autograd.backward([cls, det], [d_f0.view_as(cls), d_sil.view_as(det)])
+        outs.append((cls.detach().clone(), net.flat_gradients().clone()))
+    for cls1, g1 in outs[1:]:
+        assert torch.equal(cls1, outs[0][0]) and torch.equal(g1, outs[0][1])
