@@ -53,8 +53,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(RowLoader al, RowLoader bl
 // store instructions, bias fetched once per column quad).  Bit-identical sums.  Needs N % 4 == 0 and a 16-byte
 // aligned C with ldc % 4 == 0 (checked by the host).
 template <class TL, int MODE>
-__global__ __launch_bounds__(256, (MODE == kSplit && TL::BM == 128 && TL::BN == 128) ? 3 : 1) void gemm_nt_t_kernel(RowLoader al, RowLoader bl, StoreEpi ep, int K, int tiles_m,
-                                                        int tiles_n) {
+__global__ __launch_bounds__(256, (MODE == kSplit && TL::BM == 128 && TL::BN == 128) ? 3 : 1)
+void gemm_nt_t_kernel(RowLoader al, RowLoader bl, StoreEpi ep, int K, int tiles_m, int tiles_n) {
   using TT = Tile<TL::BN, TL::BM, TL::WAVES_N, TL::WAVES_M>;
   __shared__ __attribute__((aligned(16))) float As[TL::BM * nt_row_floats<MODE>()];
   __shared__ __attribute__((aligned(16))) float Bs[TL::BN * nt_row_floats<MODE>()];
@@ -90,13 +90,6 @@ __global__ __launch_bounds__(256, (MODE == kSplit && TL::BM == 128 && TL::BN == 
       }
     }
 }
-
-template <class F, int... Q>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Q...>) {
-  (f(std::integral_constant<int, Q>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 // ---- NT, three-term split, software-pipelined: 256 x 128 tile, ONE workgroup per CU
 // The kernels above alternate a staging phase (split + LDS stores, matrix pipe idle) with an MFMA phase between two

@@ -16,6 +16,7 @@
 // B operand lane l holds B[k = l >> 5][j = l & 31]; accumulator register g of lane l is
 // C[row = (g & 3) + 8 * (g >> 2) + 4 * (l >> 5)][col = l & 31].
 #pragma once
+#include <utility>
 #include "common.h"
 
 namespace pe {
@@ -368,6 +369,15 @@ __device__ __forceinline__ void nt_mainloop_split(AL& al, BL& bl, int K, float* 
     }
   }
 }
+
+// compile-time loop: body(std::integral_constant<int, I>) for I = 0 .. N-1 (a plain `#pragma unroll` loop of a few
+// hundred instructions is only partly unrolled, and its indices then stop being constants)
+template <class F, int... Q>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Q...>) {
+  (f(std::integral_constant<int, Q>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 template <int MODE> constexpr int nt_row_floats() { return MODE == kSplit ? kSplitRowFloats : kLdsStride; }
 
