@@ -124,13 +124,19 @@ class GradientAllReduce:
             for b in buffers:
                 dist.broadcast(b, src=0, group=group)
 
-    def reduce_range(self, lo: int, hi: int):
-        """Start reducing gradient elements [lo, hi) (they must be final), in bucket-sized messages."""
+    def reduce_range(self, lo: int, hi: int, after=None):
+        """Start reducing gradient elements [lo, hi), in bucket-sized messages.  They must be final once the work
+        queued so far on the current stream -- and on `after`, a second stream that also writes them (the model's
+        weight-gradient side stream) -- has run."""
         if self.world == 1 or hi <= lo:
             return
         self._issued = True
         if self._stream is not None:
             self._stream.wait_stream(torch.cuda.current_stream(self.flat_grad.device))
+            if after is not None:
+                self._stream.wait_stream(after)
+        elif after is not None:              # no reducer stream (gloo): the collective runs behind the current stream
+            torch.cuda.current_stream(self.flat_grad.device).wait_stream(after)
         per = max(1, self.bucket_elems)
         for a in range(lo, hi, per):
             chunk = self.flat_grad[a:min(hi, a + per)]

@@ -223,12 +223,12 @@ def _res_backward(blk: _ResBlock, s, d_out, pool, slope, grads, side):
     gradients go through `side` (_SideWork)."""
     side.run(lambda: (ops.conv3x3_wgrad(s.a, d_out, grads[blk.conv[3].weight]),
                       ops.gemm_tn(_flat2(d_out), _flat2(s.p), out=grads[blk.conv1by1.weight].view(blk.cout, blk.cin))),
-             d_out)
+             d_out, on=OVERLAP_CONV_WGRAD)
     with ops.timer_tag("dgrad"):
         d_a = ops.conv3x3_fwd(d_out, s.wd3)
     d_c = ops.bn_act_pool_bwd(s.c, d_a, s.bn_mid, grads[blk.conv[1].weight], grads[blk.conv[1].bias], pool=1,
                               slope=slope, dx=d_a)
-    side.run(lambda: ops.conv3x3_wgrad(s.p, d_c, grads[blk.conv[0].weight]), d_c)
+    side.run(lambda: ops.conv3x3_wgrad(s.p, d_c, grads[blk.conv[0].weight]), d_c, on=OVERLAP_CONV_WGRAD)
     with ops.timer_tag("dgrad"):
         d_p = ops.conv3x3_fwd(d_c, s.wd0)
     w1t = ops.transpose2d(blk.conv1by1.weight.view(blk.cout, blk.cin))
@@ -338,11 +338,15 @@ class _SideWork:
     main stream and keeps the tensors it reads alive (the allocator recycles a freed block for the stream it was
     allocated on without waiting for other streams); `join()` makes the main stream wait for all of it."""
 
-    def __init__(self, dev, enabled):
+    def __init__(self, dev, enabled=True):
         self.dev, self.enabled, self.keep, self.used = dev, enabled, [], False
 
-    def run(self, fn, *keep):
-        if not self.enabled:
+    def pending_stream(self):
+        """The side stream if anything is queued on it since the last join (a reducer must wait for it), else None."""
+        return _side_stream(self.dev) if self.used else None
+
+    def run(self, fn, *keep, on=True):
+        if not (self.enabled and on):
             fn()
             return
         side = _side_stream(self.dev)
@@ -361,11 +365,14 @@ class _SideWork:
 
 OVERLAP_CONV_WGRAD = os.environ.get("PE_OVERLAP_CONV_WGRAD", "1") != "0"
 OVERLAP_TF_WGRAD = os.environ.get("PE_OVERLAP_TF_WGRAD", "1") != "0"
+# the LSTM weight gradients are joined right after the LSTM backward: letting them float under the conv backward
+# ("late") only delays the conv weight gradients queued behind them on the same side stream (+1.1 ms, measured)
+LSTM_WGRAD_JOIN_EARLY = os.environ.get("PE_LSTM_WGRAD_JOIN", "early") == "early"
 
 
-def _lstm_backward(models, saved, dys, grads):
-    """dys: list of [B,T,ND*H] grads of the top layer outputs.  Returns grads of the inputs."""
-    pending = []
+def _lstm_backward(models, saved, dys, grads, side):
+    """dys: list of [B,T,ND*H] grads of the top layer outputs.  Returns grads of the inputs.  Weight / bias gradients
+    go through `side` (_SideWork) and are NOT joined here."""
     m0 = models[0].model
     H, L, ND = m0.hidden_size, m0.num_layers, m0.num_dirs
     B, T = dys[0].shape[:2]
@@ -396,8 +403,8 @@ def _lstm_backward(models, saved, dys, grads):
                 ops.gemm_nt(_flat2(lay.gates[mi * ND + d]), ops.transpose2d(w_ih), out=_flat2(dx), accumulate=(d > 0))
             dxs.append(dx)
 
-        # ... the weight / bias gradients need nothing downstream: on a side stream they fill the CUs the next
-        # layer's persistent recurrence leaves idle (192 of 256); joined before this function returns
+        # ... the weight / bias gradients need nothing downstream: on the (low-priority) side stream they fill the
+        # CUs the next layer's persistent recurrence leaves idle (192 of 256) and then the gaps of the conv backward
         def weight_grads(layer=layer, lay=lay, brows=brows, have_db=have_db):
             for mi, sm in enumerate(models):
                 x2 = _flat2(lay.x[mi])
@@ -409,17 +416,8 @@ def _lstm_backward(models, saved, dys, grads):
                     ops.lstm_whh_grad(dg, lay.y[mi][:, :, d * H:(d + 1) * H], grads[w_hh], d, B, T, H)
                     ops.colsum(brows[mi * ND + d] if have_db else dg2, grads[b_ih], grads[b_hh])
 
-        if OVERLAP_LSTM_WGRAD and layer > 0:
-            side = _side_stream(dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):
-                weight_grads()
-            pending.append((side, brows))             # (keeps the bias rows alive until the side stream has read them)
-        else:
-            weight_grads()
+        side.run(weight_grads, brows, on=OVERLAP_LSTM_WGRAD)   # (brows: alive until the side stream has read them)
         dys = dxs
-    for side, _ in pending:
-        torch.cuda.current_stream(dev).wait_stream(side)
     return dys
 
 
@@ -487,17 +485,20 @@ def _tf_backward(sm, saved, dy, g, side):
         # y = LN2(x1 + dropout2(ff))
         dsum = ops.layernorm_bwd(dy, c.ln2, lyr.norm2.weight, g[lyr.norm2.weight], g[lyr.norm2.bias])
         dff = _dropout_bwd(dsum, p, c.mask2)
-        side.run(lambda: (ops.gemm_tn(dff, c.a, out=g[lyr.linear2.weight]), ops.colsum(dff, g[lyr.linear2.bias])), dff)
+        side.run(lambda: (ops.gemm_tn(dff, c.a, out=g[lyr.linear2.weight]), ops.colsum(dff, g[lyr.linear2.bias])),
+                 dff, on=OVERLAP_TF_WGRAD)
         da = ops.gemm_nt(dff, ops.transpose2d(lyr.linear2.weight))
         da = _dropout_bwd(da, p, c.mask_f)
         dh_ = ops.gelu_bwd(c.h, da, out=da)
-        side.run(lambda: (ops.gemm_tn(dh_, c.x1, out=g[lyr.linear1.weight]), ops.colsum(dh_, g[lyr.linear1.bias])), dh_)
+        side.run(lambda: (ops.gemm_tn(dh_, c.x1, out=g[lyr.linear1.weight]), ops.colsum(dh_, g[lyr.linear1.bias])),
+                 dh_, on=OVERLAP_TF_WGRAD)
         dx1 = ops.gemm_nt(dh_, ops.transpose2d(lyr.linear1.weight))
         ops.copy2d(dsum, dx1, accumulate=True)                                             # residual branch
         # x1 = LN1(x + dropout1(sa))
         dsum1 = ops.layernorm_bwd(dx1, c.ln1, lyr.norm1.weight, g[lyr.norm1.weight], g[lyr.norm1.bias])
         dsa = _dropout_bwd(dsum1, p, c.mask1)
-        side.run(lambda: (ops.gemm_tn(dsa, c.o, out=g[att.out_proj.weight]), ops.colsum(dsa, g[att.out_proj.bias])), dsa)
+        side.run(lambda: (ops.gemm_tn(dsa, c.o, out=g[att.out_proj.weight]), ops.colsum(dsa, g[att.out_proj.bias])),
+                 dsa, on=OVERLAP_TF_WGRAD)
         do = ops.gemm_nt(dsa, ops.transpose2d(att.out_proj.weight))                        # [R, D] merged heads
         if c.fused:
             dqkv = ops.attn_bwd(c.qkv, c.o, do, c.lse, c.mask_p, B, T, H, scale, p if c.mask_p is not None else 0.0)
@@ -514,7 +515,7 @@ def _tf_backward(sm, saved, dy, g, side):
             ops.bgemm(1, dP, pview, kv, hview, dq, hview, H, B * H, T, dh, T)              # dQ = dS K
             ops.bgemm(2, dP, pview, qv, hview, dk, hview, H, B * H, T, dh, T)              # dK = dS^T Q
         side.run(lambda: (ops.gemm_tn(dqkv, c.x, out=g[att.in_proj_weight]), ops.colsum(dqkv, g[att.in_proj_bias])),
-                 dqkv)
+                 dqkv, on=OVERLAP_TF_WGRAD)
         dy = ops.gemm_nt(dqkv, ops.transpose2d(att.in_proj_weight))
         ops.copy2d(dsum1, dy, accumulate=True)
     dx = ops.layernorm_bwd(dy, saved.ln0, sm.layer_norm.weight, g[sm.layer_norm.weight], g[sm.layer_norm.bias])
@@ -764,16 +765,18 @@ class JDCNet(nn.Module):
         dyd = ops.head_bwd(s.yd.view(-1, D), det.weight, d_det.view(-1), g[det.weight], g[det.bias])
 
         models = [self.sequence_classifier, self.sequence_detector]
+        side = _SideWork(dev)               # weight-gradient kernels of the whole backward; joined once, at the end
         if models[0].model_type == "bilstm":
-            dseq_c, dseq_d = _lstm_backward(models, s.lstm, [dyc.view(B, T, D), dyd.view(B, T, D)], g)
+            dseq_c, dseq_d = _lstm_backward(models, s.lstm, [dyc.view(B, T, D), dyd.view(B, T, D)], g, side)
+            if LSTM_WGRAD_JOIN_EARLY:
+                side.join()
         else:
-            tf_side = _SideWork(dev, OVERLAP_TF_WGRAD)
-            dseq_d = _tf_backward(models[1], s.tf_d, dyd.view(B, T, D), g, tf_side)
-            dseq_c = _tf_backward(models[0], s.tf_c, dyc.view(B, T, D), g, tf_side)
-            tf_side.join()
+            dseq_d = _tf_backward(models[1], s.tf_d, dyd.view(B, T, D), g, side)
+            dseq_c = _tf_backward(models[0], s.tf_c, dyc.view(B, T, D), g, side)
 
-        if self._dp is not None:            # temporal heads + output heads are final: start their all-reduce
-            self._dp.reduce_range(self._seq_offset(), self._grad_flat.numel())
+        if self._dp is not None:            # temporal heads + output heads are final once the side stream has
+            # finished what is queued on it so far: the reducer's stream waits for it, the main stream does not
+            self._dp.reduce_range(self._seq_offset(), self._grad_flat.numel(), after=side.pending_stream())
 
         # detector branch (model.py:103-112)
         p_blk = self.block_dropout
@@ -783,8 +786,8 @@ class JDCNet(nn.Module):
         bn1 = self.detector_conv[1]
         d_dconv = ops.bn_act_pool_bwd(s.dconv, d_dact, s.bnd, g[bn1.weight], g[bn1.bias], pool=1, slope=slope)
         wdet = self.detector_conv[0].weight
-        side = _SideWork(dev, OVERLAP_CONV_WGRAD)
-        side.run(lambda: ops.gemm_tn(_flat2(d_dconv), s.concat.view(-1, 640), out=g[wdet].view(256, 640)), d_dconv)
+        side.run(lambda: ops.gemm_tn(_flat2(d_dconv), s.concat.view(-1, 640), out=g[wdet].view(256, 640)), d_dconv,
+                 on=OVERLAP_CONV_WGRAD)
         d_concat = ops.gemm_nt(_flat2(d_dconv), ops.transpose2d(wdet.view(256, 640))).view(B, T, 2, 640)
         # classifier branch joins at the pool_block output (channels 384..639 of the concat)
         ops.seq_to_nhwc(dseq_c, d_concat, 256, coff=384, accumulate=True)
@@ -802,7 +805,7 @@ class JDCNet(nn.Module):
         ops.maxpool_bwd_add(s.cb, d_concat, d_cb, 40, coff=0)
 
         cbk = self.conv_block
-        side.run(lambda: ops.conv3x3_wgrad(s.a0, d_cb, g[cbk[3].weight]), d_cb)
+        side.run(lambda: ops.conv3x3_wgrad(s.a0, d_cb, g[cbk[3].weight]), d_cb, on=OVERLAP_CONV_WGRAD)
         with ops.timer_tag("dgrad"):
             d_a0 = ops.conv3x3_fwd(d_cb, s.wd_cb)
         d_y0 = ops.bn_act_pool_bwd(s.y0, d_a0, s.bn0, g[cbk[1].weight], g[cbk[1].bias], pool=1, slope=slope, dx=d_a0)
