@@ -35,6 +35,7 @@ namespace {
 using namespace pe;
 
 constexpr int kMaxCells = 4;
+constexpr int kEPieces = 44;             // pieces the forward kernel's cell update is cut into (one per MFMA gap)
 constexpr int kRs = 132;                 // row stride of the 32 x 128 partial tiles (forward)
 constexpr int kRb = 36;                  // row stride of the 32 x 32 partial tiles (backward)
 constexpr unsigned kSpinLimit = 4000000; // a healthy wait is microseconds
@@ -103,6 +104,26 @@ __device__ __forceinline__ void tanh_n(const float (&x)[N], float (&y)[N]) {
   for (int k = 0; k < N; ++k) rc[k] = __builtin_amdgcn_rcpf(1.0f + e[k]);
 #pragma unroll
   for (int k = 0; k < N; ++k) y[k] = copysignf(ax[k] < 0.25f ? sm[k] : (1.0f - e[k]) * rc[k], x[k]);
+}
+
+// c_t = f * c_{t-1} + i * g with the contraction spelled out: the forward kernels evaluate it in several code
+// instances (halves, peeled steps, the piecewise epilogue) and hipcc is free to fuse either product into the add --
+// two instances that choose differently make a sample's result depend on its position in the batch.
+__device__ __forceinline__ float cell_c(float f, float c, float i, float g) { return fmaf(f, c, i * g); }
+
+// The stages of tanh_n / sigm_n one value at a time, for epilogues that are cut into pieces and issued between MFMAs
+// (same operations in the same order: bit-identical to the functions above).
+__device__ __forceinline__ float sig_exp(float x) { return __builtin_amdgcn_exp2f(-x * 1.44269504088896340736f); }
+__device__ __forceinline__ void tanh_s1(float x, float& ax, float& e) {
+  ax = fabsf(x);
+  e = __builtin_amdgcn_exp2f((-2.0f * ax) * 1.44269504088896340736f);
+}
+__device__ __forceinline__ float tanh_s2(float x, float ax) {
+  const float x2 = x * x;
+  return ax * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 62.0f / 2835.0f, -17.0f / 315.0f), 2.0f / 15.0f), -1.0f / 3.0f), 1.0f);
+}
+__device__ __forceinline__ float tanh_s4(float x, float ax, float e, float sm, float rc) {
+  return copysignf(ax < 0.25f ? sm : (1.0f - e) * rc, x);
 }
 
 // X3 variants: the recurrent products run as the exact three-term bf16 split (gemm_engine.h).  The W_hh
@@ -465,10 +486,10 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_kernel(const PFwdC
         const float4 gg = make_float4(tanh_fast(pre[2].x), tanh_fast(pre[2].y), tanh_fast(pre[2].z), tanh_fast(pre[2].w));
         const float4 go = make_float4(sigm(pre[3].x), sigm(pre[3].y), sigm(pre[3].z), sigm(pre[3].w));
         float4 cn;
-        cn.x = gf.x * creg[hf].x + gi.x * gg.x;
-        cn.y = gf.y * creg[hf].y + gi.y * gg.y;
-        cn.z = gf.z * creg[hf].z + gi.z * gg.z;
-        cn.w = gf.w * creg[hf].w + gi.w * gg.w;
+        cn.x = cell_c(gf.x, creg[hf].x, gi.x, gg.x);
+        cn.y = cell_c(gf.y, creg[hf].y, gi.y, gg.y);
+        cn.z = cell_c(gf.z, creg[hf].z, gi.z, gg.z);
+        cn.w = cell_c(gf.w, creg[hf].w, gi.w, gg.w);
         creg[hf] = cn;
         const float4 hv = make_float4(go.x * tanh_fast(cn.x), go.y * tanh_fast(cn.y), go.z * tanh_fast(cn.z),
                                       go.w * tanh_fast(cn.w));
@@ -639,10 +660,10 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_v2_kernel(const PF
     const float4 go = make_float4(sy[8], sy[9], sy[10], sy[11]);
     const float4 gg = make_float4(ty[0], ty[1], ty[2], ty[3]);
     float4 cn;
-    cn.x = gf.x * creg[hf].x + gi.x * gg.x;
-    cn.y = gf.y * creg[hf].y + gi.y * gg.y;
-    cn.z = gf.z * creg[hf].z + gi.z * gg.z;
-    cn.w = gf.w * creg[hf].w + gi.w * gg.w;
+    cn.x = cell_c(gf.x, creg[hf].x, gi.x, gg.x);
+    cn.y = cell_c(gf.y, creg[hf].y, gi.y, gg.y);
+    cn.z = cell_c(gf.z, creg[hf].z, gi.z, gg.z);
+    cn.w = cell_c(gf.w, creg[hf].w, gi.w, gg.w);
     creg[hf] = cn;
     const float cx[4] = {cn.x, cn.y, cn.z, cn.w};
     float cy[4];
@@ -741,9 +762,122 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_v2_kernel(const PF
       for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[g][q] = 0.f;
+      if constexpr (TERMS == 3 && NB1 * 24 >= kEPieces + NB1) {
+        // The pending epilogue E(i-1) in kEPieces pieces of a few instructions, one per MFMA gap (an MFMA holds the
+        // vector issue port for 8 of its 32 cycles): sched_barrier(0) after every MFMA pins the interleave, which
+        // hipcc does not produce by itself.  Operations and their order are those of cell_update.
+        float4 pp[2][4], pre[4], cnv, hv;
+        float se[12], sy[12], tax[4], te[4], tsm[4], trc[4], ty[4], cax[4], ce[4], csm[4], crc[4], cy[4];
+        unsigned e_el = 0u, gbo = 0u;
+        auto rd_red = [&](int g, float4 (&d)[4]) {
+          const float* rp = red + prow * kRs + g * 32 + 4 * pq;
+          d[0] = *reinterpret_cast<const float4*>(rp);
+          d[1] = *reinterpret_cast<const float4*>(rp + 32 * kRs);
+          d[2] = *reinterpret_cast<const float4*>(rp + 2 * 32 * kRs);
+          d[3] = *reinterpret_cast<const float4*>(rp + 3 * 32 * kRs);
+        };
+        auto sxv = [&](int k) -> float {               // sigmoid inputs: gates i, f, o
+          const float4& v = pre[k < 4 ? 0 : k < 8 ? 1 : 3];
+          return (k & 3) == 0 ? v.x : (k & 3) == 1 ? v.y : (k & 3) == 2 ? v.z : v.w;
+        };
+        auto comp = [&](const float4& v, int k) -> float { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; };
+        auto e_piece = [&](auto P) {
+          constexpr int p = decltype(P)::value;
+          if constexpr (p == 0) { e_el = item_elem(pstep, phf); rd_red(0, pp[0]); }
+          else if constexpr (p == 1) rd_red(1, pp[1]);
+          else if constexpr (p >= 2 && p <= 9) {       // pre[g]: halves xy / zw; the next gate's tiles two pieces ahead
+            constexpr int g = (p - 2) / 2, half = (p - 2) % 2;
+            const float4(&q)[4] = pp[g & 1];
+            if constexpr (half == 0) {
+              pre[g].x = ((q[0].x + q[1].x) + (q[2].x + q[3].x)) + xp_prev[g].x;
+              pre[g].y = ((q[0].y + q[1].y) + (q[2].y + q[3].y)) + xp_prev[g].y;
+            } else {
+              pre[g].z = ((q[0].z + q[1].z) + (q[2].z + q[3].z)) + xp_prev[g].z;
+              pre[g].w = ((q[0].w + q[1].w) + (q[2].w + q[3].w)) + xp_prev[g].w;
+              if constexpr (g + 2 < 4) rd_red(g + 2, pp[g & 1]);
+            }
+          } else if constexpr (p >= 10 && p <= 12) {   // sigmoid: exponentials
 #pragma unroll
-      for (int b = 0; b < NB1; ++b) mfma_block(b);
-      cell_update(pstep, phf, xp_prev);
+            for (int k = 4 * (p - 10); k < 4 * (p - 10) + 4; ++k) se[k] = sig_exp(sxv(k));
+          } else if constexpr (p == 13 || p == 14) {   // tanh(g gate): |x|, exponential
+#pragma unroll
+            for (int k = 2 * (p - 13); k < 2 * (p - 13) + 2; ++k) tanh_s1(comp(pre[2], k), tax[k], te[k]);
+          } else if constexpr (p == 15 || p == 16) {
+#pragma unroll
+            for (int k = 6 * (p - 15); k < 6 * (p - 15) + 6; ++k) se[k] = 1.0f + se[k];
+          } else if constexpr (p >= 17 && p <= 20) {
+#pragma unroll
+            for (int k = 3 * (p - 17); k < 3 * (p - 17) + 3; ++k) sy[k] = __builtin_amdgcn_rcpf(se[k]);
+          } else if constexpr (p >= 21 && p <= 24) {
+            tsm[p - 21] = tanh_s2(comp(pre[2], p - 21), tax[p - 21]);
+          } else if constexpr (p == 25 || p == 26) {
+#pragma unroll
+            for (int k = 2 * (p - 25); k < 2 * (p - 25) + 2; ++k) trc[k] = __builtin_amdgcn_rcpf(1.0f + te[k]);
+          } else if constexpr (p == 27 || p == 28) {
+#pragma unroll
+            for (int k = 2 * (p - 27); k < 2 * (p - 27) + 2; ++k)
+              ty[k] = tanh_s4(comp(pre[2], k), tax[k], te[k], tsm[k], trc[k]);
+          } else if constexpr (p == 29) {              // c_t = f * c_{t-1} + i * g
+            cnv.x = cell_c(sy[4], creg[phf].x, sy[0], ty[0]);
+            cnv.y = cell_c(sy[5], creg[phf].y, sy[1], ty[1]);
+            cnv.z = cell_c(sy[6], creg[phf].z, sy[2], ty[2]);
+            cnv.w = cell_c(sy[7], creg[phf].w, sy[3], ty[3]);
+            creg[phf] = cnv;
+          } else if constexpr (p == 30 || p == 31) {
+#pragma unroll
+            for (int k = 2 * (p - 30); k < 2 * (p - 30) + 2; ++k) tanh_s1(comp(cnv, k), cax[k], ce[k]);
+          } else if constexpr (p >= 32 && p <= 35) {
+            csm[p - 32] = tanh_s2(comp(cnv, p - 32), cax[p - 32]);
+          } else if constexpr (p == 36 || p == 37) {
+#pragma unroll
+            for (int k = 2 * (p - 36); k < 2 * (p - 36) + 2; ++k) crc[k] = __builtin_amdgcn_rcpf(1.0f + ce[k]);
+          } else if constexpr (p == 38 || p == 39) {
+#pragma unroll
+            for (int k = 2 * (p - 38); k < 2 * (p - 38) + 2; ++k) cy[k] = tanh_s4(comp(cnv, k), cax[k], ce[k], csm[k], crc[k]);
+          } else if constexpr (p == 40) {              // h first and write-through: it is what the group waits for
+            hv = make_float4(sy[8] * cy[0], sy[9] * cy[1], sy[10] * cy[2], sy[11] * cy[3]);
+            store_sc1(yrs, oob(e_el, (e_el * (unsigned)ldy + (unsigned)(j0 + 4 * pq)) * 4u), hv);
+          } else if constexpr (p == 41) {
+            gbo = oob(e_el, (e_el * (unsigned)(4 * H) + (unsigned)(j0 + 4 * pq)) * 4u);
+            store4(grs, gbo, 0u, make_float4(sy[0], sy[1], sy[2], sy[3]));
+            store4(grs, gbo, (unsigned)(H * 4), make_float4(sy[4], sy[5], sy[6], sy[7]));
+          } else if constexpr (p == 42) {
+            store4(grs, gbo, (unsigned)(2 * H * 4), make_float4(ty[0], ty[1], ty[2], ty[3]));
+            store4(grs, gbo, (unsigned)(3 * H * 4), make_float4(sy[8], sy[9], sy[10], sy[11]));
+          } else if constexpr (p == 43) {
+            store4(crs, oob(e_el, (e_el * (unsigned)H + (unsigned)(j0 + 4 * pq)) * 4u), 0u, cnv);
+          }
+        };
+        bf16x8 fa1[TERMS == 3 ? 3 : 1], wl1[4];
+        static_for<NB1 * 24>([&](auto Q) {
+          constexpr int q = decltype(Q)::value, b = q / 24, t6 = (q % 24) / 4, g = q % 4;
+          if constexpr (q % 24 == 0) {                 // operands of block b
+            const float4 a0 = *reinterpret_cast<const float4*>(asrc + 8 * b);
+            const float4 a1 = *reinterpret_cast<const float4*>(asrc + 8 * b + 4);
+            if constexpr (TERMS == 3) {
+              split8(a0, a1, fa1);
+#pragma unroll
+              for (int gg = 0; gg < 4; ++gg)
+                wl1[gg] = b < NBR ? bwlo[gg][b < NBR ? b : 0]
+                                  : __builtin_bit_cast(bf16x8, wlo_lds[(gg * (NB - NBR) + (b - NBR)) * 256 + tid]);
+            } else {
+              fa1[0] = round8(a0, a1);
+            }
+          }
+          if constexpr (TERMS == 3) {
+            acc[g] = mfma_bf16(kTb[t6] == 2 ? wl1[g] : bwhm[g][b][kTb[t6] == 2 ? 0 : kTb[t6]], fa1[kTa[t6]], acc[g]);
+          } else {
+            if constexpr (t6 == 0) acc[g] = mfma_bf16(bwhm[g][b][0], fa1[0], acc[g]);
+          }
+          constexpr int gap = q - (q / 24 + 1);        // gaps that carry no operand preparation, numbered from 0
+          if constexpr (q % 24 != 0 && gap < kEPieces) e_piece(std::integral_constant<int, gap>{});
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      } else {
+#pragma unroll
+        for (int b = 0; b < NB1; ++b) mfma_block(b);
+        cell_update(pstep, phf, xp_prev);
+      }
       PE_STAMP(0)                                                 // region 1: MFMAs + pending epilogue issued
       asm volatile("s_waitcnt vmcnt(5)" ::: "memory");            // the h store (issued first) has completed
       PE_STAMP(1)                                                 // ... its store drain
