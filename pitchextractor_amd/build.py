@@ -42,11 +42,18 @@ def _needs(target: Path, deps) -> bool:
 F16_SOURCES = ("gemm", "conv", "lstm", "lstm_persistent")
 
 
+# per-source flags.  lstm_persistent: the cell / gate updates are issued in the shadow of MFMAs, where hipcc's SLP
+# packing of adjacent scalar f32 operations into v_pk_* costs more issue time than it saves (MI355X guide, constants
+# table; measured: forward item 11.4 -> 10.7 k cycles)
+EXTRA_FLAGS = {"lstm_persistent": ["-fno-slp-vectorize"]}
+
+
 def _compile(job, verbose: bool) -> Path:
     src, f16 = job
     obj = OBJ_DIR / (src.stem + ("_f16" if f16 else "") + ".o")
-    if _needs(obj, [src] + _headers()):
-        cmd = [HIPCC, *CXXFLAGS, *(["-DPE_F16_BUILD"] if f16 else []), "-c", str(src), "-o", str(obj)]
+    if _needs(obj, [src] + _headers() + [Path(__file__)]):
+        cmd = [HIPCC, *CXXFLAGS, *EXTRA_FLAGS.get(src.stem, []), *(["-DPE_F16_BUILD"] if f16 else []), "-c", str(src),
+               "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
