@@ -45,7 +45,7 @@ F16_SOURCES = ("gemm", "conv", "lstm", "lstm_persistent")
 # per-source flags.  lstm_persistent: the cell / gate updates are issued in the shadow of MFMAs, where hipcc's SLP
 # packing of adjacent scalar f32 operations into v_pk_* costs more issue time than it saves (MI355X guide, constants
 # table; measured: forward item 11.4 -> 10.7 k cycles)
-EXTRA_FLAGS = {"lstm_persistent": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"lstm_persistent": ["-fno-slp-vectorize"]}      # (gemm.hip / lstm.hip: no difference, measured)
 
 
 def _compile(job, verbose: bool) -> Path:
