@@ -894,14 +894,52 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_v2_kernel(const PF
       PE_STAMP(4)                                                 // poll (wave 0)
       __syncthreads();                                            // #3: the poll result reaches every wave
       PE_STAMP(5)
-      if (want_fetch) fetch_rows(nstep, nhf);
-      mfma_block(NB - 1);
+      auto red_store = [&](int g, int q4) {
+        *reinterpret_cast<float4*>(red + (wv * 32 + r) * kRs + g * 32 + 8 * q4 + 4 * hh) =
+            make_float4(acc[g][4 * q4], acc[g][4 * q4 + 1], acc[g][4 * q4 + 2], acc[g][4 * q4 + 3]);
+      };
+      if constexpr (TERMS == 3 && NST <= 12) {
+        // last block gate by gate (each accumulator's six products keep their order): the h-row requests of the
+        // next item ride in the odd MFMA gaps, a finished gate's partial tile goes to LDS in the even gaps of the
+        // gates after it -- instead of a burst of requests before and a burst of stores after the 24 MFMAs
+        const int t_n = rev ? T - 1 - nstep : nstep, tp_n = rev ? t_n + 1 : t_n - 1;
+        const int brow_n = b0 + 32 * nhf + (tid >> 3);
+        const bool ok_n = want_fetch && brow_n < B;
+        const unsigned base_n = ok_n ? ((unsigned)(brow_n * T + tp_n) * (unsigned)ldy + (unsigned)(tid & 7) * 4u) * 4u
+                                     : 0xfffffff0u;
+        bf16x8 fa3[3], wl3[4];
+        {
+          constexpr int b = NB - 1;
+          const float4 a0 = *reinterpret_cast<const float4*>(asrc + 8 * b);
+          const float4 a1 = *reinterpret_cast<const float4*>(asrc + 8 * b + 4);
+          split8(a0, a1, fa3);
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
+          for (int gg = 0; gg < 4; ++gg)
+            wl3[gg] = b < NBR ? bwlo[gg][b < NBR ? b : 0]
+                              : __builtin_bit_cast(bf16x8, wlo_lds[(gg * (NB - NBR) + (b - NBR)) * 256 + tid]);
+        }
+        static_for<24>([&](auto Q) {
+          constexpr int q = decltype(Q)::value, g = q / 6, t6 = q % 6, b = NB - 1;
+          acc[g] = mfma_bf16(kTb[t6] == 2 ? wl3[g] : bwhm[g][b][kTb[t6] == 2 ? 0 : kTb[t6]], fa3[kTa[t6]], acc[g]);
+          if constexpr ((q & 1) == 1 && q / 2 < NST)
+            stage[q / 2] = load_sc1(yrs, base_n + (ok_n ? (unsigned)(q / 2) * 128u : 0u));
+          if constexpr ((q & 1) == 0 && q >= 6) {    // even gaps: gate (q - 6) / 8's tile, one float4 per gap
+            constexpr int e = (q - 6) / 2;           // 0 .. 8
+            if constexpr (e / 4 < g) red_store(e / 4, e % 4);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        // what the gaps did not cover: gate 2's last float4s and gate 3
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4)
-          *reinterpret_cast<float4*>(red + (wv * 32 + r) * kRs + g * 32 + 8 * q4 + 4 * hh) =
-              make_float4(acc[g][4 * q4], acc[g][4 * q4 + 1], acc[g][4 * q4 + 2], acc[g][4 * q4 + 3]);
+        for (int e = 9; e < 16; ++e) red_store(e / 4, e % 4);
+      } else {
+        if (want_fetch) fetch_rows(nstep, nhf);
+        mfma_block(NB - 1);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) red_store(g, q4);
+      }
       PE_STAMP(6)                                                 // last block + accumulators -> red
       __syncthreads();                                            // #0: As(i) is free, red(i) complete
       PE_STAMP(7)
