@@ -545,13 +545,16 @@ extern "C" int pe_bn_finalize_stats(const double* partials, int nparts, long n_p
   hipStream_t st = pe_stream(stream);
   const double* src = partials;
   int n = nparts;
-  if (nparts > 256) {                    // fold tens of thousands of tile partials to 128 with coalesced reads first
-    if (!workspace || workspace_bytes < (size_t)128 * 2 * C * sizeof(double)) return PE_E_WORKSPACE;
+  if (nparts > 512) {                    // fold tens of thousands of tile partials with coalesced reads first; the
+    // per-thread chain is a serial sum, so the fold goes as wide as the finalize below still reads cheaply (30 k parts
+    // over 128 blocks = 240 dependent adds per thread took 50 us per BatchNorm)
+    constexpr int kFold = 512;
+    if (!workspace || workspace_bytes < (size_t)kFold * 2 * C * sizeof(double)) return PE_E_WORKSPACE;
     double* folded = reinterpret_cast<double*>(workspace);
-    hipLaunchKernelGGL(bn_partials_fold_kernel, dim3(128), dim3(256), 0, st, partials, nparts, 2 * C, folded);
+    hipLaunchKernelGGL(bn_partials_fold_kernel, dim3(kFold), dim3(256), 0, st, partials, nparts, 2 * C, folded);
     PE_LAUNCH_CHECK();
     src = folded;
-    n = 128;
+    n = kFold;
   }
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(pe_cdiv(C, 4)), dim3(256), 0, st, src, n, n_pix, C, gamma, beta,
                      eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
