@@ -523,10 +523,12 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_kernel(const PFwdC
 //     barrier #0   every wave has finished reading As(i);  h rows of item i+1 -> As
 //
 // What overlaps is the MEMORY side of the epilogue (store drain, hand-off propagation, counter poll, h-row fetch):
-// all of it is in flight under MFMAs.  The gate arithmetic itself still issues after the first-half MFMAs of the
-// same wave (a wave issues in order; hipcc keeps the two instruction groups apart even under
-// sched_group_barrier -- s_memtime stamps, tools/stamp_lstm.py: 5.2 k of an item's 12.4 k cycles are that
-// region, 4.6 k are MFMA issue); interleaving it by hand is the open item.  The region is branch-free: step 0
+// all of it is in flight under MFMAs.  The gate arithmetic issues in order with the wave's MFMAs, and hipcc keeps
+// the two instruction groups apart even under sched_group_barrier (s_memtime stamps, tools/stamp_lstm.py: 5.2 k of
+// an item's 12.4 k cycles were that region, 2.3 k of them MFMA issue), so for H = 384 the update is cut BY HAND
+// into kEPieces pieces of a few instructions, one per MFMA gap of the first three blocks, and the last block runs
+// gate by gate with the next item's row requests and the finished gates' partial-tile stores in its gaps
+// (static_for + sched_barrier(0) after every MFMA; item 12.3 -> 10.0 k cycles).  The region is branch-free: step 0
 // (no recurrent input) is peeled, rows beyond B are handled by the buffer range check (loads return 0, stores
 // are dropped) instead of exec-masked branches.
 // The consumer of item i-1's h is item i+1 (same half, next step), so the hand-off has half an MFMA phase to
