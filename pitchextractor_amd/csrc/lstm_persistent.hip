@@ -1420,11 +1420,18 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_ks_kernel(const PB
     const unsigned xo = (((unsigned)(hf * 2 + (step & 1)) * NJ * NJ + (unsigned)jt) * TILE + (unsigned)r * 8u +
                          (unsigned)hh * 4u) * 4u;
     const unsigned tb = tile_base(pre_step, pre_hf);
-    float4 pend[4];                                   // finished tile of the previous column block
+    // two accumulator pairs (even / odd k groups), alternating per column block: the finished block's tile is summed
+    // and stored piecewise in the next block's MFMA gaps instead of in one burst between the blocks
+    f32x16 accs[2][2];
+    auto tile_piece = [&](const f32x16& a, const f32x16& b, int i) {
+      return make_float4(a[4 * i] + b[4 * i], a[4 * i + 1] + b[4 * i + 1], a[4 * i + 2] + b[4 * i + 2],
+                         a[4 * i + 3] + b[4 * i + 3]);
+    };
     unsigned seen = 0xffffffffu;
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
-      f32x16 acc, acc2;
+      f32x16& acc = accs[nb & 1][0];
+      f32x16& acc2 = accs[nb & 1][1];
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[q] = acc2[q] = 0.f;
       // operands of group kb + 1 are requested before group kb multiplies; the scheduling barriers keep hipcc from
@@ -1472,7 +1479,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_ks_kernel(const PB
           }
         }
         if (nb > 0 && kb < 4)
-          store_sc1(xrs, xo + ((unsigned)((wv * NBW + nb - 1) * NJ) * TILE + (unsigned)kb * 256u) * 4u, pend[kb]);
+          store_sc1(xrs, xo + ((unsigned)((wv * NBW + nb - 1) * NJ) * TILE + (unsigned)kb * 256u) * 4u,
+                    tile_piece(accs[(nb - 1) & 1][0], accs[(nb - 1) & 1][1], kb));
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (TERMS == 3) {
 #pragma unroll
@@ -1487,14 +1495,11 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_ks_kernel(const PB
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        pend[i] = make_float4(acc[4 * i] + acc2[4 * i], acc[4 * i + 1] + acc2[4 * i + 1], acc[4 * i + 2] + acc2[4 * i + 2],
-                              acc[4 * i + 3] + acc2[4 * i + 3]);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      store_sc1(xrs, xo + ((unsigned)((wv * NBW + NBW - 1) * NJ) * TILE + (unsigned)i * 256u) * 4u, pend[i]);
+      store_sc1(xrs, xo + ((unsigned)((wv * NBW + NBW - 1) * NJ) * TILE + (unsigned)i * 256u) * 4u,
+                tile_piece(accs[(NBW - 1) & 1][0], accs[(NBW - 1) & 1][1], i));
     PE_STAMP(2)                                                   // second half of the product, tile stores issued
   };
   // Hand-off of a product's tiles: each wave drains its own stores and arrives (no workgroup barrier: the next writer
