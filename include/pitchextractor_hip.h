@@ -153,8 +153,11 @@ int pe_conv3x3_wgrad_x3(const float* x, const float* dy, float* dw_oihw, int B, 
                         int Cout, float* workspace, size_t workspace_bytes, void* stream);
 int pe_conv3x3_wgrad_bf16(const float* x, const float* dy, float* dw_oihw, int B, int T, int F, int Cin,
                           int Cout, float* workspace, size_t workspace_bytes, void* stream);   /* mixed precision */
+/* first convolution (1 -> 64 channels).  bn_partials (nullable): [pe_conv3x3_c1_stat_parts()][2][64] doubles that
+ * receive per-workgroup sums / sums of squares of the output channels (input of pe_bn_finalize_stats). */
+int pe_conv3x3_c1_stat_parts(int B, int T, int F);
 int pe_conv3x3_c1_fwd(const float* x, long sb, long st, long sf, const float* w_oihw, float* y, int B,
-                      int T, int F, void* stream);
+                      int T, int F, double* bn_partials, void* stream);
 int pe_conv3x3_c1_wgrad(const float* x, long sb, long st, long sf, const float* dy, float* dw_oihw,
                         int B, int T, int F, float* workspace, size_t workspace_bytes, void* stream);
 

@@ -64,7 +64,8 @@ PROTOTYPES = {
     "pe_conv3x3_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
     "pe_conv3x3_wgrad_x3": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
     "pe_conv3x3_wgrad_bf16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
-    "pe_conv3x3_c1_fwd": (_i, [_p, _l, _l, _l, _p, _p, _i, _i, _i, _p]),
+    "pe_conv3x3_c1_stat_parts": (_i, [_i, _i, _i]),
+    "pe_conv3x3_c1_fwd": (_i, [_p, _l, _l, _l, _p, _p, _i, _i, _i, _p, _p]),
     "pe_conv3x3_c1_wgrad": (_i, [_p, _l, _l, _l, _p, _p, _i, _i, _i, _p, _z, _p]),
     "pe_bn_workspace_bytes": (_z, [_i]),
     "pe_bn_train_stats": (_i, [_p, _l, _i, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _z, _p]),

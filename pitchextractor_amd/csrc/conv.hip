@@ -828,9 +828,14 @@ int launch_wgrad(const float* x, const float* dy, float* dw, float* ws, int B, i
 // ---------------------------------------------------------------- first layer, Cin = 1 -> Cout = 64
 // x element (b, t, f) at x[b*sb + t*st + f*sf]; y channels-last [B][T][F][64].  16 threads per pixel,
 // 4 output channels each (one float4 store; 16 threads write one 256-B pixel row).
+// STATS: also reduce the BatchNorm batch statistics of the output (double sum / sum of squares per channel over this
+// workgroup's pixels -> one [2][64] row of bn_partials per workgroup), saving the 1 GB statistics pass over y
+template <bool STATS>
 __global__ __launch_bounds__(256) void conv3x3_c1_fwd_kernel(const float* __restrict__ x, long sb, long st_, long sf,
                                                              const float* __restrict__ w, float* __restrict__ y,
-                                                             int B, int T, int F) {
+                                                             double* __restrict__ bn_partials, int B, int T, int F) {
+  __shared__ double sred[STATS ? 2 * 16 * 64 : 1];
+  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
   const int q = threadIdx.x & 15;                 // channel quad
   float wr[4][9];
 #pragma unroll
@@ -855,8 +860,29 @@ __global__ __launch_bounds__(256) void conv3x3_c1_fwd_kernel(const float* __rest
 #pragma unroll
       for (int k = 0; k < 9; ++k) s = fmaf(in[k], wr[c][k], s);
       op[c] = s;
+      if constexpr (STATS) {
+        const double dv = (double)s;
+        s1[c] += dv;
+        s2[c] += dv * dv;
+      }
     }
     *reinterpret_cast<float4*>(y + p * 64 + q * 4) = o;
+  }
+  if constexpr (STATS) {                          // fold the 16 pixel groups of the workgroup (fixed order)
+    const int grp = threadIdx.x >> 4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      sred[grp * 64 + q * 4 + c] = s1[c];
+      sred[16 * 64 + grp * 64 + q * 4 + c] = s2[c];
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      const int which = threadIdx.x >> 6, ch = threadIdx.x & 63;
+      double t = 0.0;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) t += sred[which * 16 * 64 + g * 64 + ch];
+      bn_partials[((long)blockIdx.x * 2 + which) * 64 + ch] = t;
+    }
   }
 }
 
@@ -1107,13 +1133,24 @@ extern "C" int pe_conv3x3_wgrad_x3(const float* x, const float* dy, float* dw_oi
   return conv3x3_wgrad_impl<kSplit>(x, dy, dw_oihw, B, T, F, Cin, Cout, workspace, workspace_bytes, stream);
 }
 
-extern "C" int pe_conv3x3_c1_fwd(const float* x, long sb, long st, long sf, const float* w_oihw, float* y, int B,
-                                 int T, int F, void* stream) {
-  if (!x || !w_oihw || !y || B <= 0 || T <= 0 || F <= 0) return PE_E_ARG;
+static int c1_grid(int B, int T, int F) {
   const long P = (long)B * T * F;
-  const int grid = (int)((P + 15) / 16 < 8192 ? (P + 15) / 16 : 8192);
-  hipLaunchKernelGGL(conv3x3_c1_fwd_kernel, dim3(grid), dim3(256), 0, pe_stream(stream), x, sb, st, sf, w_oihw, y,
-                     B, T, F);
+  return (int)((P + 15) / 16 < 8192 ? (P + 15) / 16 : 8192);
+}
+
+// rows of the [rows][2][64] double partials pe_conv3x3_c1_fwd writes when bn_partials is given
+extern "C" int pe_conv3x3_c1_stat_parts(int B, int T, int F) { return (B > 0 && T > 0 && F > 0) ? c1_grid(B, T, F) : 0; }
+
+extern "C" int pe_conv3x3_c1_fwd(const float* x, long sb, long st, long sf, const float* w_oihw, float* y, int B,
+                                 int T, int F, double* bn_partials, void* stream) {
+  if (!x || !w_oihw || !y || B <= 0 || T <= 0 || F <= 0) return PE_E_ARG;
+  const int grid = c1_grid(B, T, F);
+  if (bn_partials)
+    hipLaunchKernelGGL(conv3x3_c1_fwd_kernel<true>, dim3(grid), dim3(256), 0, pe_stream(stream), x, sb, st, sf, w_oihw,
+                       y, bn_partials, B, T, F);
+  else
+    hipLaunchKernelGGL(conv3x3_c1_fwd_kernel<false>, dim3(grid), dim3(256), 0, pe_stream(stream), x, sb, st, sf,
+                       w_oihw, y, nullptr, B, T, F);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }

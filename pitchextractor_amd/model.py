@@ -694,8 +694,8 @@ class JDCNet(nn.Module):
         B, T, F = x_btf.shape
         s.x_btf = x_btf
         cbk = self.conv_block
-        s.y0 = ops.conv3x3_c1_fwd(x_btf, cbk[0].weight)
-        s.bn0 = _bn(cbk[1], s.y0, train)
+        s.y0, y0_stats = ops.conv3x3_c1_fwd(x_btf, cbk[0].weight, bn_stats=train)
+        s.bn0 = _bn(cbk[1], s.y0, train, y0_stats)
         s.a0 = ops.bn_act_pool_fwd(s.y0, s.bn0, pool=1, slope=slope)
         wf, s.wd_cb = ops.conv3x3_repack(cbk[3].weight, True, need_grad)
         s.cb, st_cb = ops.conv3x3_fwd(s.a0, wf, bn_stats=train)                      # convblock_out

@@ -349,15 +349,23 @@ def _btf_view(x):
     return x.shape, x.stride()
 
 
-def conv3x3_c1_fwd(x_btf, w, out=None):
+def conv3x3_c1_fwd(x_btf, w, out=None, bn_stats=None):
+    """First convolution.  bn_stats is None: returns out.  Otherwise returns (out, partials): with bn_stats true the
+    kernel also leaves the BatchNorm batch statistics of its output as [parts][2][64] float64 partial sums (else None),
+    as conv3x3_fwd does."""
     (B, T, F), (sb, st, sf) = _btf_view(x_btf)
     w = _dense(w, "w")
     _chk(w.shape == (64, 1, 3, 3), "first conv is 1 -> 64")
     if out is None:
         out = torch.empty((B, T, F, 64), dtype=torch.float32, device=x_btf.device)
     _chk(_dense(out, "out").shape == (B, T, F, 64), "conv3x3_c1_fwd: out shape")
-    _call("pe_conv3x3_c1_fwd", x_btf.data_ptr(), sb, st, sf, w.data_ptr(), out.data_ptr(), B, T, F, _s())
-    return out
+    parts = None
+    if bn_stats:
+        parts = torch.empty((_lib.load().pe_conv3x3_c1_stat_parts(B, T, F), 2, 64), dtype=torch.float64,
+                            device=x_btf.device)
+    _call("pe_conv3x3_c1_fwd", x_btf.data_ptr(), sb, st, sf, w.data_ptr(), out.data_ptr(), B, T, F, _lib.ptr(parts),
+          _s())
+    return out if bn_stats is None else (out, parts)
 
 
 def conv3x3_c1_wgrad(x_btf, dy, dw):

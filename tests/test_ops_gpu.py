@@ -287,6 +287,15 @@ def test_conv3x3_first_layer(hip_device):
     xv = mel.to(hip_device).transpose(-1, -2)[:, 0]          # strided (B,T,80)
     assert not xv.is_contiguous()
     close(nchw(ops.conv3x3_c1_fwd(xv, w.detach().float().to(hip_device))), y)
+    # with bn_stats the kernel also leaves the BatchNorm batch statistics of its output (no pass over y needed)
+    yd, parts = ops.conv3x3_c1_fwd(xv, w.detach().float().to(hip_device), bn_stats=True)
+    assert torch.equal(yd, ops.conv3x3_c1_fwd(xv, w.detach().float().to(hip_device))) and parts.dtype == torch.float64
+    gamma, beta = torch.ones(64, device=hip_device), torch.zeros(64, device=hip_device)
+    st_a = ops.bn_train_stats(yd, gamma, beta, None, None)
+    st_b = ops.bn_train_stats(yd, gamma, beta, None, None, partials=parts)
+    close(st_b.mean, st_a.mean.cpu(), 1e-6)
+    close(st_b.invstd, st_a.invstd.cpu(), 1e-6)
+    close(st_b.mean, y.mean(dim=(0, 2, 3)), 1e-5)
     dw = torch.empty(64, 1, 3, 3, device=hip_device)
     close(ops.conv3x3_c1_wgrad(xv, nhwc(dy.float()).to(hip_device), dw), w.grad)
 
