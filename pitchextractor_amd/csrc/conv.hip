@@ -842,31 +842,40 @@ __global__ __launch_bounds__(256) void conv3x3_c1_fwd_kernel(const float* __rest
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int k = 0; k < 9; ++k) wr[c][k] = w[(q * 4 + c) * 9 + k];
-  const long P = (long)B * T * F;
-  for (long p = (long)blockIdx.x * 16 + (threadIdx.x >> 4); p < P; p += (long)gridDim.x * 16) {
-    const int f = (int)(p % F), t = (int)((p / F) % T);
-    const long b = p / ((long)F * T);
-    float in[9];
+  // A 16-thread group takes RUNS of four consecutive f positions of one (b, t) row (F % 4 == 0, host): 18 input
+  // loads for four output pixels instead of 36 -- the kernel is bound by vector-memory instruction issue (ten per KB
+  // written before), not by HBM.
+  const int F4 = F >> 2, R = B * T * F4;          // < 2^31 (checked by the host): 32-bit index arithmetic
+  for (int run = blockIdx.x * 16 + (threadIdx.x >> 4); run < R; run += gridDim.x * 16) {
+    const int bt = run / F4, f0 = (run - bt * F4) * 4;
+    const long b = bt / T;
+    const int t = bt - (int)b * T;
+    float in[3][6];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const int tt = t + k / 3 - 1, ff = f + k % 3 - 1;
-      in[k] = (tt >= 0 && tt < T && ff >= 0 && ff < F) ? x[b * sb + tt * st_ + ff * sf] : 0.f;
-    }
-    float4 o;
-    float* op = reinterpret_cast<float*>(&o);
+    for (int dt = 0; dt < 3; ++dt)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      float s = 0.f;
-#pragma unroll
-      for (int k = 0; k < 9; ++k) s = fmaf(in[k], wr[c][k], s);
-      op[c] = s;
-      if constexpr (STATS) {
-        const double dv = (double)s;
-        s1[c] += dv;
-        s2[c] += dv * dv;
+      for (int df = 0; df < 6; ++df) {
+        const int tt = t + dt - 1, ff = f0 + df - 1;
+        in[dt][df] = (tt >= 0 && tt < T && ff >= 0 && ff < F) ? x[b * sb + tt * st_ + ff * sf] : 0.f;
       }
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+      float4 o;
+      float* op = reinterpret_cast<float*>(&o);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s = fmaf(in[k / 3][px + k % 3], wr[c][k], s);
+        op[c] = s;
+        if constexpr (STATS) {
+          const double dv = (double)s;
+          s1[c] += dv;
+          s2[c] += dv * dv;
+        }
+      }
+      *reinterpret_cast<float4*>(y + ((long)bt * F + f0 + px) * 64 + q * 4) = o;
     }
-    *reinterpret_cast<float4*>(y + p * 64 + q * 4) = o;
   }
   if constexpr (STATS) {                          // fold the 16 pixel groups of the workgroup (fixed order)
     const int grp = threadIdx.x >> 4;
@@ -1134,8 +1143,8 @@ extern "C" int pe_conv3x3_wgrad_x3(const float* x, const float* dy, float* dw_oi
 }
 
 static int c1_grid(int B, int T, int F) {
-  const long P = (long)B * T * F;
-  return (int)((P + 15) / 16 < 8192 ? (P + 15) / 16 : 8192);
+  const long R = (long)B * T * (F / 4);           // runs of four pixels, 16 per workgroup pass
+  return (int)((R + 15) / 16 < 8192 ? (R + 15) / 16 : 8192);
 }
 
 // rows of the [rows][2][64] double partials pe_conv3x3_c1_fwd writes when bn_partials is given
@@ -1144,6 +1153,7 @@ extern "C" int pe_conv3x3_c1_stat_parts(int B, int T, int F) { return (B > 0 && 
 extern "C" int pe_conv3x3_c1_fwd(const float* x, long sb, long st, long sf, const float* w_oihw, float* y, int B,
                                  int T, int F, double* bn_partials, void* stream) {
   if (!x || !w_oihw || !y || B <= 0 || T <= 0 || F <= 0) return PE_E_ARG;
+  if ((F & 3) || (long)B * T * F >= (1L << 31) - 64L * 8192) return PE_E_UNSUPPORTED;   // runs of 4, 32-bit indices
   const int grid = c1_grid(B, T, F);
   if (bn_partials)
     hipLaunchKernelGGL(conv3x3_c1_fwd_kernel<true>, dim3(grid), dim3(256), 0, pe_stream(stream), x, sb, st, sf, w_oihw,
