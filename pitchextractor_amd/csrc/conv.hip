@@ -908,19 +908,30 @@ __global__ __launch_bounds__(256) void conv3x3_c1_wgrad_kernel(const float* __re
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[c][k] = 0.f;
-  const int P = B * T * F;                                     // < 2^31 (checked by the host)
-  for (int p = blockIdx.x * 16 + grp; p < P; p += gridDim.x * 16) {
-    const int f = p % F, bt = p / F, t = bt % T, b = bt / T;
-    const float4 g = *reinterpret_cast<const float4*>(dy + (long)p * 64 + q * 4);
+  // runs of four consecutive f positions per group, as in the forward kernel: 18 + 4 loads for four pixels
+  const int F4 = F >> 2, R = B * T * F4;                       // F % 4 == 0, B*T*F < 2^31 (checked by the host)
+  for (int run = blockIdx.x * 16 + grp; run < R; run += gridDim.x * 16) {
+    const int bt = run / F4, f0 = (run - bt * F4) * 4, b = bt / T, t = bt - b * T;
     const float* xb = x + b * sb;
+    float in[3][6];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const int tt = t + k / 3 - 1, ff = f + k % 3 - 1;
-      const float xv = (tt >= 0 && tt < T && ff >= 0 && ff < F) ? xb[tt * st_ + ff * sf] : 0.f;
-      acc[0][k] = fmaf(g.x, xv, acc[0][k]);
-      acc[1][k] = fmaf(g.y, xv, acc[1][k]);
-      acc[2][k] = fmaf(g.z, xv, acc[2][k]);
-      acc[3][k] = fmaf(g.w, xv, acc[3][k]);
+    for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+      for (int df = 0; df < 6; ++df) {
+        const int tt = t + dt - 1, ff = f0 + df - 1;
+        in[dt][df] = (tt >= 0 && tt < T && ff >= 0 && ff < F) ? xb[tt * st_ + ff * sf] : 0.f;
+      }
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+      const float4 g = *reinterpret_cast<const float4*>(dy + ((long)bt * F + f0 + px) * 64 + q * 4);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const float xv = in[k / 3][px + k % 3];
+        acc[0][k] = fmaf(g.x, xv, acc[0][k]);
+        acc[1][k] = fmaf(g.y, xv, acc[1][k]);
+        acc[2][k] = fmaf(g.z, xv, acc[2][k]);
+        acc[3][k] = fmaf(g.w, xv, acc[3][k]);
+      }
     }
   }
 #pragma unroll
@@ -1168,7 +1179,7 @@ extern "C" int pe_conv3x3_c1_fwd(const float* x, long sb, long st, long sf, cons
 extern "C" int pe_conv3x3_c1_wgrad(const float* x, long sb, long st, long sf, const float* dy, float* dw_oihw,
                                    int B, int T, int F, float* workspace, size_t workspace_bytes, void* stream) {
   if (!x || !dy || !dw_oihw || B <= 0 || T <= 0 || F <= 0) return PE_E_ARG;
-  if ((long)B * T * F >= (1L << 31) - 65536) return PE_E_UNSUPPORTED;          // 32-bit pixel index in the kernel
+  if ((F & 3) || (long)B * T * F >= (1L << 31) - 65536) return PE_E_UNSUPPORTED;   // runs of 4, 32-bit pixel index
   if (!workspace || workspace_bytes < (size_t)kC1WgradBlocks * 576 * sizeof(float)) return PE_E_WORKSPACE;
   hipLaunchKernelGGL(conv3x3_c1_wgrad_kernel, dim3(kC1WgradBlocks), dim3(256), 0, pe_stream(stream), x, sb, st, sf,
                      dy, workspace, B, T, F);
