@@ -426,8 +426,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(KRowLoader<BM> al, KRowLoa
                                                       int k_per_split, int tiles_n, int accumulate) {
   __shared__ __attribute__((aligned(16))) float As[tn_lds_floats<MODE, BM>()];
   __shared__ __attribute__((aligned(16))) float Bs[tn_lds_floats<MODE, BN>()];
-  const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
-  const int kb = blockIdx.y * k_per_split;
+  // 1-D grid over (split, tile) with every XCD taking a CONTIGUOUS run of it: the tiles of one k-split then share
+  // an XCD's L2 for the operand rows they all read (PMC: 2.3 GB of fabric reads per dW_ih launch, 5x the operands,
+  // with the (tile, split) grid whose consecutive workgroups go round-robin over the eight XCDs)
+  const int tiles_mn = ((M + BM - 1) / BM) * tiles_n;
+  const int lin = xcd_remap(blockIdx.x, gridDim.x);                // grid = tiles_mn * splits workgroups
+  const int tile_id = lin % tiles_mn, split_id = lin / tiles_mn;
+  const int m0 = (tile_id / tiles_n) * BM, n0 = (tile_id % tiles_n) * BN;
+  const int kb = split_id * k_per_split;
   const int ke = min(K, kb + k_per_split);
   al.init(m0, kb);
   bl.init(n0, kb);
@@ -439,7 +445,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(KRowLoader<BM> al, KRowLoa
 #pragma unroll
       for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
   tn_mainloop_mode<MODE, BM, BN>(al, bl, kb, ke, As, Bs, acc);
-  float* dst = out + (long)blockIdx.y * split_stride;
+  float* dst = out + (long)split_id * split_stride;
   tn_for_each_acc<BM, BN>(acc, [&](int r, int c, float v) {
     const int row = m0 + r, col = n0 + c;
     if (row < M && col < N) {
@@ -488,7 +494,7 @@ int launch_tn(const float* A, long lda, const float* B, long ldb, float* C, long
   }
   const size_t need = (size_t)splits * M * N * sizeof(float);
   if (!ws || ws_bytes < need) return PE_E_WORKSPACE;
-  hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, MODE>), dim3(tm * tn, splits), dim3(256), 0, st, al, bl, ws, (long)N,
+  hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, MODE>), dim3(tm * tn * splits), dim3(256), 0, st, al, bl, ws, (long)N,
                      (long)M * N, M, N, K, kps, tn, 0);
   PE_LAUNCH_CHECK();
   const long total = (long)M * N;
