@@ -680,8 +680,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(const float* 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm = wv >> 1, wn = wv & 1, r = lane & 31, h = lane >> 5;
   const int g1 = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = (lane & 3) * 4;
-  const int m0 = (blockIdx.x / tiles_n) * 64, n0 = (blockIdx.x % tiles_n) * 64;
-  const int kb = blockIdx.y * k_per_split;
+  // 1-D grid over (split, tile), XCD-contiguous (as gemm_tn_kernel): the tiles of a pixel range share an XCD's L2
+  const int tiles_mn = (Cout / 64) * tiles_n;
+  const int lin = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_id = lin % tiles_mn, split_id = lin / tiles_mn;
+  const int m0 = (tile_id / tiles_n) * 64, n0 = (tile_id % tiles_n) * 64;
+  const int kb = split_id * k_per_split;
   const int ke = min(P, kb + k_per_split);
 
   f32x16 acc[9];
@@ -775,7 +779,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(const float* 
   }
 #pragma unroll
   for (int tp = 0; tp < 9; ++tp) {
-    float* dst = ws + ((long)blockIdx.y * 9 + tp) * Cout * Cin;
+    float* dst = ws + ((long)split_id * 9 + tp) * Cout * Cin;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int co = m0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
@@ -1123,7 +1127,7 @@ static int conv3x3_wgrad_impl(const float* x, const float* dy, float* dw_oihw, i
       hipLaunchKernelGGL(conv3x3_wgrad9_x3_kernel<1>, dim3((Cout / 64) * tn * splits), dim3(256), 0, st, dy, x,
                          workspace, T, F, Cin, Cout, P, kps, tn);
     else
-      hipLaunchKernelGGL(conv3x3_wgrad9_kernel<0>, dim3((Cout / 64) * tn, splits), dim3(256), 0, st, dy, x,
+      hipLaunchKernelGGL(conv3x3_wgrad9_kernel<0>, dim3((Cout / 64) * tn * splits), dim3(256), 0, st, dy, x,
                          workspace, T, F, Cin, Cout, P, kps, tn);
     PE_LAUNCH_CHECK();
     const int n = 9 * Cout * Cin;

@@ -193,7 +193,8 @@ def test_transpose2d(hip_device):
 @pytest.mark.parametrize("B,T,Fq,Ci,Co", [(2, 12, 10, 64, 64), (1, 9, 7, 64, 128), (2, 5, 20, 128, 192),
                                           (1, 6, 10, 192, 256), (1, 4, 5, 256, 256), (3, 16, 40, 128, 128),
                                           (1, 3, 80, 64, 64), (1, 5, 45, 64, 128), (1, 4, 50, 64, 128),
-                                          (2, 1, 33, 96, 160)])
+                                          (2, 1, 33, 96, 160),
+                                          (2, 64, 40, 64, 64), (2, 48, 40, 128, 128)])   # > 2048 pixels: split-K slabs
 @pytest.mark.parametrize("fp32_mode", ["native", "x3"])
 def test_conv3x3_fwd_dgrad_wgrad(hip_device, B, T, Fq, Ci, Co, fp32_mode, monkeypatch):
     monkeypatch.setattr(ops, "FP32_MATMUL", fp32_mode)
