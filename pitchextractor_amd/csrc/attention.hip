@@ -21,6 +21,14 @@
 // deterministic, no atomics, no cross-workgroup reduction.
 #include "common.h"
 
+// XCD-aware block order (workgroups b and b + 8 share an XCD and its L2): give every XCD a contiguous run of
+// logical blocks, so the workgroups that read the same K / V rows hit the same L2.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_run(int bid, int n) {
+  const int q = n >> 3, r = n & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 namespace {
 
 constexpr int kDh = 64;
@@ -87,7 +95,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs a) {
   float* Vs = Ks + HR * kStr;            // [HR][kStr]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
-  const int bh = blockIdx.x / 3, part = blockIdx.x - bh * 3, b = bh / a.H, h = bh - b * a.H;
+  const int blk = xcd_run(blockIdx.x, gridDim.x);              // the three parts of a head share an XCD's L2
+  const int bh = blk / 3, part = blk - bh * 3, b = bh / a.H, h = bh - b * a.H;
   const float* base = a.qkv + (long)b * T * a.ld_qkv + h * kDh;
   const int q0 = (part * 4 + wv) * 16;
   const long row = (long)bh * T + q0 + j;
@@ -216,7 +225,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kv_kernel(const AttnArgs a) {
   float* dl_s = lse_s + T;               // [T] delta
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
-  const int bh = blockIdx.x / 3, part = blockIdx.x - bh * 3, b = bh / a.H, h = bh - b * a.H;
+  const int blk = xcd_run(blockIdx.x, gridDim.x);              // the three parts of a head share an XCD's L2
+  const int bh = blk / 3, part = blk - bh * 3, b = bh / a.H, h = bh - b * a.H;
   const float* base = a.qkv + (long)b * T * a.ld_qkv + h * kDh;
   const float* dob = a.d_o + (long)b * T * a.ld_o + h * kDh;
   const int k0 = (part * 4 + wv) * 16;
@@ -301,7 +311,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const AttnArgs a) {
   float* Vs = Ks + HR * kStr;            // [HR][kStr]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
-  const int bh = blockIdx.x / 3, part = blockIdx.x - bh * 3, b = bh / a.H, h = bh - b * a.H;
+  const int blk = xcd_run(blockIdx.x, gridDim.x);              // the three parts of a head share an XCD's L2
+  const int bh = blk / 3, part = blk - bh * 3, b = bh / a.H, h = bh - b * a.H;
   const float* base = a.qkv + (long)b * T * a.ld_qkv + h * kDh;
   const float* dob = a.d_o + (long)b * T * a.ld_o + h * kDh;
   const int q0 = (part * 4 + wv) * 16;
