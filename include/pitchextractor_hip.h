@@ -351,6 +351,26 @@ int pe_layernorm_bwd(const float* dy, const float* z, const float* mean, const f
                      size_t workspace_bytes, void* stream);
 int pe_gelu_fwd(const float* x, float* y, long n, void* stream);
 int pe_gelu_bwd(const float* x, const float* dy, float* dx, long n, void* stream);
+/* Dropout folded into the neighbouring pass of an encoder layer (nn.TransformerEncoderLayer, model.py:231-239:
+ * x = norm1(x + dropout1(sa)); x = norm2(x + dropout2(linear2(dropout(gelu(linear1(x))))))).  Element <-> Philox
+ * counter mapping, keep rule and 1/(1-p) scaling are pe_dropout_fwd's on a dense tensor, so the results equal the
+ * separate passes bit for bit; mask_in replays given bytes, mask_out (optional) records them; 0 < p < 1.
+ * pe_layernorm_dropout_fwd: z = a + dropout(b) (+ pe); y = LN(z).
+ * pe_layernorm_bwd_fused: dy2 (optional) is added to dy first (the residual branch's gradient); dz_drop (with
+ *   drop_mask, both or neither) additionally receives dropout_bwd(dz).
+ * pe_gelu_dropout_fwd: y = dropout(gelu(x)); pe_gelu_dropout_bwd: dx = dropout_bwd(dy) * gelu'(x). */
+int pe_layernorm_dropout_fwd(const float* a, const float* b, const float* pe, int period, const float* gamma,
+                             const float* beta, float eps, float* z_out, float* y, float* mean, float* rstd,
+                             long rows, int D, const unsigned char* mask_in, unsigned char* mask_out, float p,
+                             unsigned long long seed, unsigned long long offset, void* stream);
+int pe_layernorm_bwd_fused(const float* dy, const float* dy2, const float* z, const float* mean, const float* rstd,
+                           const float* gamma, float* dz, const unsigned char* drop_mask, float p, float* dz_drop,
+                           float* dgamma, float* dbeta, long rows, int D, void* workspace, size_t workspace_bytes,
+                           void* stream);
+int pe_gelu_dropout_fwd(const float* x, float* y, long n, const unsigned char* mask_in, unsigned char* mask_out,
+                        float p, unsigned long long seed, unsigned long long offset, void* stream);
+int pe_gelu_dropout_bwd(const float* x, const float* dy, const unsigned char* mask, float p, float* dx, long n,
+                        void* stream);
 
 /* ---- resampler (meldataset.py:621-627 -> torchaudio.functional.resample defaults) ----
  * sinc_interp_hann, lowpass_filter_width 6, rolloff 0.99; y has ceil(new * n_in / orig) samples. */

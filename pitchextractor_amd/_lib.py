@@ -112,6 +112,10 @@ PROTOTYPES = {
     "pe_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _l, _i, _p, _z, _p]),
     "pe_gelu_fwd": (_i, [_p, _p, _l, _p]),
     "pe_gelu_bwd": (_i, [_p, _p, _p, _l, _p]),
+    "pe_layernorm_dropout_fwd": (_i, [_p, _p, _p, _i, _p, _p, _f, _p, _p, _p, _p, _l, _i, _p, _p, _f, _u64, _u64, _p]),
+    "pe_layernorm_bwd_fused": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _l, _i, _p, _z, _p]),
+    "pe_gelu_dropout_fwd": (_i, [_p, _p, _l, _p, _p, _f, _u64, _u64, _p]),
+    "pe_gelu_dropout_bwd": (_i, [_p, _p, _p, _f, _p, _l, _p]),
     "pe_resample_plan_create": (_i, [C.POINTER(_p), _i, _i, _i, _f]),
     "pe_resample_plan_destroy": (_i, [_p]),
     "pe_resample_out_len": (_l, [_p, _l]),

@@ -143,15 +143,45 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
   }
 }
 
+// ------------------------------------------------------------------ dropout folded into a neighbouring pass
+// Same element <-> Philox counter mapping, keep rule and scaling as dropout_fwd_kernel (elementwise.hip) on a dense
+// [rows][cols] tensor: quad q = (row * cols + col) / 4 draws philox4(seed, offset + q); keep = u >= p; kept values
+// are multiplied by 1 / (1 - p).  mask_in replays given bytes; mask_out (optional) records them for the backward.
+struct DropArgs {
+  const uint8_t* mask_in;
+  uint8_t* mask_out;
+  float p, scale;
+  uint64_t seed, offset;
+};
+
+__device__ __forceinline__ float4 drop_quad(const DropArgs& d, long quad, const float4& v) {
+  // no mul+add contraction: the fused and the plain instances must round alike (results are compared bit for bit)
+#pragma clang fp contract(off)
+  uint8_t keep[4];
+  if (d.mask_in) {
+    const uchar4 m = *reinterpret_cast<const uchar4*>(d.mask_in + quad * 4);
+    keep[0] = m.x; keep[1] = m.y; keep[2] = m.z; keep[3] = m.w;
+  } else {
+    uint32_t rnd[4];
+    philox4(d.seed, d.offset + (uint64_t)quad, rnd);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) keep[k] = ((float)(rnd[k] >> 8) * (1.0f / 16777216.0f)) >= d.p ? 1 : 0;
+  }
+  if (d.mask_out) *reinterpret_cast<uchar4*>(d.mask_out + quad * 4) = make_uchar4(keep[0], keep[1], keep[2], keep[3]);
+  return make_float4(keep[0] ? v.x * d.scale : 0.f, keep[1] ? v.y * d.scale : 0.f, keep[2] ? v.z * d.scale : 0.f,
+                     keep[3] ? v.w * d.scale : 0.f);
+}
+
 // ------------------------------------------------------------------ LayerNorm (one wave per row, D = 256 * NV)
-template <int NV>
+template <int NV, bool DROP>      // DROP: z = a + dropout(b) (+ pe), the post-norm residual of an encoder layer
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                             const float* __restrict__ pe, int period,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps,
                                                             float* __restrict__ z_out, float* __restrict__ y,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                            long rows) {
+                                                            long rows, DropArgs drop) {
+#pragma clang fp contract(off)
   constexpr int D = 256 * NV;
   const int lane = threadIdx.x & 63;
   const long row = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
@@ -163,7 +193,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     const int c = lane * 4 + 256 * i;
     v[i] = *reinterpret_cast<const float4*>(a + row * D + c);
     if (b) {
-      const float4 t = *reinterpret_cast<const float4*>(b + row * D + c);
+      float4 t = *reinterpret_cast<const float4*>(b + row * D + c);
+      if constexpr (DROP) t = drop_quad(drop, (row * D + c) >> 2, t);
       v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w;
     }
     if (pe) {
@@ -202,12 +233,18 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 
 // dz = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  per-wave partial sums of
 // dy * xhat (dgamma) and dy (dbeta) go to partial[wave][2][D]
-template <int NV>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z,
+// FUSED: dy = dy + dy2 (the residual branch's gradient, when dy2 != NULL) and a second output dz_drop = dropout_bwd(dz)
+// (when drop_mask != NULL): the two passes an encoder layer's backward otherwise runs around this one
+template <int NV, bool FUSED>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ dy2,
+                                                            const float* __restrict__ z,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, float* __restrict__ dz,
+                                                            const uint8_t* __restrict__ drop_mask, float drop_scale,
+                                                            float* __restrict__ dz_drop,
                                                             float* __restrict__ partial, long rows) {
+#pragma clang fp contract(off)
   constexpr int D = 256 * NV;
   const int lane = threadIdx.x & 63;
   const long wave = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
@@ -222,7 +259,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = lane * 4 + 256 * i;
-      const float4 d = *reinterpret_cast<const float4*>(dy + row * D + c);
+      float4 d = *reinterpret_cast<const float4*>(dy + row * D + c);
+      if constexpr (FUSED) {
+        if (dy2) {
+          const float4 e = *reinterpret_cast<const float4*>(dy2 + row * D + c);
+          d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w;
+        }
+      }
       const float4 zz = *reinterpret_cast<const float4*>(z + row * D + c);
       const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
       xh[i] = make_float4((zz.x - mu) * rs, (zz.y - mu) * rs, (zz.z - mu) * rs, (zz.w - mu) * rs);
@@ -247,6 +290,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       o.z = rs * (g[i].z - m1 - xh[i].z * m2);
       o.w = rs * (g[i].w - m1 - xh[i].w * m2);
       *reinterpret_cast<float4*>(dz + row * D + c) = o;
+      if constexpr (FUSED) {
+        if (drop_mask) {
+          const uchar4 m = *reinterpret_cast<const uchar4*>(drop_mask + row * D + c);
+          *reinterpret_cast<float4*>(dz_drop + row * D + c) =
+              make_float4(m.x ? o.x * drop_scale : 0.f, m.y ? o.y * drop_scale : 0.f, m.z ? o.z * drop_scale : 0.f,
+                          m.w ? o.w * drop_scale : 0.f);
+        }
+      }
     }
   }
 #pragma unroll
@@ -274,6 +325,7 @@ constexpr int kLnBwdBlocks = 256;     // -> 1024 waves of partials
 
 // ------------------------------------------------------------------ exact (erf) GELU
 __global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n4) {
+#pragma clang fp contract(off)
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
     const float4 v = reinterpret_cast<const float4*>(x)[i];
     float4 o;
@@ -286,14 +338,48 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__
 }
 
 __device__ __forceinline__ float gelu_grad(float x) {
+#pragma clang fp contract(off)
   return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
 }
 
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                        float* __restrict__ dx, long n4) {
+#pragma clang fp contract(off)
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
     const float4 v = reinterpret_cast<const float4*>(x)[i];
     const float4 d = reinterpret_cast<const float4*>(dy)[i];
+    reinterpret_cast<float4*>(dx)[i] =
+        make_float4(d.x * gelu_grad(v.x), d.y * gelu_grad(v.y), d.z * gelu_grad(v.z), d.w * gelu_grad(v.w));
+  }
+}
+
+// a = dropout(gelu(h)) in one pass (linear1 -> activation -> dropout of an encoder layer), and its backward
+// dh = dropout_bwd(da) * gelu'(h); dense [rows][cols], the quad index is the flat float4 index
+__global__ __launch_bounds__(256) void gelu_dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                               long n4, DropArgs drop) {
+#pragma clang fp contract(off)
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    float4 o;
+    o.x = 0.5f * v.x * (1.0f + erff(v.x * 0.70710678118654752f));
+    o.y = 0.5f * v.y * (1.0f + erff(v.y * 0.70710678118654752f));
+    o.z = 0.5f * v.z * (1.0f + erff(v.z * 0.70710678118654752f));
+    o.w = 0.5f * v.w * (1.0f + erff(v.w * 0.70710678118654752f));
+    reinterpret_cast<float4*>(y)[i] = drop_quad(drop, i, o);
+  }
+}
+
+__global__ __launch_bounds__(256) void gelu_dropout_bwd_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ dy,
+                                                               const uint8_t* __restrict__ mask, float scale,
+                                                               float* __restrict__ dx, long n4) {
+#pragma clang fp contract(off)
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    float4 d = reinterpret_cast<const float4*>(dy)[i];
+    const uchar4 m = reinterpret_cast<const uchar4*>(mask)[i];
+    d = make_float4(m.x ? d.x * scale : 0.f, m.y ? d.y * scale : 0.f, m.z ? d.z * scale : 0.f,
+                    m.w ? d.w * scale : 0.f);
     reinterpret_cast<float4*>(dx)[i] =
         make_float4(d.x * gelu_grad(v.x), d.y * gelu_grad(v.y), d.z * gelu_grad(v.z), d.w * gelu_grad(v.w));
   }
@@ -350,20 +436,58 @@ extern "C" int pe_softmax_bwd(const float* p, float* dp, long rows, int L, float
   return PE_OK;
 }
 
+namespace {
+template <bool DROP>
+int launch_layernorm_fwd(const float* a, const float* b, const float* pe, int period, const float* gamma,
+                         const float* beta, float eps, float* z_out, float* y, float* mean, float* rstd, long rows,
+                         int D, const DropArgs& drop, hipStream_t st) {
+  dim3 grid(pe_cdiv(rows, 4));
+  if (D == 256) hipLaunchKernelGGL((layernorm_fwd_kernel<1, DROP>), grid, dim3(256), 0, st, a, b, pe, period, gamma, beta, eps, z_out, y, mean, rstd, rows, drop);
+  else if (D == 512) hipLaunchKernelGGL((layernorm_fwd_kernel<2, DROP>), grid, dim3(256), 0, st, a, b, pe, period, gamma, beta, eps, z_out, y, mean, rstd, rows, drop);
+  else if (D == 768) hipLaunchKernelGGL((layernorm_fwd_kernel<3, DROP>), grid, dim3(256), 0, st, a, b, pe, period, gamma, beta, eps, z_out, y, mean, rstd, rows, drop);
+  else if (D == 1024) hipLaunchKernelGGL((layernorm_fwd_kernel<4, DROP>), grid, dim3(256), 0, st, a, b, pe, period, gamma, beta, eps, z_out, y, mean, rstd, rows, drop);
+  else return PE_E_UNSUPPORTED;
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+
+template <bool FUSED>
+int launch_layernorm_bwd(const float* dy, const float* dy2, const float* z, const float* mean, const float* rstd,
+                         const float* gamma, float* dz, const uint8_t* mask, float scale, float* dz_drop,
+                         float* dgamma, float* dbeta, long rows, int D, float* partial, hipStream_t st) {
+  dim3 grid(kLnBwdBlocks);
+  if (D == 256) hipLaunchKernelGGL((layernorm_bwd_kernel<1, FUSED>), grid, dim3(256), 0, st, dy, dy2, z, mean, rstd, gamma, dz, mask, scale, dz_drop, partial, rows);
+  else if (D == 512) hipLaunchKernelGGL((layernorm_bwd_kernel<2, FUSED>), grid, dim3(256), 0, st, dy, dy2, z, mean, rstd, gamma, dz, mask, scale, dz_drop, partial, rows);
+  else if (D == 768) hipLaunchKernelGGL((layernorm_bwd_kernel<3, FUSED>), grid, dim3(256), 0, st, dy, dy2, z, mean, rstd, gamma, dz, mask, scale, dz_drop, partial, rows);
+  else if (D == 1024) hipLaunchKernelGGL((layernorm_bwd_kernel<4, FUSED>), grid, dim3(256), 0, st, dy, dy2, z, mean, rstd, gamma, dz, mask, scale, dz_drop, partial, rows);
+  else return PE_E_UNSUPPORTED;
+  PE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(layernorm_bwd_final_kernel, dim3(pe_cdiv(2 * D, 4)), dim3(256), 0, st, partial, kLnBwdBlocks * 4, D,
+                     dgamma, dbeta);
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+}  // namespace
+
 extern "C" int pe_layernorm_fwd(const float* a, const float* b, const float* pe, int period, const float* gamma,
                                 const float* beta, float eps, float* z_out, float* y, float* mean, float* rstd,
                                 long rows, int D, void* stream) {
   if (!a || !gamma || !beta || !y || !mean || !rstd || rows <= 0) return PE_E_ARG;
   if (pe && period <= 0) return PE_E_ARG;
-  dim3 grid(pe_cdiv(rows, 4));
-  hipStream_t st = pe_stream(stream);
-  if (D == 256) hipLaunchKernelGGL(layernorm_fwd_kernel<1>, grid, dim3(256), 0, st, a, b, pe, period, gamma, beta, eps, z_out, y, mean, rstd, rows);
-  else if (D == 512) hipLaunchKernelGGL(layernorm_fwd_kernel<2>, grid, dim3(256), 0, st, a, b, pe, period, gamma, beta, eps, z_out, y, mean, rstd, rows);
-  else if (D == 768) hipLaunchKernelGGL(layernorm_fwd_kernel<3>, grid, dim3(256), 0, st, a, b, pe, period, gamma, beta, eps, z_out, y, mean, rstd, rows);
-  else if (D == 1024) hipLaunchKernelGGL(layernorm_fwd_kernel<4>, grid, dim3(256), 0, st, a, b, pe, period, gamma, beta, eps, z_out, y, mean, rstd, rows);
-  else return PE_E_UNSUPPORTED;
-  PE_LAUNCH_CHECK();
-  return PE_OK;
+  return launch_layernorm_fwd<false>(a, b, pe, period, gamma, beta, eps, z_out, y, mean, rstd, rows, D, DropArgs{},
+                                     pe_stream(stream));
+}
+
+extern "C" int pe_layernorm_dropout_fwd(const float* a, const float* b, const float* pe, int period,
+                                        const float* gamma, const float* beta, float eps, float* z_out, float* y,
+                                        float* mean, float* rstd, long rows, int D, const unsigned char* mask_in,
+                                        unsigned char* mask_out, float p, unsigned long long seed,
+                                        unsigned long long offset, void* stream) {
+  if (!a || !b || !gamma || !beta || !y || !mean || !rstd || rows <= 0 || p <= 0.f || p >= 1.f) return PE_E_ARG;
+  if (pe && period <= 0) return PE_E_ARG;
+  const DropArgs drop{mask_in, mask_out, p, 1.0f / (1.0f - p), (uint64_t)seed, (uint64_t)offset};
+  return launch_layernorm_fwd<true>(a, b, pe, period, gamma, beta, eps, z_out, y, mean, rstd, rows, D, drop,
+                                    pe_stream(stream));
 }
 
 extern "C" size_t pe_layernorm_bwd_workspace_bytes(int D) { return (size_t)kLnBwdBlocks * 4 * 2 * D * sizeof(float); }
@@ -373,19 +497,22 @@ extern "C" int pe_layernorm_bwd(const float* dy, const float* z, const float* me
                                 void* workspace, size_t workspace_bytes, void* stream) {
   if (!dy || !z || !mean || !rstd || !gamma || !dz || !dgamma || !dbeta || rows <= 0) return PE_E_ARG;
   if (!workspace || workspace_bytes < pe_layernorm_bwd_workspace_bytes(D)) return PE_E_WORKSPACE;
-  float* partial = reinterpret_cast<float*>(workspace);
-  hipStream_t st = pe_stream(stream);
-  dim3 grid(kLnBwdBlocks);
-  if (D == 256) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, dim3(256), 0, st, dy, z, mean, rstd, gamma, dz, partial, rows);
-  else if (D == 512) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, dim3(256), 0, st, dy, z, mean, rstd, gamma, dz, partial, rows);
-  else if (D == 768) hipLaunchKernelGGL(layernorm_bwd_kernel<3>, grid, dim3(256), 0, st, dy, z, mean, rstd, gamma, dz, partial, rows);
-  else if (D == 1024) hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, dim3(256), 0, st, dy, z, mean, rstd, gamma, dz, partial, rows);
-  else return PE_E_UNSUPPORTED;
-  PE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(layernorm_bwd_final_kernel, dim3(pe_cdiv(2 * D, 4)), dim3(256), 0, st, partial, kLnBwdBlocks * 4, D,
-                     dgamma, dbeta);
-  PE_LAUNCH_CHECK();
-  return PE_OK;
+  return launch_layernorm_bwd<false>(dy, nullptr, z, mean, rstd, gamma, dz, nullptr, 1.f, nullptr, dgamma, dbeta, rows,
+                                     D, reinterpret_cast<float*>(workspace), pe_stream(stream));
+}
+
+extern "C" int pe_layernorm_bwd_fused(const float* dy, const float* dy2, const float* z, const float* mean,
+                                      const float* rstd, const float* gamma, float* dz,
+                                      const unsigned char* drop_mask, float p, float* dz_drop, float* dgamma,
+                                      float* dbeta, long rows, int D, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+  if (!dy || !z || !mean || !rstd || !gamma || !dz || !dgamma || !dbeta || rows <= 0) return PE_E_ARG;
+  if ((drop_mask != nullptr) != (dz_drop != nullptr)) return PE_E_ARG;
+  if (drop_mask && (p <= 0.f || p >= 1.f)) return PE_E_ARG;
+  if (!workspace || workspace_bytes < pe_layernorm_bwd_workspace_bytes(D)) return PE_E_WORKSPACE;
+  return launch_layernorm_bwd<true>(dy, dy2, z, mean, rstd, gamma, dz, drop_mask, drop_mask ? 1.0f / (1.0f - p) : 1.f,
+                                    dz_drop, dgamma, dbeta, rows, D, reinterpret_cast<float*>(workspace),
+                                    pe_stream(stream));
 }
 
 extern "C" int pe_gelu_fwd(const float* x, float* y, long n, void* stream) {
@@ -400,6 +527,28 @@ extern "C" int pe_gelu_bwd(const float* x, const float* dy, float* dx, long n, v
   if (!x || !dy || !dx || n <= 0) return PE_E_ARG;
   if (n & 3) return PE_E_UNSUPPORTED;
   hipLaunchKernelGGL(gelu_bwd_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, pe_stream(stream), x, dy, dx, n / 4);
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+
+extern "C" int pe_gelu_dropout_fwd(const float* x, float* y, long n, const unsigned char* mask_in,
+                                   unsigned char* mask_out, float p, unsigned long long seed,
+                                   unsigned long long offset, void* stream) {
+  if (!x || !y || n <= 0 || p <= 0.f || p >= 1.f) return PE_E_ARG;
+  if (n & 3) return PE_E_UNSUPPORTED;
+  const DropArgs drop{mask_in, mask_out, p, 1.0f / (1.0f - p), (uint64_t)seed, (uint64_t)offset};
+  hipLaunchKernelGGL(gelu_dropout_fwd_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, pe_stream(stream), x, y, n / 4,
+                     drop);
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+
+extern "C" int pe_gelu_dropout_bwd(const float* x, const float* dy, const unsigned char* mask, float p, float* dx,
+                                   long n, void* stream) {
+  if (!x || !dy || !mask || !dx || n <= 0 || p <= 0.f || p >= 1.f) return PE_E_ARG;
+  if (n & 3) return PE_E_UNSUPPORTED;
+  hipLaunchKernelGGL(gelu_dropout_bwd_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, pe_stream(stream), x, dy, mask,
+                     1.0f / (1.0f - p), dx, n / 4);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }

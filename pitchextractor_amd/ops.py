@@ -865,7 +865,9 @@ def layernorm_fwd(a2d, gamma, beta, b2d=None, pe=None, eps=1e-5, keep_z=True):
     return y, LnState(z if need_z else (a2d if keep_z else None), mean, rstd)
 
 
-def layernorm_bwd(dy2d, st: LnState, gamma, dgamma, dbeta, dz=None):
+def layernorm_bwd(dy2d, st: LnState, gamma, dgamma, dbeta, dz=None, dy_add=None, drop_mask=None, p=0.0):
+    """dz = dLN(dy [+ dy_add]).  With ``drop_mask`` (uint8 [R, D], rate ``p``) returns (dz, dropout_bwd(dz)) from the
+    same pass."""
     dy2d = _dense(dy2d, "dy")
     R, D = dy2d.shape
     _chk(_dense(st.z, "z").shape == (R, D), "layernorm_bwd: z shape")
@@ -875,9 +877,71 @@ def layernorm_bwd(dy2d, st: LnState, gamma, dgamma, dbeta, dz=None):
     _chk(_dense(dgamma, "dgamma").numel() == D and _dense(dbeta, "dbeta").numel() == D, "layernorm_bwd: grads")
     lib = _lib.load()
     ws = workspace(lib.pe_layernorm_bwd_workspace_bytes(D), dy2d.device)
-    _call("pe_layernorm_bwd", dy2d.data_ptr(), st.z.data_ptr(), st.mean.data_ptr(), st.rstd.data_ptr(),
-          gamma.data_ptr(), dz.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), R, D, ws.data_ptr(), ws.numel(), _s())
-    return dz
+    if dy_add is None and drop_mask is None:
+        _call("pe_layernorm_bwd", dy2d.data_ptr(), st.z.data_ptr(), st.mean.data_ptr(), st.rstd.data_ptr(),
+              gamma.data_ptr(), dz.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), R, D, ws.data_ptr(), ws.numel(),
+              _s())
+        return dz
+    if dy_add is not None:
+        _chk(_dense(dy_add, "dy_add").shape == (R, D), "layernorm_bwd: dy_add shape")
+    dz_drop = None
+    if drop_mask is not None:
+        _chk(drop_mask.is_cuda and drop_mask.dtype == torch.uint8 and drop_mask.is_contiguous()
+             and drop_mask.numel() == R * D, "layernorm_bwd: drop_mask")
+        dz_drop = torch.empty_like(dy2d)
+    _call("pe_layernorm_bwd_fused", dy2d.data_ptr(), _lib.ptr(dy_add), st.z.data_ptr(), st.mean.data_ptr(),
+          st.rstd.data_ptr(), gamma.data_ptr(), dz.data_ptr(), _lib.ptr(drop_mask), float(p), _lib.ptr(dz_drop),
+          dgamma.data_ptr(), dbeta.data_ptr(), R, D, ws.data_ptr(), ws.numel(), _s())
+    return dz if drop_mask is None else (dz, dz_drop)
+
+
+def layernorm_dropout_fwd(a2d, b2d, gamma, beta, p, mask_in=None, seed=0, offset=0, eps=1e-5):
+    """y = LN(a + dropout(b)); returns (y, LnState, mask uint8 [R, D]).  Same masks and values as ``dropout`` followed
+    by ``layernorm_fwd(a, b2d=...)``."""
+    a2d, b2d = _dense(a2d, "a"), _dense(b2d, "b")
+    R, D = a2d.shape
+    _chk(b2d.shape == (R, D), "layernorm_dropout: b shape")
+    _chk(_dense(gamma, "gamma").numel() == D and _dense(beta, "beta").numel() == D, "layernorm_dropout: affine size")
+    mask_out = None
+    if mask_in is not None:
+        _chk(mask_in.is_cuda and mask_in.dtype == torch.uint8 and mask_in.is_contiguous()
+             and mask_in.numel() == R * D, "layernorm_dropout: mask_in")
+    else:
+        mask_out = torch.empty((R, D), dtype=torch.uint8, device=a2d.device)
+    z = torch.empty_like(a2d)
+    y = torch.empty_like(a2d)
+    mean = torch.empty((R,), dtype=torch.float32, device=a2d.device)
+    rstd = torch.empty((R,), dtype=torch.float32, device=a2d.device)
+    _call("pe_layernorm_dropout_fwd", a2d.data_ptr(), b2d.data_ptr(), None, 0, gamma.data_ptr(), beta.data_ptr(),
+          float(eps), z.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), R, D, _lib.ptr(mask_in),
+          _lib.ptr(mask_out), float(p), int(seed), int(offset), _s())
+    return y, LnState(z, mean, rstd), (mask_in if mask_in is not None else mask_out)
+
+
+def gelu_dropout_fwd(x, p, mask_in=None, seed=0, offset=0):
+    """dropout(gelu(x)) in one pass; returns (out, mask uint8 of x's shape)."""
+    x = _dense(x, "x")
+    out = torch.empty_like(x)
+    mask_out = None
+    if mask_in is not None:
+        _chk(mask_in.is_cuda and mask_in.dtype == torch.uint8 and mask_in.is_contiguous()
+             and mask_in.numel() == x.numel(), "gelu_dropout: mask_in")
+    else:
+        mask_out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    _call("pe_gelu_dropout_fwd", x.data_ptr(), out.data_ptr(), x.numel(), _lib.ptr(mask_in), _lib.ptr(mask_out),
+          float(p), int(seed), int(offset), _s())
+    return out, (mask_in if mask_in is not None else mask_out)
+
+
+def gelu_dropout_bwd(x, dy, mask, p, out=None):
+    x, dy = _dense(x, "x"), _dense(dy, "dy")
+    _chk(x.numel() == dy.numel() == mask.numel() and mask.dtype == torch.uint8 and mask.is_contiguous(),
+         "gelu_dropout_bwd: sizes")
+    if out is None:
+        out = torch.empty_like(x)
+    _call("pe_gelu_dropout_bwd", x.data_ptr(), dy.data_ptr(), mask.data_ptr(), float(p), out.data_ptr(), x.numel(),
+          _s())
+    return out
 
 
 def gelu_fwd(x, out=None):

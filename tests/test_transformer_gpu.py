@@ -303,3 +303,62 @@ def test_side_stream_weight_gradients_change_nothing_transformer(hip_device, mon
         outs.append((cls.detach().clone(), net.flat_gradients().clone()))
     for cls1, g1 in outs[1:]:
         assert torch.equal(cls1, outs[0][0]) and torch.equal(g1, outs[0][1])
+
+
+@pytest.mark.parametrize("inject", [False, True])
+def test_dropout_folded_into_layernorm_and_gelu_ops(hip_device, inject):
+    """The fused passes equal the separate ones bit for bit: same Philox counters / replayed bytes, same arithmetic."""
+    R, D, FF, p = 96, 512, 1024, 0.1
+    a, b = rnd(R, D, seed=1).to(hip_device), rnd(R, D, seed=2).to(hip_device)
+    gam, bet = rnd(D, seed=3).to(hip_device), rnd(D, seed=4).to(hip_device)
+    m_in = (torch.rand(R, D, generator=torch.Generator().manual_seed(5)) >= p).to(torch.uint8).to(hip_device) \
+        if inject else None
+    bd, m_ref = ops.dropout(b, p, mask_in=m_in, seed=9, offset=1234)
+    y_ref, st_ref = ops.layernorm_fwd(a, gam, bet, b2d=bd)
+    y, st, m = ops.layernorm_dropout_fwd(a, b, gam, bet, p, mask_in=m_in, seed=9, offset=1234)
+    assert torch.equal(m, m_ref) and torch.equal(y, y_ref) and torch.equal(st.z, st_ref.z)
+    assert torch.equal(st.mean, st_ref.mean) and torch.equal(st.rstd, st_ref.rstd)
+    assert 0.05 < 1.0 - m.float().mean().item() < 0.15
+    # backward: dz = dLN(dy + dy2), second output dropout_bwd(dz)
+    dy, dy2 = rnd(R, D, seed=6).to(hip_device), rnd(R, D, seed=7).to(hip_device)
+    dg_ref, db_ref = torch.empty(D, device=hip_device), torch.empty(D, device=hip_device)
+    dz_ref = ops.layernorm_bwd(dy + dy2, st_ref, gam, dg_ref, db_ref)
+    dzd_ref, _ = ops.dropout(dz_ref, p, mask_in=m_ref)
+    dg, db = torch.empty(D, device=hip_device), torch.empty(D, device=hip_device)
+    dz, dzd = ops.layernorm_bwd(dy, st, gam, dg, db, dy_add=dy2, drop_mask=m, p=p)
+    assert torch.equal(dz, dz_ref) and torch.equal(dzd, dzd_ref) and torch.equal(dg, dg_ref) and torch.equal(db, db_ref)
+    dz_only = ops.layernorm_bwd(dy, st, gam, dg, db, dy_add=dy2)
+    assert torch.equal(dz_only, dz_ref)
+    # GELU
+    h, da = rnd(R, FF, seed=8).to(hip_device), rnd(R, FF, seed=10).to(hip_device)
+    mf_in = (torch.rand(R, FF, generator=torch.Generator().manual_seed(11)) >= p).to(torch.uint8).to(hip_device) \
+        if inject else None
+    act_ref, mf_ref = ops.dropout(ops.gelu_fwd(h), p, mask_in=mf_in, seed=9, offset=77)
+    act, mf = ops.gelu_dropout_fwd(h, p, mask_in=mf_in, seed=9, offset=77)
+    assert torch.equal(mf, mf_ref) and torch.equal(act, act_ref)
+    dh_ref = ops.gelu_bwd(h, ops.dropout(da, p, mask_in=mf_ref)[0])
+    assert torch.equal(ops.gelu_dropout_bwd(h, da, mf, p), dh_ref)
+
+
+@pytest.mark.parametrize("dropout", [0.1, 0.0])
+def test_folded_dropout_changes_nothing_in_the_model(hip_device, monkeypatch, dropout):
+    """Transformer-head JDCNet, train mode: logits and the flat gradient buffer with the dropouts / residual adds folded
+    into the LayerNorm and GELU passes are bit-identical to the separate passes (live Philox masks)."""
+    from pitchextractor_amd import model as pe_model
+    state = model_ref.seeded_state(11, model_type="transformer", num_layers=2)
+    cfg = dict(TF_CFG, num_layers=2, dropout=dropout)
+    x = golden_input(6).repeat(4, 1, 1, 1)
+    f0, sil = (t.repeat(4, 1).to(hip_device) for t in golden_targets(6))
+    outs = []
+    for fused in (False, True):
+        monkeypatch.setattr(pe_model, "TF_FUSE_DROPOUT", fused)
+        net = JDCNet(num_class=1, sequence_model_config=dict(cfg))
+        net.load_state_dict(state)
+        net = net.to(hip_device).train()
+        net.dropout_cfg.seed = 5
+        cls, det = net(x.to(hip_device))
+        out3, d_f0, d_sil = ops.f0_sil_loss(cls.detach().reshape(-1), f0.reshape(-1), det.detach().reshape(-1),
+                                            sil.reshape(-1), 0.1)
+        torch.autograd.backward([cls, det], [d_f0.view_as(cls), d_sil.view_as(det)])
+        outs.append((cls.detach().clone(), net.flat_gradients().clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
