@@ -156,6 +156,9 @@ def main():
                          "--family-steps extra steps after it")
     ap.add_argument("--family-steps", type=int, default=3,
                     help="extra steps after the timed region with events around every call (0 = skip; N = 1 only)")
+    ap.add_argument("--dp-payload", choices=["fp32", "bf16"], default=None,
+                    help="gradient all-reduce payload (N > 1): fp32 (default) or bf16 buckets (57.8 MB instead of 115.5 MB "
+                         "per step on xGMI; meant for --precision bf16 = BASELINE config[3])")
     ap.add_argument("--host-steps", type=int, default=None,
                     help="extra steps fed from pinned host memory with double-buffered H2D (default: --steps; 0 = skip)")
     args = ap.parse_args()
@@ -185,9 +188,11 @@ def main():
                                   "scheduler_params": {"max_lr": 3e-4, "pct_start": 0.0, "epochs": 100,
                                                        "steps_per_epoch": 1000}})
     dp = None
-    if world > 1:
+    dp_on = world > 1 or pdist.rehearse_single_rank()       # PE_DP_REHEARSE=1: the RCCL path at world size 1
+    if dp_on:
         buffers = [b for b in net.buffers() if b.dtype.is_floating_point]
-        dp = pdist.GradientAllReduce(net.flat_gradients(), opt, flat_param=net.flat_parameters, buffers=buffers)
+        dp = pdist.GradientAllReduce(net.flat_gradients(), opt, flat_param=net.flat_parameters, buffers=buffers,
+                                     payload=args.dp_payload)
         net.attach_data_parallel(dp)            # buckets go out as backward finalises them
     crit = {"l1": torch.nn.SmoothL1Loss(), "ce": torch.nn.BCEWithLogitsLoss()}
     log = logging.getLogger("bench")
@@ -204,7 +209,7 @@ def main():
     real_frames = 1 + w32.shape[1] // DEFAULT_MEL_PARAMS["hop_length"]
 
     def barrier():
-        if world > 1:
+        if dp_on:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -230,7 +235,7 @@ def main():
     if rank == 0:
         print(f"[bench] timed {args.steps} steps: {elapsed / args.steps * 1e3:.1f} ms/step", file=sys.stderr,
               flush=True)
-    if world > 1:
+    if dp_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -274,7 +279,7 @@ def main():
             ticket = nxt
         barrier()
         el_h = time.perf_counter() - t_h
-        if world > 1:
+        if dp_on:
             t = torch.tensor([el_h], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el_h = float(t.item())
@@ -369,6 +374,12 @@ def main():
                        "real_frames_per_utterance": real_frames, "parallelism": f"dp{world}"},
             "loss": last["loss"], "roofline": roof, "roofline_mel": roof_mel,
         }
+        if dp is not None:
+            line["config"]["gradient_allreduce"] = {
+                "backend": dist.get_backend(), "payload": dp.payload, "bucket_bytes": 32 << 20,
+                "bytes_per_step": net.flat_gradients().numel() * (2 if dp.payload == "bf16" else 4),
+                "messages_per_step": dp.messages / max(1, tr._runs),
+                "rehearsal_world1": bool(world == 1)}
         if from_host is not None:
             line["from_host"] = from_host
         if fam_summ is not None:
@@ -384,7 +395,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.head == "bilstm" and not bf16:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dp_on:
         dist.destroy_process_group()
 
 

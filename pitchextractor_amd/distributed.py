@@ -20,6 +20,13 @@ import torch
 import torch.distributed as dist
 
 
+def rehearse_single_rank() -> bool:
+    """``PE_DP_REHEARSE=1``: run the whole data-parallel wiring (process group, broadcasts, bucketed all-reduce on
+    the reducer stream, cross-rank flags) even at world size 1, so a one-GPU box executes the RCCL code path that
+    the multi-GPU launch uses (a sum over one rank is the identity: results must equal the plain run bit for bit)."""
+    return os.environ.get("PE_DP_REHEARSE", "0") == "1"
+
+
 def init_from_env(backend: str | None = None):
     """torchrun-style rendezvous (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  Returns (rank, world, local)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -27,7 +34,7 @@ def init_from_env(backend: str | None = None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if "PE_FORCE_DEVICE" in os.environ:             # rehearsal on a 1-GPU box: every rank on one device
         local = int(os.environ["PE_FORCE_DEVICE"])
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or rehearse_single_rank()) and not dist.is_initialized():
         if backend is None:
             backend = os.environ.get("PE_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -88,7 +95,7 @@ class EpochShardSampler(torch.utils.data.Sampler):
 
 def mean_over_ranks(values: dict, weight: float, device=None, group=None) -> dict:
     """Weighted mean of per-rank scalar dicts (same keys everywhere); logging only."""
-    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+    if not (dist.is_initialized() and (dist.get_world_size(group) > 1 or rehearse_single_rank())):
         return dict(values)
     keys = sorted(values)
     t = torch.tensor([float(values[k]) * weight for k in keys] + [float(weight)], dtype=torch.float64, device=device)
@@ -102,33 +109,50 @@ class GradientAllReduce:
 
     ``flat_grad`` is the model's flat gradient tensor (``JDCNet.flat_gradients()``);
     ``optimizer.grad_scale`` is set to 1/world so the mean is taken inside the AdamW kernel.
-    """
+    ``payload="bf16"`` (or ``PE_DP_PAYLOAD=bf16``; BASELINE config[3]) halves the bytes on xGMI: each bucket is
+    rounded to bf16 on the reducer stream, summed in bf16 by the collective and widened back into the fp32 buffer
+    before the optimizer reads it (115.5 MB -> 57.8 MB per step; the sum of `world` bf16 terms carries ~8 bits, so
+    this is an opt-in that belongs with mixed-precision training, never the fp32 parity path)."""
 
     def __init__(self, flat_grad: torch.Tensor, optimizer=None, group=None, bucket_bytes: int = 32 << 20,
-                 flat_param: torch.Tensor | None = None, buffers=()):
+                 flat_param: torch.Tensor | None = None, buffers=(), payload: str | None = None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (dist.is_initialized() and rehearse_single_rank())
         self.flat_grad = flat_grad
+        payload = (payload or os.environ.get("PE_DP_PAYLOAD") or "fp32").lower()
+        if payload not in ("fp32", "bf16"):
+            raise ValueError(f"GradientAllReduce: payload must be 'fp32' or 'bf16', not {payload!r}")
+        self.payload = payload
         n = flat_grad.numel()
-        per = max(1, bucket_bytes // 4)
+        per = max(1, bucket_bytes // (2 if payload == "bf16" else 4))
         self.bucket_elems = per
         self.buckets = [(lo, min(n, lo + per)) for lo in range(0, n, per)]
         self._pending = []
         self._issued = False
+        self.messages = 0                   # collectives issued so far (tests / logging)
         self._stream = torch.cuda.Stream(device=flat_grad.device) if flat_grad.is_cuda else None
         if optimizer is not None:
             optimizer.grad_scale = 1.0 / self.world
-        if self.world > 1:
+        if self.active:
             if flat_param is not None:
                 dist.broadcast(flat_param.data, src=0, group=group)     # identical replicas at step 0
             for b in buffers:
                 dist.broadcast(b, src=0, group=group)
 
+    def _all_reduce(self, chunk):
+        """One bucket: fp32 in place, or through a bf16 staging tensor widened back by `finish`."""
+        if self.payload == "bf16":
+            stage = chunk.to(torch.bfloat16)
+            work = dist.all_reduce(stage, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            return work, stage, chunk
+        return dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, chunk
+
     def reduce_range(self, lo: int, hi: int, after=None):
         """Start reducing gradient elements [lo, hi), in bucket-sized messages.  They must be final once the work
         queued so far on the current stream -- and on `after`, a second stream that also writes them (the model's
         weight-gradient side stream) -- has run."""
-        if self.world == 1 or hi <= lo:
+        if not self.active or hi <= lo:
             return
         self._issued = True
         if self._stream is not None:
@@ -142,14 +166,14 @@ class GradientAllReduce:
             chunk = self.flat_grad[a:min(hi, a + per)]
             if self._stream is not None:
                 with torch.cuda.stream(self._stream):
-                    self._pending.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group,
-                                                         async_op=True))
+                    self._pending.append(self._all_reduce(chunk))
             else:
-                self._pending.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self._pending.append(self._all_reduce(chunk))
+            self.messages += 1
 
     def any_rank(self, flag: bool) -> bool:
         """Logical OR of a per-rank status over the group (fault flags must be acted on by every rank)."""
-        if self.world == 1:
+        if not self.active:
             return bool(flag)
         t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=self.flat_grad.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
@@ -157,12 +181,16 @@ class GradientAllReduce:
 
     def finish(self):
         """Reduce whatever has not been issued yet and make the compute stream wait for all of it."""
-        if self.world == 1:
+        if not self.active:
             return
         if not self._issued:
             self.reduce_range(0, self.flat_grad.numel())
-        for w in self._pending:
-            w.wait()
+        for work, stage, chunk in self._pending:
+            work.wait()                      # RCCL: the current stream waits for the collective; gloo: the host does
+            if stage is not None:
+                if stage.is_cuda:            # allocated on the reducer stream, read here on the compute stream
+                    stage.record_stream(torch.cuda.current_stream(stage.device))
+                chunk.copy_(stage)           # widen the bf16 sum back into the fp32 gradient buffer
         self._pending = []
         self._issued = False
         if self._stream is not None:

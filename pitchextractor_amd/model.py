@@ -637,6 +637,7 @@ class JDCNet(nn.Module):
         self.dropout_cfg = _DropoutCfg()
         self.training_graph_wanted = True
         self._dp = None
+        self._dp_cuts = None
         self.keep_last_context = False      # tests: expose the saved tensors (dropout masks) of the last forward
         self.checkpoint_forward = False     # Trainer(gradient_checkpointing=True): recompute the forward in backward
         self.last_context = None
@@ -691,10 +692,27 @@ class JDCNet(nn.Module):
 
     def attach_data_parallel(self, dp):
         """``dp``: pitchextractor_amd.distributed.GradientAllReduce over ``flat_gradients()``.  Backward then
-        hands it gradient ranges as they become final: [sequence models .. heads] (93 % of the bytes)
-        right after the temporal-head backward, so that all-reduce runs on its own stream underneath the
-        whole convolution backward; the convolution stack's range follows at the end."""
+        hands it gradient ranges as they become final, in backward order: [sequence models .. heads]
+        (93 % of the bytes) right after the temporal-head backward, so that all-reduce runs on its own stream
+        underneath the whole convolution backward; then [res_block3 .. detector_conv], res_block2 and res_block1
+        as each block's backward finishes, and only [conv_block] (148 KB) after the last kernel."""
         self._dp = dp
+        self._dp_cuts = self._block_cuts()
+
+    def _block_cuts(self):
+        """Flat-buffer offsets where conv_block | res_block1 | res_block2 | res_block3+pool_block+detector_conv |
+        temporal heads begin, or None if the parameter order is not that (then the conv range goes out whole)."""
+        def first(mod):
+            return min(self._param_offsets[id(q)] for q in mod.parameters())
+
+        def last(mod):
+            return max(self._param_offsets[id(q)] for q in mod.parameters())
+        blocks = [self.conv_block, self.res_block1, self.res_block2, self.res_block3]
+        cuts = [first(b) for b in blocks] + [self._seq_offset()]
+        tail_ok = all(cuts[3] < first(m) and last(m) < cuts[4] for m in (self.pool_block, self.detector_conv))
+        ordered = cuts[0] == 0 and all(a < b for a, b in zip(cuts, cuts[1:])) and \
+            all(last(b) < c for b, c in zip(blocks, cuts[1:]))
+        return cuts if (ordered and tail_ok) else None
 
     def _seq_offset(self):
         first = next(self.sequence_classifier.parameters())
@@ -841,11 +859,20 @@ class JDCNet(nn.Module):
         bnp = self.pool_block[0]
         d_rb3 = ops.bn_act_pool_bwd(s.rb3, d_pool, s.bnp, g[bnp.weight], g[bnp.bias], pool=4, slope=slope)
 
+        cuts = self._dp_cuts if self._dp is not None else None
+
+        def block_done(k):                  # gradients of flat range [cuts[k], cuts[k+1]) are queued: reduce them
+            if cuts is not None:
+                self._dp.reduce_range(cuts[k], cuts[k + 1], after=side.pending_stream())
+
         d_rb2 = _res_backward(self.res_block3, s.r3, d_rb3, 2, slope, g, side)
+        block_done(3)                       # res_block3 + pool_block + detector_conv
         ops.maxpool_bwd_add(s.rb2, d_concat, d_rb2, 10, coff=192)
         d_rb1 = _res_backward(self.res_block2, s.r2, d_rb2, 2, slope, g, side)
+        block_done(2)
         ops.maxpool_bwd_add(s.rb1, d_concat, d_rb1, 20, coff=64)
         d_cb = _res_backward(self.res_block1, s.r1, d_rb1, 2, slope, g, side)
+        block_done(1)
         ops.maxpool_bwd_add(s.cb, d_concat, d_cb, 40, coff=0)
 
         cbk = self.conv_block
@@ -856,4 +883,4 @@ class JDCNet(nn.Module):
         ops.conv3x3_c1_wgrad(s.x_btf, d_y0, g[cbk[0].weight])
         side.join()                             # every weight gradient is final from here on
         if self._dp is not None:
-            self._dp.reduce_range(0, self._seq_offset())
+            self._dp.reduce_range(0, cuts[1] if cuts is not None else self._seq_offset())

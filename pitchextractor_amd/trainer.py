@@ -225,7 +225,7 @@ class Trainer(object):
         results are suspect or its peers would deadlock in the next all-reduce).  Clears the sticky word and
         switches this process to the one-launch-per-time-step kernels."""
         bad = ops.persistent_lstm_error(device)
-        if self.data_parallel is not None and self.data_parallel.world > 1:
+        if self.data_parallel is not None and self.data_parallel.active:
             bad = self.data_parallel.any_rank(bad)
         if bad:
             ops.clear_persistent_lstm_error(device)
@@ -248,7 +248,7 @@ class Trainer(object):
             self.optimizer.step()
         else:                                              # scaler.step(optimizer); scaler.update()  (trainer.py:242-244)
             found = bool(ops.nonfinite_flag(self.model.flat_gradients()).item())
-            if self.data_parallel is not None and self.data_parallel.world > 1:
+            if self.data_parallel is not None and self.data_parallel.active:
                 found = self.data_parallel.any_rank(found)
             if not found:
                 self.optimizer.loss_scale_inv = 1.0 / self.scaler.scale      # unscale inside the fused AdamW

@@ -90,3 +90,56 @@ def test_two_rank_step_equals_mean_gradient_update(tmp_path):
     # (g0 + g1) summed by gloo then scaled inside AdamW vs averaged first: a few ulps apart
     np.testing.assert_allclose(p0, ref, rtol=1e-5, atol=1e-7)
     assert not np.array_equal(p0, np.zeros_like(p0))
+
+
+def _rccl_worker(rank, world, port, out_dir):
+    """World size 1 over backend "nccl" (= RCCL): the one-GPU box executes the communicator set-up, the broadcasts and
+    the bucketed all-reduces on the reducer stream that the 8-GPU launch uses.  A sum over one rank is the identity."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      PE_DP_REHEARSE="1")
+    from oracle import model_ref
+    from pitchextractor_amd import distributed as pdist
+    from pitchextractor_amd.trainer import Trainer
+    pdist.init_from_env("nccl")
+    assert dist.get_backend() == "nccl"
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    state = model_ref.seeded_state(3, hidden_size=64, num_layers=2)
+    crit = {"l1": torch.nn.SmoothL1Loss(), "ce": torch.nn.BCEWithLogitsLoss()}
+    result = {}
+    for tag, payload in (("plain", None), ("fp32", "fp32"), ("bf16", "bf16")):
+        net, opt, sched = _make(state, dev)
+        dp = None
+        if payload is not None:
+            dp = pdist.GradientAllReduce(net.flat_gradients(), opt, flat_param=net.flat_parameters,
+                                         buffers=[b for b in net.buffers() if b.dtype.is_floating_point],
+                                         bucket_bytes=1 << 20, payload=payload)
+            net.attach_data_parallel(dp)
+            assert dp.active and net._dp_cuts is not None
+        tr = Trainer(model=net, criterion=crit, optimizer=opt, scheduler=sched, device="cuda:0",
+                     loss_config={"lambda_f0": 0.1}, logger=logging.getLogger("dp"), data_parallel=dp)
+        for step in range(2):
+            out = tr.run(_batch(step, dev))
+            if step == 0:
+                result[tag + "_grad"] = net.flat_gradients().detach().cpu().numpy()
+        torch.cuda.synchronize()
+        result[tag] = net.flat_parameters.detach().cpu().numpy()
+        result[tag + "_loss"] = np.array(out["loss"])
+        if dp is not None:
+            # per step: heads, res_block3.., res_block2, res_block1, conv_block -- each range in >= 1 message
+            result[tag + "_msgs"] = np.array(dp.messages)
+    np.savez(os.path.join(out_dir, "rccl.npz"), **result)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_world1_rehearsal(tmp_path):
+    mp.spawn(_rccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    r = np.load(tmp_path / "rccl.npz")
+    assert np.array_equal(r["plain"], r["fp32"]) and r["plain_loss"] == r["fp32_loss"]      # RCCL sum over one rank
+    assert r["fp32_msgs"] >= 2 * 5 and r["bf16_msgs"] >= 2 * 5
+    # bf16 buckets: the gradient the optimizer saw in step 1 is exactly the fp32 gradient rounded to bf16
+    g, gb = r["fp32_grad"], r["bf16_grad"]
+    assert np.array_equal(r["plain_grad"], g) and not np.array_equal(g, gb)
+    assert np.array_equal(gb, torch.from_numpy(g).to(torch.bfloat16).float().numpy())
+    np.testing.assert_allclose(r["bf16"], r["plain"], rtol=0, atol=1e-4)        # two AdamW steps at lr 3e-4

@@ -91,7 +91,8 @@ def main(config_path):
     # contiguous per-rank shards truncated to a common length (distributed.EpochShardSampler), so all ranks
     # run the same number of steps and OneCycleLR sees the same steps_per_epoch everywhere.
     seed = int(config.get("seed", 1234))
-    shard = (rank, world, seed) if world > 1 else None
+    dp_on = world > 1 or pdist.rehearse_single_rank()
+    shard = (rank, world, seed) if dp_on else None
     per_rank_batch = max(1, batch_size // world)
     train_dataloader = build_dataloader(train_list, batch_size=per_rank_batch, num_workers=num_workers,
                                         dataset_config=config.get("dataset_params", {}), device=device, shard=shard)
@@ -117,10 +118,11 @@ def main(config_path):
         {"params": model.parameters(), "optimizer_params": {}, "scheduler_params": scheduler_params})
     criterion = {"l1": nn.SmoothL1Loss(), "ce": nn.BCEWithLogitsLoss()}
     dp = None
-    if world > 1:
+    if dp_on:
         buffers = [b for b in model.buffers() if b.dtype.is_floating_point]
+        # training.gradient_payload: "fp32" (default) or "bf16" buckets on xGMI (BASELINE config[3])
         dp = pdist.GradientAllReduce(model.flat_gradients(), optimizer, flat_param=model.flat_parameters,
-                                     buffers=buffers)
+                                     buffers=buffers, payload=training_config.get("gradient_payload"))
         model.attach_data_parallel(dp)
     trainer = Trainer(model=model, criterion=criterion, optimizer=optimizer, scheduler=scheduler, device=device,
                       train_dataloader=train_dataloader, val_dataloader=val_dataloader,
@@ -136,7 +138,7 @@ def main(config_path):
     for epoch in range(1, epochs + 1):
         results = trainer._train_epoch()
         evals = trainer._eval_epoch()
-        if world > 1:                               # logging only: every rank's batches count
+        if dp_on:                                   # logging only: every rank's batches count
             lr = results.pop("train/learning_rate")
             results = pdist.mean_over_ranks(results, len(train_dataloader), device=device)
             results["train/learning_rate"] = lr
