@@ -20,8 +20,13 @@ hop_length), then the legacy ``<wav>_f0.npy``; or from an ``f0_provider`` callab
 metadata does not match is skipped with a warning and left on disk (the reference deletes and
 recomputes it; this build cannot recompute).  An item with no usable label source fails loudly, as the
 reference does when no backend is usable (meldataset.py:80-88).  ``<wav>_mel.npy`` caches
-(meldataset.py:679-788) are neither read nor written: the mel is recomputed on the device, one launch
-per batch.  Files at another sample rate are resampled on the GPU
+(meldataset.py:679-741) are honoured read-only under the reference's rule: whole-file items without
+augmentation whose ``<wav>_mel_meta.json`` equals the expected metadata (audio/dataset sample rate, sample
+count, channel count, mel_params) take their spectrogram from the cache -- normalised on the host with the
+reference's own float32 expression, cropped, and written over that batch row after the mel launch -- so a
+dataset trained with cached spectrograms keeps seeing exactly those values.  Caches are never written (the
+device recomputes the mel in one launch per batch) and a mismatching cache is skipped with a warning, not
+deleted (the reference clears every cache of the dataset on the first mismatch, :743-767).  Files at another sample rate are resampled on the GPU
 (meldataset.py:621-627 -> ``pitchextractor_amd.resample.Resampler``) right before the mel launch; one
 batch must come from one source rate.
 """
@@ -262,6 +267,9 @@ class MelDataset(torch.utils.data.Dataset):
         self.requires_cuda_backend = False
         self._audio_metadata_cache = {}
         self._invalid_paths = set()
+        self._mel_cache_suffix, self._mel_meta_suffix = "_mel.npy", "_mel_meta.json"      # meldataset.py:102-103
+        self._cache_enabled = True
+        self._mel_cache_warned = False
         if synthetic_data and synthetic_data.get("enabled", False) and not validation:
             logger.warning("synthetic_data augmentation (WORLD / pitch-shift) needs pyworld/librosa, which are "
                            "not available: disabled")
@@ -320,6 +328,57 @@ class MelDataset(torch.utils.data.Dataset):
                            "(+ .json) cache, no legacy '_f0.npy' and no f0_provider (the reference's tracker "
                            "backends are outside this build)")
 
+    # ---- cached spectrograms (meldataset.py:679-741), read-only ------------------------------
+    def _build_mel_metadata(self, num_samples: int, wave_sr: int) -> dict:
+        """meldataset.py:679-701 for the mono float waveform handed to ``_build_training_example``."""
+        def plain(v):
+            if isinstance(v, np.ndarray):
+                return v.tolist()
+            if isinstance(v, np.generic):
+                return v.item()
+            if isinstance(v, torch.Tensor):
+                v = v.detach().cpu()
+                return v.item() if v.numel() == 1 else v.tolist()
+            return v
+        return {"audio_sample_rate": int(wave_sr), "audio_num_samples": int(num_samples), "audio_num_channels": 1,
+                "dataset_sample_rate": int(self.sr), "mel_params": {k: plain(v) for k, v in self.mel_params.items()}}
+
+    def _mel_cache_paths(self, path):
+        return path + self._mel_cache_suffix, path + self._mel_meta_suffix
+
+    def _load_cached_mel(self, path, expected_metadata):
+        """meldataset.py:706-741: the cached power-mel (n_mels, L) if its metadata file equals
+        ``expected_metadata``; None otherwise.  Nothing is deleted."""
+        if not self._cache_enabled or self.data_augmentation:
+            return None
+        mel_path, meta_path = self._mel_cache_paths(path)
+        if not os.path.isfile(mel_path):
+            return None
+        why = None
+        if not os.path.isfile(meta_path):
+            why = "has no metadata file"
+        else:
+            try:
+                with open(meta_path, "r", encoding="utf-8") as fh:
+                    cached = json.load(fh)
+            except (OSError, json.JSONDecodeError):
+                cached, why = None, "has unreadable metadata"
+            if why is None and cached != expected_metadata:
+                why = "was computed for other audio / mel parameters"
+        if why is None:
+            try:
+                mel = np.load(mel_path)
+                if mel.ndim == 2 and mel.shape[0] == int(self.mel_params["n_mels"]):
+                    return np.ascontiguousarray(mel, dtype=np.float32)
+                why = f"has shape {mel.shape}"
+            except (OSError, ValueError):
+                why = "is unreadable"
+        if not self._mel_cache_warned:          # once per dataset, like the reference's one-shot invalidation
+            self._mel_cache_warned = True
+            logger.warning("[MelDataset] mel cache %s %s: skipped, the device recomputes it (the reference would clear "
+                           "the dataset's caches here)", mel_path, why)
+        return None
+
     # ---- one item -------------------------------------------------------------------------
     def _metadata(self, path):
         md = self._audio_metadata_cache.get(path)
@@ -350,6 +409,13 @@ class MelDataset(torch.utils.data.Dataset):
             wave = (0.5 + 0.5 * np.random.random()) * wave                        # meldataset.py:232-234
             wave = wave.astype(np.float32)
         mel_len = 1 + n_target // hop
+        # meldataset.py:236-237,640-642: whole-file items without augmentation may come from the spectrogram cache
+        self._last_cached_mel = None
+        if full and not self.data_augmentation:
+            cached = self._load_cached_mel(path, self._build_mel_metadata(n_target, self.sr))
+            if cached is not None:
+                mel_len = cached.shape[1]                                         # meldataset.py:651
+                self._last_cached_mel = cached
         f0 = align_length(f0, mel_len)
         sil = (f0 == 0).astype(np.float32)
         crop = 0
@@ -359,6 +425,10 @@ class MelDataset(torch.utils.data.Dataset):
             sil = sil[crop:crop + self.max_mel_length]
         f0 = np.where(np.isnan(f0), np.float32(self.zero_value), f0).astype(np.float32)
         self._last_sr = wave_sr
+        if self._last_cached_mel is not None:
+            # meldataset.py:650,668-670 in the reference's own float32 torch arithmetic, on the host
+            m = (torch.log(LOG_EPS + torch.from_numpy(self._last_cached_mel)) - self.mean) / self.std
+            self._last_cached_mel = m[:, crop:crop + self.max_mel_length].contiguous()
         return wave, f0, sil, crop
 
     def __getitem__(self, idx):
@@ -377,12 +447,15 @@ class MelDataset(torch.utils.data.Dataset):
                 self._invalid_paths.add(path)
                 logger.warning("[MelDataset] Skipping unreadable audio file: %s (%s)", path, exc)
                 continue
-            return torch.from_numpy(wave), torch.from_numpy(f0), torch.from_numpy(sil), crop, int(self._last_sr)
+            item = (torch.from_numpy(wave), torch.from_numpy(f0), torch.from_numpy(sil), crop, int(self._last_sr))
+            return item if self._last_cached_mel is None else item + (self._last_cached_mel,)
         raise RuntimeError("No valid audio files could be loaded from the dataset")
 
     def path_to_mel_and_label(self, path, device="cuda"):
         """Reference-shaped single item: (mel (80, L<=192) normalised log-mel on the device, f0, is_silence)."""
         wave, f0, sil, crop = self.path_to_wave_and_label(path)
+        if self._last_cached_mel is not None:
+            return self._last_cached_mel.to(device), torch.from_numpy(f0), torch.from_numpy(sil)
         wave_dev = torch.from_numpy(wave).to(device)
         if self._last_sr != self.sr:
             wave_dev = Resampler(self._last_sr, self.sr)(wave_dev)
@@ -395,8 +468,9 @@ class Collater(object):
     """Zero-pads items to 192 frames (meldataset.py:790-826).
 
     Accepts the reference's ``(mel (80,L), f0, is_silence)`` items, or this build's raw-audio items
-    ``(wave (N,), f0, is_silence, crop_start[, source_sr])``; for the latter it returns host tensors
-    ``(waves (B,Nmax), lengths, crop_starts, f0s, is_silences, source_sr)`` for the device mel stage."""
+    ``(wave (N,), f0, is_silence, crop_start[, source_sr[, cached_mel (80,L<=192)]])``; for the latter it returns
+    host tensors ``(waves (B,Nmax), lengths, crop_starts, f0s, is_silences, source_sr)`` for the device mel stage,
+    followed by ``(cached_rows (K,), cached_mels (K,80,192))`` when any item carries a cached spectrogram."""
 
     def __init__(self, return_wave=False):
         self.return_wave = return_wave
@@ -432,7 +506,15 @@ class Collater(object):
             crops[i] = int(crop)
             f0s[i, :f0.shape[0]] = f0
             sils[i, :sil.shape[0]] = sil
-        return waves, lengths, crops, f0s, sils, (rates.pop() if rates else 0)
+        out = (waves, lengths, crops, f0s, sils, (rates.pop() if rates else 0))
+        rows = [i for i, item in enumerate(batch) if len(item) > 5]
+        if rows:                                       # normalised, cropped cache rows, zero-padded like :812-816
+            cached = torch.zeros((len(rows), batch[rows[0]][5].shape[0], L), dtype=torch.float32)
+            for k, i in enumerate(rows):
+                m = batch[i][5]
+                cached[k, :, :m.shape[1]] = m
+            out += (torch.tensor(rows, dtype=torch.int64), cached)
+        return out
 
 
 class H2DPrefetcher:
@@ -481,7 +563,7 @@ class DeviceMelLoader:
             sampler.set_epoch(epoch)
 
     def _finish(self, ticket):
-        waves, lengths, crops, f0s, sils, src_sr = self._h2d.acquire(ticket)
+        waves, lengths, crops, f0s, sils, src_sr, *cached = self._h2d.acquire(ticket)
         if src_sr and src_sr != self.mel.sample_rate:
             rs = self._resamplers.setdefault(src_sr, Resampler(src_sr, self.mel.sample_rate))
             waves = rs(waves)                                 # zero-padded rows resample exactly like each item alone
@@ -490,6 +572,9 @@ class DeviceMelLoader:
         else:
             self._host_lengths.pop(0)
         mels = self.mel.log_mel_ragged(waves, lengths, crops, max_frames=MAX_MEL_LENGTH)
+        if cached:                                            # rows whose spectrogram came from <wav>_mel.npy
+            rows, cached_mels = cached
+            mels[:, 0].index_copy_(0, rows, cached_mels)
         return mels, f0s, sils
 
     def __iter__(self):

@@ -170,3 +170,75 @@ def test_resampler_oracle_properties():
     assert np.abs(y - ref)[200:-200].max() < 1e-3
     assert rr.resample(np.ones(1000), 24000, 24000).shape == (1000,)
     assert rr.resample(np.zeros(107722), 44100, 24000).shape == (58625,)            # ceil(80 * 107722 / 147)
+
+
+def _mel_cache_fixture(tmp_path, n_files=3):
+    """Whole-file items (2 s < the 58 624-sample segment) with legacy F0 caches; file 1 gets a spectrogram cache
+    written exactly as meldataset.py:780-786 writes it (np.save + json.dump(sort_keys=True))."""
+    import json
+    lines, paths = [], []
+    for i in range(n_files):
+        wave, f0, _ = synthetic.utterance(10 + i, duration=2.0)
+        p = str(tmp_path / f"c{i}.wav")
+        write_wav(p, wave, 24000, "float32")
+        np.save(p + "_f0.npy", f0)
+        lines.append(f"{p}|0\n")
+        paths.append(p)
+    rng = np.random.default_rng(5)
+    cached = rng.uniform(1e-4, 3.0, size=(80, 161)).astype(np.float32)     # recognisably NOT what the device computes
+    np.save(paths[1] + "_mel.npy", cached)
+    meta = {"audio_sample_rate": 24000, "audio_num_samples": 48000, "audio_num_channels": 1,
+            "dataset_sample_rate": 24000,
+            "mel_params": {"sample_rate": 24000, "n_mels": 80, "n_fft": 1024, "win_length": 1024, "hop_length": 300}}
+    with open(paths[1] + "_mel_meta.json", "w", encoding="utf-8") as fh:
+        json.dump(meta, fh, sort_keys=True)
+    return lines, paths, cached, meta
+
+
+def test_mel_cache_contract_read_only(tmp_path):
+    """meldataset.py:679-741: a whole-file item takes its spectrogram from <wav>_mel.npy only when
+    <wav>_mel_meta.json equals the expected metadata; normalisation is the reference's float32 expression."""
+    import json
+    lines, paths, cached, meta = _mel_cache_fixture(tmp_path)
+    ds = md.MelDataset(lines, verbose=False)
+    assert ds._build_mel_metadata(48000, 24000) == meta
+    plain, hit = ds[0], ds[1]
+    assert len(plain) == 5 and len(hit) == 6
+    want = (torch.log(1e-5 + torch.from_numpy(cached)) - (-4.0)) / 4.0            # meldataset.py:650
+    assert torch.equal(hit[5], want) and hit[1].shape == (161,)
+    out = md.Collater()([plain, hit, ds[2]])
+    assert len(out) == 8 and out[6].tolist() == [1] and out[7].shape == (1, 80, 192)
+    assert torch.equal(out[7][0, :, :161], want) and not out[7][0, :, 161:].any()  # zero padding after normalisation
+    assert len(md.Collater()([plain, ds[2]])) == 6                                 # no cache rows: the usual tuple
+
+    # a cached spectrogram of another length drives the label length, as mel_tensor.size(1) does (:651-656)
+    np.save(paths[2] + "_mel.npy", cached[:, :150])
+    with open(paths[2] + "_mel_meta.json", "w", encoding="utf-8") as fh:
+        json.dump(meta, fh, sort_keys=True)
+    assert ds[2][5].shape == (80, 150) and ds[2][1].shape == (150,)
+
+    # mismatching metadata (other hop), missing metadata, augmentation: not used -- and nothing is deleted
+    bad = dict(meta, mel_params=dict(meta["mel_params"], hop_length=256))
+    with open(paths[1] + "_mel_meta.json", "w", encoding="utf-8") as fh:
+        json.dump(bad, fh, sort_keys=True)
+    assert len(ds[1]) == 5 and os.path.isfile(paths[1] + "_mel.npy") and os.path.isfile(paths[1] + "_mel_meta.json")
+    os.remove(paths[2] + "_mel_meta.json")
+    assert len(ds[2]) == 5 and os.path.isfile(paths[2] + "_mel.npy")
+    with open(paths[1] + "_mel_meta.json", "w", encoding="utf-8") as fh:
+        json.dump(meta, fh, sort_keys=True)
+    assert len(ds[1]) == 6
+    assert len(md.MelDataset(lines, verbose=False, data_augmentation=True)[1]) == 5
+
+
+def test_mel_cache_not_used_for_pre_cropped_segments(tmp_path):
+    """cache_key is the path only for whole files (meldataset.py:236): a 3 s file is pre-cropped, so its cache is ignored."""
+    import json
+    wave, f0, _ = synthetic.utterance(3, duration=3.0)
+    p = str(tmp_path / "long.wav")
+    write_wav(p, wave, 24000, "float32")
+    np.save(p + "_f0.npy", f0)
+    np.save(p + "_mel.npy", np.ones((80, 241), np.float32))
+    ds = md.MelDataset([f"{p}|0\n"], verbose=False)
+    with open(p + "_mel_meta.json", "w", encoding="utf-8") as fh:
+        json.dump(ds._build_mel_metadata(72000, 24000), fh, sort_keys=True)
+    assert len(ds[0]) == 5

@@ -113,3 +113,23 @@ def test_dataloader_resamples_44k_files(tmp_path, hip_device):
         assert np.abs(mels[i, 0, :, :L].cpu().numpy() - ref).max() <= 2e-3
         np.testing.assert_array_equal(f0s[i, :len(f0)].cpu().numpy(), f0)
     assert mels.shape == (2, 1, 80, 192)
+
+
+def test_dataloader_takes_cached_spectrograms(tmp_path, hip_device):
+    """meldataset.py:640-650: a whole-file item with a valid <wav>_mel.npy cache trains on the cached spectrogram
+    (bit-exact: normalised with the reference's float32 expression), its neighbours on the device mel."""
+    from tests.test_data_layer import _mel_cache_fixture
+    lines, paths, cached, _ = _mel_cache_fixture(tmp_path)
+    cfg = {"mel_params": {"sample_rate": 24000, "win_len": 1024, "n_fft": 1024, "n_mels": 80, "hop_length": 300},
+           "verbose": False}
+    loader = md.build_dataloader(lines, validation=True, batch_size=3, num_workers=2, device="cuda:0",
+                                 dataset_config=cfg)           # worker processes + pinned memory carry the extra tensors
+    (mels, f0s, sils), = list(loader)
+    mels = mels.cpu()
+    want = (torch.log(1e-5 + torch.from_numpy(cached)) + 4.0) / 4.0
+    assert torch.equal(mels[1, 0, :, :161], want) and not mels[1, 0, :, 161:].any()
+    for i in (0, 2):
+        wave, _ = md.read_wav(paths[i])
+        ref = mel_ref.log_mel(wave)
+        assert np.abs(mels[i, 0, :, :161].numpy() - ref).max() <= 1e-3
+    assert f0s.shape == (3, 192) and sils.shape == (3, 192)
