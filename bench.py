@@ -28,8 +28,15 @@ import sys
 import time
 from pathlib import Path
 
-import numpy as np
-import torch
+# Data-parallel runs: cap the HIP runtime's hardware queues at 3 (compute, weight-gradient side stream, RCCL) BEFORE
+# the runtime loads.  With the default of 4, every step that touches RCCL's stream measured +5 ms on one MI355X
+# (+11 ms without the side stream) even with identity collectives; 3 brings it to +0.3 ms
+# (tools/micro/dp_overhead.py, profiles/dp_overhead_r02.txt).
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("PE_DP_REHEARSE") == "1":
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))

@@ -7,10 +7,11 @@ buffer per optimizer step (115.5 MB fp32), divided by the world size inside the 
 kernel.  BatchNorm keeps per-replica statistics, exactly as N independent reference processes
 would (no SyncBN exists in the reference).
 
-The flat gradient buffer is reduced in a few large buckets on a dedicated HIP stream: ring
-all-reduce over point-to-point xGMI is per-link bound, so few large messages beat many small
-ones.  Buckets are issued in backward-completion order (sequence models first: 93 % of the
-bytes) as soon as JDCNet's backward signals them, and the optimizer waits on the last one.
+The flat gradient buffer is reduced in a few large buckets on RCCL's own stream: ring all-reduce
+over point-to-point xGMI is per-link bound, so few large messages beat many small ones.  Buckets
+are issued in backward-completion order (sequence models first: 93 % of the bytes) as soon as
+JDCNet's backward signals them, from the stream that produced them (no private reducer stream:
+see ``reduce_range``), and the optimizer waits on the last one.
 """
 from __future__ import annotations
 
@@ -39,6 +40,11 @@ def init_from_env(backend: str | None = None):
             backend = os.environ.get("PE_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl" and "GPU_MAX_HW_QUEUES" not in os.environ:
+            import warnings
+            warnings.warn("GPU_MAX_HW_QUEUES is unset: with the HIP default of 4 hardware queues a step that uses "
+                          "RCCL's stream measured ~5 ms slower on MI355X; export GPU_MAX_HW_QUEUES=3 before the "
+                          "process starts (bench.py / train.py do it themselves)")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -131,7 +137,8 @@ class GradientAllReduce:
         self._pending = []
         self._issued = False
         self.messages = 0                   # collectives issued so far (tests / logging)
-        self._stream = torch.cuda.Stream(device=flat_grad.device) if flat_grad.is_cuda else None
+        private = flat_grad.is_cuda and os.environ.get("PE_DP_ISSUE", "side") == "reducer"
+        self._stream = torch.cuda.Stream(device=flat_grad.device) if private else None
         if optimizer is not None:
             optimizer.grad_scale = 1.0 / self.world
         if self.active:
@@ -151,21 +158,34 @@ class GradientAllReduce:
     def reduce_range(self, lo: int, hi: int, after=None):
         """Start reducing gradient elements [lo, hi), in bucket-sized messages.  They must be final once the work
         queued so far on the current stream -- and on `after`, a second stream that also writes them (the model's
-        weight-gradient side stream) -- has run."""
+        weight-gradient side stream) -- has run.
+
+        The collectives are ISSUED from `after` once it has been made to wait for the current stream (which every
+        later piece of side work does anyway), or from the current stream when there is no `after`: RCCL's own
+        stream then waits for exactly the work that produces the range and nothing here blocks the compute stream.
+        A private reducer stream (``PE_DP_ISSUE=reducer``) measured +5.4 ms/step on one MI355X even with identity
+        collectives: one more stream made the weight-gradient overlap collapse (tools/micro/dp_overhead.py)."""
         if not self.active or hi <= lo:
             return
         self._issued = True
-        if self._stream is not None:
-            self._stream.wait_stream(torch.cuda.current_stream(self.flat_grad.device))
-            if after is not None:
-                self._stream.wait_stream(after)
-        elif after is not None:              # no reducer stream (gloo): the collective runs behind the current stream
-            torch.cuda.current_stream(self.flat_grad.device).wait_stream(after)
+        issue_on = None
+        if self.flat_grad.is_cuda:
+            cur = torch.cuda.current_stream(self.flat_grad.device)
+            if self._stream is not None:
+                self._stream.wait_stream(cur)
+                if after is not None:
+                    self._stream.wait_stream(after)
+                issue_on = self._stream
+            elif after is not None:
+                after.wait_stream(cur)
+                issue_on = after
+            else:
+                issue_on = cur
         per = max(1, self.bucket_elems)
         for a in range(lo, hi, per):
             chunk = self.flat_grad[a:min(hi, a + per)]
-            if self._stream is not None:
-                with torch.cuda.stream(self._stream):
+            if issue_on is not None:
+                with torch.cuda.stream(issue_on):
                     self._pending.append(self._all_reduce(chunk))
             else:
                 self._pending.append(self._all_reduce(chunk))

@@ -17,16 +17,21 @@ import shutil
 import sys
 from logging import StreamHandler
 
-import click
-import torch
-import torch.nn as nn
-import yaml
+# data-parallel runs: three HIP hardware queues (compute, weight-gradient side stream, RCCL), set before the
+# runtime loads -- the default of four costs ~5 ms per step once RCCL's stream is in use (see bench.py)
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("PE_DP_REHEARSE") == "1":
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")
 
-from pitchextractor_amd import distributed as pdist
-from pitchextractor_amd.meldataset import build_dataloader
-from pitchextractor_amd.model import JDCNet
-from pitchextractor_amd.optimizers import build_optimizer
-from pitchextractor_amd.trainer import Trainer
+import click  # noqa: E402
+import torch  # noqa: E402
+import torch.nn as nn  # noqa: E402
+import yaml  # noqa: E402
+
+from pitchextractor_amd import distributed as pdist  # noqa: E402
+from pitchextractor_amd.meldataset import build_dataloader  # noqa: E402
+from pitchextractor_amd.model import JDCNet  # noqa: E402
+from pitchextractor_amd.optimizers import build_optimizer  # noqa: E402
+from pitchextractor_amd.trainer import Trainer  # noqa: E402
 
 logger = logging.getLogger(__name__)
 logger.setLevel(logging.DEBUG)
