@@ -42,7 +42,7 @@ def _batch(rank, dev):
     return x.to(dev), f0.to(dev), sil.to(dev)
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, amp=False, payload=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK="0")
     from oracle import model_ref
@@ -54,11 +54,13 @@ def _worker(rank, world, port, out_dir):
     torch.cuda.set_device(dev)
     state = model_ref.seeded_state(3, hidden_size=64, num_layers=2)
     net, opt, sched = _make(state, dev)
-    dp = pdist.GradientAllReduce(net.flat_gradients(), opt, flat_param=net.flat_parameters, bucket_bytes=1 << 20)
+    dp = pdist.GradientAllReduce(net.flat_gradients(), opt, flat_param=net.flat_parameters, bucket_bytes=1 << 20,
+                                 payload=payload)
     net.attach_data_parallel(dp)
     crit = {"l1": torch.nn.SmoothL1Loss(), "ce": torch.nn.BCEWithLogitsLoss()}
     tr = Trainer(model=net, criterion=crit, optimizer=opt, scheduler=sched, device="cuda:0",
-                 loss_config={"lambda_f0": 0.1}, logger=logging.getLogger("dp"), data_parallel=dp)
+                 loss_config={"lambda_f0": 0.1}, logger=logging.getLogger("dp"), data_parallel=dp,
+                 use_mixed_precision=amp)
     tr.run(_batch(rank, dev))
     torch.cuda.synchronize()
     mine = net.flat_parameters.detach().cpu().numpy()
@@ -69,14 +71,20 @@ def _worker(rank, world, port, out_dir):
         for r in range(world):
             n2, _, _ = _make(state, dev)
             x, f0, sil = _batch(r, dev)
-            cls, det = n2(x.transpose(-1, -2))
+            with ops.matmul_bf16(amp, "bf16"):
+                cls, det = n2(x.transpose(-1, -2))
             _, d_f0, d_sil = ops.f0_sil_loss(cls.detach().reshape(-1), f0.reshape(-1), det.detach().reshape(-1),
                                              sil.reshape(-1), 0.1)
-            torch.autograd.backward([cls, det], [d_f0.view_as(cls), d_sil.view_as(det)])
+            with ops.matmul_bf16(amp, "bf16"):
+                torch.autograd.backward([cls, det], [d_f0.view_as(cls), d_sil.view_as(det)])
             grads.append(n2.flat_gradients().clone())
         ref, ropt, _ = _make(state, dev)
         ref._grad_views()
-        ref.flat_gradients().copy_((grads[0] + grads[1]) * 0.5)
+        if payload == "bf16":       # what the collective computes: bf16-rounded replicas summed in bf16
+            total = (grads[0].to(torch.bfloat16) + grads[1].to(torch.bfloat16)).float()
+        else:
+            total = grads[0] + grads[1]
+        ref.flat_gradients().copy_(total * 0.5)
         ropt.step()
         np.save(os.path.join(out_dir, "ref.npy"), ref.flat_parameters.detach().cpu().numpy())
     dist.barrier()
@@ -90,6 +98,15 @@ def test_two_rank_step_equals_mean_gradient_update(tmp_path):
     # (g0 + g1) summed by gloo then scaled inside AdamW vs averaged first: a few ulps apart
     np.testing.assert_allclose(p0, ref, rtol=1e-5, atol=1e-7)
     assert not np.array_equal(p0, np.zeros_like(p0))
+
+
+def test_two_rank_mixed_precision_step_with_bf16_buckets(tmp_path):
+    """BASELINE config[3]'s shape on one GPU: mixed-precision (bf16 operand) replicas exchanging bf16 gradient
+    buckets.  The update must equal AdamW on half the bf16 sum of the bf16-rounded per-replica gradients."""
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), True, "bf16"), nprocs=2, join=True)
+    p0, p1, ref = (np.load(tmp_path / n) for n in ("p0.npy", "p1.npy", "ref.npy"))
+    assert np.array_equal(p0, p1)
+    np.testing.assert_allclose(p0, ref, rtol=1e-5, atol=1e-7)
 
 
 def _rccl_worker(rank, world, port, out_dir):
