@@ -23,7 +23,7 @@ import torch.distributed as dist
 
 def rehearse_single_rank() -> bool:
     """``PE_DP_REHEARSE=1``: run the whole data-parallel wiring (process group, broadcasts, bucketed all-reduce on
-    the reducer stream, cross-rank flags) even at world size 1, so a one-GPU box executes the RCCL code path that
+    the issuing stream, cross-rank flags) even at world size 1, so a one-GPU box executes the RCCL code path that
     the multi-GPU launch uses (a sum over one rank is the identity: results must equal the plain run bit for bit)."""
     return os.environ.get("PE_DP_REHEARSE", "0") == "1"
 
@@ -116,7 +116,7 @@ class GradientAllReduce:
     ``flat_grad`` is the model's flat gradient tensor (``JDCNet.flat_gradients()``);
     ``optimizer.grad_scale`` is set to 1/world so the mean is taken inside the AdamW kernel.
     ``payload="bf16"`` (or ``PE_DP_PAYLOAD=bf16``; BASELINE config[3]) halves the bytes on xGMI: each bucket is
-    rounded to bf16 on the reducer stream, summed in bf16 by the collective and widened back into the fp32 buffer
+    rounded to bf16 on the issuing stream, summed in bf16 by the collective and widened back into the fp32 buffer
     before the optimizer reads it (115.5 MB -> 57.8 MB per step; the sum of `world` bf16 terms carries ~8 bits, so
     this is an opt-in that belongs with mixed-precision training, never the fp32 parity path)."""
 
@@ -163,8 +163,8 @@ class GradientAllReduce:
         The collectives are ISSUED from `after` once it has been made to wait for the current stream (which every
         later piece of side work does anyway), or from the current stream when there is no `after`: RCCL's own
         stream then waits for exactly the work that produces the range and nothing here blocks the compute stream.
-        A private reducer stream (``PE_DP_ISSUE=reducer``) measured +5.4 ms/step on one MI355X even with identity
-        collectives: one more stream made the weight-gradient overlap collapse (tools/micro/dp_overhead.py)."""
+        A private reducer stream (``PE_DP_ISSUE=reducer``) measured 0.5-1 ms/step worse (tools/micro/dp_overhead.py);
+        the large effect found there is the hardware-queue count, see bench.py / DESIGN section 5."""
         if not self.active or hi <= lo:
             return
         self._issued = True
@@ -208,7 +208,7 @@ class GradientAllReduce:
         for work, stage, chunk in self._pending:
             work.wait()                      # RCCL: the current stream waits for the collective; gloo: the host does
             if stage is not None:
-                if stage.is_cuda:            # allocated on the reducer stream, read here on the compute stream
+                if stage.is_cuda:            # allocated on the issuing stream, read here on the compute stream
                     stage.record_stream(torch.cuda.current_stream(stage.device))
                 chunk.copy_(stage)           # widen the bf16 sum back into the fp32 gradient buffer
         self._pending = []
