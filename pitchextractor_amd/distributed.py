@@ -199,6 +199,17 @@ class GradientAllReduce:
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return bool(int(t.item()))
 
+    def any_rank_word(self, word) -> bool:
+        """`any_rank` for a status that already lives on the device (`word`: 1-element integer tensor, or None when
+        this process has none -- the same on every rank): max-reduced copy, ONE host read for flag and agreement."""
+        if word is None:
+            return False
+        if not self.active:
+            return bool(int(word.item()) != 0)
+        t = (word != 0).to(torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return bool(int(t.item()))
+
     def finish(self):
         """Reduce whatever has not been issued yet and make the compute stream wait for all of it."""
         if not self.active:

@@ -565,6 +565,13 @@ def persistent_lstm_error(device) -> bool:
     return bool(buf is not None and int(buf[0].item()) != 0)
 
 
+def persistent_lstm_error_word(device):
+    """The sticky barrier-timeout word as a 1-element device tensor (None before any persistent launch): a
+    data-parallel trainer max-reduces it across ranks and reads it once (distributed.GradientAllReduce.any_rank_word)."""
+    buf = _SYNC.get(torch.device(device))
+    return None if buf is None else buf[0:1]
+
+
 def clear_persistent_lstm_error(device) -> None:
     """Reset the sticky barrier-timeout word (the persistent kernels skip their waits while it is set)."""
     buf = _SYNC.get(torch.device(device))

@@ -220,13 +220,16 @@ class Trainer(object):
             self.data_parallel.finish()
         return out3
 
-    def _lstm_fault(self, device) -> bool:
+    def _lstm_fault(self, device, collective=True) -> bool:
         """True when a persistent-LSTM group barrier timed out in this step on ANY rank (then every rank's
         results are suspect or its peers would deadlock in the next all-reduce).  Clears the sticky word and
-        switches this process to the one-launch-per-time-step kernels."""
-        bad = ops.persistent_lstm_error(device)
-        if self.data_parallel is not None and self.data_parallel.active:
-            bad = self.data_parallel.any_rank(bad)
+        switches this process to the one-launch-per-time-step kernels.  ``collective=False`` (evaluation: ranks
+        may hold different numbers of validation batches, so nothing there may be a collective) looks at this
+        rank's word only."""
+        if collective and self.data_parallel is not None and self.data_parallel.active:
+            bad = self.data_parallel.any_rank_word(ops.persistent_lstm_error_word(device))   # one host read
+        else:
+            bad = ops.persistent_lstm_error(device)
         if bad:
             ops.clear_persistent_lstm_error(device)
             ops.USE_PERSISTENT_LSTM = False
@@ -283,7 +286,7 @@ class Trainer(object):
         x, f0, sil = self._inputs(batch)
         with ops.matmul_bf16(self.use_amp, self.amp_dtype):
             f0_pred, sil_pred = self.model(x.transpose(-1, -2))
-        if self._lstm_fault(x.device):
+        if self._lstm_fault(x.device, collective=False):
             with ops.matmul_bf16(self.use_amp, self.amp_dtype):
                 f0_pred, sil_pred = self.model(x.transpose(-1, -2))
         out3, _, _ = self._loss(f0_pred, sil_pred, f0, sil, False)

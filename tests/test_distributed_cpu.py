@@ -80,6 +80,9 @@ def _epoch_worker(rank, world, port, out_dir):
     stats = pdist.mean_over_ranks({"eval/loss": float(rank + 1)}, weight=float(rank + 1))
     assert abs(stats["eval/loss"] - (1 * 1 + 2 * 2) / 3.0) < 1e-12
     assert pdist.GradientAllReduce(torch.zeros(4), None).any_rank(rank == 1) is True
+    dpw = pdist.GradientAllReduce(torch.zeros(4), None)
+    assert dpw.any_rank_word(torch.tensor([7 if rank == 1 else 0], dtype=torch.int32)) is True     # one rank faulted
+    assert dpw.any_rank_word(torch.zeros(1, dtype=torch.int32)) is False and dpw.any_rank_word(None) is False
     np.save(os.path.join(out_dir, f"seen{rank}.npy"), np.array(seen))
     dist.destroy_process_group()
 

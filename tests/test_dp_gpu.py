@@ -65,6 +65,12 @@ def _worker(rank, world, port, out_dir, amp=False, payload=None):
     torch.cuda.synchronize()
     mine = net.flat_parameters.detach().cpu().numpy()
     np.save(os.path.join(out_dir, f"p{rank}.npy"), mine)
+    # validation shards may differ by a batch between ranks: evaluation must not contain a collective
+    net.eval()
+    for _ in range(2 - rank):
+        ev = tr._eval_step(_batch(rank, dev))
+        assert np.isfinite(ev["loss"])
+    net.train()
     if rank == 0:
         # oracle for DP: mean of the per-replica gradients, each from a fresh replica with local-batch BN
         grads = []
