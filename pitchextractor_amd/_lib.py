@@ -146,6 +146,12 @@ def load():
         raise HipLibraryError(
             f"{LIB_PATH} not found: build it with `python -m pitchextractor_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # One HIP runtime per process: torch bundles its own libamdhip64 (same SONAME as /opt/rocm's, but its
+    # libraries ask for it by the unversioned file name, so it is loaded even when /opt/rocm's copy already
+    # is).  Loading this library first therefore left TWO runtimes in the process, and the second to open the
+    # device reported hipErrorNoDevice (seen with build() followed by smoke() in one interpreter).  With torch
+    # imported first, this library's DT_NEEDED libamdhip64.so.7 resolves to the copy torch already loaded.
+    import torch  # noqa: F401
     lib = C.CDLL(str(LIB_PATH))
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)
