@@ -140,6 +140,25 @@ def _family_table(summ, steps, step_ms):
     return rows
 
 
+class _QuietStdout:
+    """Native libraries write to file descriptor 1 behind Python's back (RCCL prints a five-line version banner when
+    its first communicator is created), and the contract is ONE JSON line on stdout: everything this process writes
+    to fd 1 goes to stderr instead, except inside `line()`."""
+
+    def __init__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def line(self, text):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        try:
+            print(text, flush=True)
+        finally:
+            os.dup2(2, 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,6 +188,7 @@ def main():
     ap.add_argument("--host-steps", type=int, default=None,
                     help="extra steps fed from pinned host memory with double-buffered H2D (default: --steps; 0 = skip)")
     args = ap.parse_args()
+    quiet = _QuietStdout()
     bf16 = args.precision == "bf16"
 
     from pitchextractor_amd import distributed as pdist
@@ -383,7 +403,7 @@ def main():
         }
         if dp is not None:
             line["config"]["gradient_allreduce"] = {
-                "backend": dist.get_backend(), "payload": dp.payload, "bucket_bytes": 32 << 20,
+                "backend": dist.get_backend(), "payload": dp.payload, "bucket_bytes": dp.bucket_elems * (2 if dp.payload == "bf16" else 4),
                 "bytes_per_step": net.flat_gradients().numel() * (2 if dp.payload == "bf16" else 4),
                 "messages_per_step": dp.messages / max(1, tr._runs),
                 "rehearsal_world1": bool(world == 1)}
@@ -401,7 +421,7 @@ def main():
             line["fp32_native_mfma"] = native_ref
         if world == 1 and not args.no_cpu_baseline and args.head == "bilstm" and not bf16:
             line["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(line), flush=True)
+        quiet.line(json.dumps(line))
     if dp_on:
         dist.destroy_process_group()
 
