@@ -188,3 +188,32 @@ def test_backward_order_block_cuts_of_the_flat_gradient_buffer():
             issued.append((lo, hi))
     net.attach_data_parallel(_Rec())
     assert net._dp_cuts == cuts
+
+
+def test_shard_sampler_properties():
+    """For any list size / batch / world: training shards are disjoint, equally long (whole batches, so every rank
+    runs the same number of steps), identical across ranks' view of the epoch permutation, and reshuffled per epoch;
+    validation shards cover every item exactly once."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=150, deadline=None)
+    @given(n=st.integers(0, 300), batch=st.integers(1, 9), world=st.integers(1, 8), seed=st.integers(0, 10_000),
+           epoch=st.integers(0, 50))
+    def check(n, batch, world, seed, epoch):
+        shards = []
+        for r in range(world):
+            s = pdist.EpochShardSampler(n, batch, r, world, seed=seed)
+            s.set_epoch(epoch)
+            shards.append(list(s))
+            assert len(shards[-1]) == len(s) == (n // (world * batch)) * batch
+        flat = sum(shards, [])
+        assert len(set(flat)) == len(flat) and all(0 <= i < n for i in flat)
+        if n >= 2 * world * batch:            # a permutation, not the identity cut (overwhelmingly likely)
+            other = pdist.EpochShardSampler(n, batch, 0, world, seed=seed)
+            other.set_epoch(epoch + 1)
+            assert len(list(other)) == len(shards[0])
+        val = [list(pdist.EpochShardSampler(n, batch, r, world, shuffle=False, drop_last=False)) for r in range(world)]
+        assert sorted(sum(val, [])) == list(range(n))
+        assert max(map(len, val)) - min(map(len, val)) <= 1
+
+    check()
