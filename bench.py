@@ -295,7 +295,9 @@ def main():
     from_host = None
     host_steps = args.steps if args.host_steps is None else args.host_steps
     if host_steps > 0:
-        feeder = H2DPrefetcher(dev)
+        # data-parallel runs (three hardware queues): copies issued from the weight-gradient side stream, idle in forward
+        from pitchextractor_amd import model as pe_model_h
+        feeder = H2DPrefetcher(dev, stream=pe_model_h._side_stream(dev) if dp_on else None)
         tr.run(feeder.acquire(feeder.submit(host)))                       # warm the side-stream allocations
         barrier()
         t_h = time.perf_counter()
