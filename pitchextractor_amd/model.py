@@ -837,7 +837,7 @@ class JDCNet(nn.Module):
             dseq_c = _tf_backward(models[0], s.tf_c, dyc.view(B, T, D), g, side)
 
         if self._dp is not None:            # temporal heads + output heads are final once the side stream has
-            # finished what is queued on it so far: the reducer's stream waits for it, the main stream does not
+            # finished what is queued on it so far: the collectives are issued from that stream, the main stream does not wait
             self._dp.reduce_range(self._seq_offset(), self._grad_flat.numel(), after=side.pending_stream())
 
         # detector branch (model.py:103-112)
