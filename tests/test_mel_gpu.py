@@ -98,3 +98,29 @@ def test_rejects_bad_arguments(hip_device):
         tf(torch.zeros(512, device=hip_device))          # reflect pad needs N > n_fft/2
     with pytest.raises(RuntimeError):
         MelSpectrogram(n_fft=2048, win_length=2048)(torch.zeros(4800, device=hip_device))
+
+
+def test_error_against_float64_is_that_of_the_reference_arithmetic(hip_device):
+    """Why the log-mel tolerance is 1e-3 and not the north star's 1e-4: measured against the float64 oracle, the
+    REFERENCE's own fp32 arithmetic (torch.stft in float32 + float32 filterbank product, what torchaudio runs,
+    `mel_ref.mel_spectrogram_torch_stft`) is off by the same amount on the bins near the 1e-5 log floor.  The HIP
+    kernel must be no further from exact arithmetic than twice that CPU fp32 path, on sweeps and on noise."""
+    rng = np.random.default_rng(7)
+    waves = [synthetic.utterance(i, duration=2.0)[0] for i in (0, 5)]
+    waves.append((0.3 * rng.standard_normal(48000)).astype(np.float32))
+    tf = MelSpectrogram(**mel_ref.DEFAULT_MEL_PARAMS)
+    worst_hip = worst_cpu = worst_hip_pow = worst_cpu_pow = 0.0
+    for w in waves:
+        ref64 = mel_ref.mel_spectrogram(w)
+        cpu32 = np.asarray(mel_ref.mel_spectrogram_torch_stft(w), dtype=np.float64)
+        hip32 = tf(torch.from_numpy(w).to(hip_device)).cpu().numpy().astype(np.float64)
+        l64 = mel_ref.log_normalise(ref64)
+        worst_cpu = max(worst_cpu, np.abs(mel_ref.log_normalise(cpu32) - l64).max())
+        worst_hip = max(worst_hip, np.abs(mel_ref.log_normalise(hip32) - l64).max())
+        strong = ref64 >= 1e-2
+        worst_cpu_pow = max(worst_cpu_pow, (np.abs(cpu32 - ref64)[strong] / ref64[strong]).max())
+        worst_hip_pow = max(worst_hip_pow, (np.abs(hip32 - ref64)[strong] / ref64[strong]).max())
+    print(f"log-mel max |err| vs float64: HIP {worst_hip:.2e}, CPU fp32 torch.stft {worst_cpu:.2e}; "
+          f"power rel err on bins >= 1e-2: HIP {worst_hip_pow:.2e}, CPU fp32 {worst_cpu_pow:.2e}")
+    assert worst_hip <= max(2.0 * worst_cpu, 1e-4)
+    assert worst_hip_pow <= max(2.0 * worst_cpu_pow, 1e-5)
