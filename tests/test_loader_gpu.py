@@ -133,3 +133,34 @@ def test_dataloader_takes_cached_spectrograms(tmp_path, hip_device):
         ref = mel_ref.log_mel(wave)
         assert np.abs(mels[i, 0, :, :161].numpy() - ref).max() <= 1e-3
     assert f0s.shape == (3, 192) and sils.shape == (3, 192)
+
+
+def test_full_size_resample_and_mel_config4_shape(hip_device):
+    """BASELINE config[4]'s front end at its real size: 256 utterances of 4 s at 44.1 kHz (176 400 samples) ->
+    GPU resample (147 -> 80) -> ragged mel with a random 192-frame crop per item.  Size-independent properties
+    (power-of-two scaling is exact, tiled replicas agree bit for bit) plus three rows against the float64 oracles."""
+    from oracle import resample_ref as rr
+    from pitchextractor_amd.resample import Resampler
+    rng = np.random.default_rng(3)
+    n_src = 4 * 44100
+    t = np.arange(n_src) / 44100.0
+    base = np.stack([(0.4 * np.sin(2 * np.pi * (110.0 + 37.0 * i) * t * (1.0 + 0.1 * t))
+                      + 0.01 * rng.standard_normal(n_src)).astype(np.float32) for i in range(8)])
+    x = torch.from_numpy(np.tile(base, (32, 1))).to(hip_device)                  # (256, 176400)
+    rs = Resampler(44100, 24000)
+    y = rs(x)
+    assert y.shape == (256, rs.out_len(n_src)) == (256, 96000)
+    assert torch.equal(rs(x * 2.0), y * 2.0)                                      # linear, power-of-two exact
+    assert torch.equal(y[:8], y[248:])                                            # no cross-row leakage at full size
+    for i in (0, 3, 7):
+        ref = rr.resample(base[i], 44100, 24000)
+        assert np.abs(y[i].cpu().numpy() - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max())
+    tf = MelSpectrogram(**mel_ref.DEFAULT_MEL_PARAMS)
+    lengths = torch.full((256,), 96000, dtype=torch.int32, device=hip_device)
+    crops_host = np.tile(rng.integers(0, 321 - 192, size=8), 32).astype(np.int32)
+    crops = torch.from_numpy(crops_host).to(hip_device)
+    mels = tf.log_mel_ragged(y, lengths, crops, max_frames=192)
+    assert mels.shape == (256, 1, 80, 192) and torch.equal(mels[:8], mels[248:])
+    for i in (0, 3, 7):
+        ref = mel_ref.log_mel(rr.resample(base[i], 44100, 24000))[:, crops_host[i]:crops_host[i] + 192]
+        assert np.abs(mels[i, 0].cpu().numpy() - ref).max() <= 2e-3
