@@ -134,7 +134,8 @@ def _family_table(summ, steps, step_ms):
                 # the entry point's suffix names the pipe its products ran on
                 base = name.split("#")[0]           # "#tag": ops.timer_tag (e.g. the overlapped dgrad launches)
                 peak = (MFMA_BF16_PEAK_TFLOPS if base.endswith("_bf16") else
-                        MFMA_BF16_PEAK_TFLOPS / 6.0 if base.endswith("_x3") else MFMA_F32_PEAK_TFLOPS)
+                        MFMA_BF16_PEAK_TFLOPS / 6.0 if base.endswith("_x3") else
+                        MFMA_BF16_PEAK_TFLOPS / 3.0 if base.endswith("_h2") else MFMA_F32_PEAK_TFLOPS)
                 row.update(bound="mfma", achieved_tflops=rate / 1e12, peak_tflops=peak, frac_of_peak=rate / 1e12 / peak)
         rows[name] = row
     return rows
@@ -171,9 +172,10 @@ def main():
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
                     help="fp32 = BASELINE config[1] (headline); bf16 = training.mixed_precision "
                          "(bf16 MFMA operands, fp32 accumulate/state) = BASELINE configs[2]/[3]")
-    ap.add_argument("--fp32-matmul", choices=["native", "x3"], default=None,
-                    help="fp32 products on v_mfma_f32_32x32x2_f32 (native) or as an exact three-term bf16 split "
-                         "on the bf16 MFMA pipe (x3, fp32-accurate); default: PE_FP32_MATMUL or the library default")
+    ap.add_argument("--fp32-matmul", choices=["native", "x3", "h2"], default=None,
+                    help="fp32 products on v_mfma_f32_32x32x2_f32 (native), as an exact three-term bf16 split (x3: six "
+                         "bf16 MFMAs per block) or as two scaled fp16 terms (h2: three fp16 MFMAs per block); "
+                         "default: PE_FP32_MATMUL or the library default (h2)")
     ap.add_argument("--no-native-ref", action="store_true",
                     help="skip the 7 extra steps that time the native fp32 MFMA form for the fp32_native_mfma field")
     ap.add_argument("--family-timing", action="store_true",
@@ -248,8 +250,10 @@ def main():
             print(f"[bench] warmup {i}: {time.perf_counter() - t_w:.3f} s loss {last['loss']:.4f}", file=sys.stderr,
                   flush=True)
     barrier()
-    x3 = ops.FP32_MATMUL == "x3"
-    sfx = "_bf16" if bf16 else "_x3" if x3 else ""
+    x3 = ops.FP32_MATMUL in ("x3", "h2")        # fp32 results from split 16-bit terms on the bf16 / fp16 MFMA pipe
+    h2 = ops.FP32_MATMUL == "h2"
+    fp32_mode = ops.FP32_MATMUL
+    sfx = "_bf16" if bf16 else "_h2" if h2 else "_x3" if x3 else ""
     conv_key = "pe_conv3x3_fwd" + sfx
     conv_keys = {conv_key, "pe_conv3x3_fwd_wf" + sfx}       # weights staged through LDS / fed as fragments from L2
     ops.TIMER = ops.KernelTimer(None if args.family_timing else conv_keys | {"pe_mel_forward"})
@@ -333,7 +337,7 @@ def main():
             native_ref = {"ms_per_step": ms_n, "value": args.batch * FRAMES / (ms_n * 1e-3), "unit": "mel-frames/s",
                           "steps": 5, "note": "PE_FP32_MATMUL=native: v_mfma_f32_32x32x2_f32 for every fp32 product"}
         finally:
-            ops.FP32_MATMUL = "x3"
+            ops.FP32_MATMUL = fp32_mode
 
     if rank == 0:
         frames = args.batch * world * FRAMES * args.steps
@@ -360,6 +364,10 @@ def main():
             tflops = conv["work"] / (conv["total_ms"] * 1e-3) / 1e12        # algorithmic 2*M*N*K per launch
             if bf16:
                 peak, note = MFMA_BF16_PEAK_TFLOPS, "bf16 dense MFMA peak"
+            elif h2:
+                peak, note = MFMA_BF16_PEAK_TFLOPS / 3.0, ("fp32 product = 3 fp16 MFMAs (two scaled fp16 terms per operand): "
+                                                           "fp16 dense MFMA peak / 3 (builder-defined ceiling); the "
+                                                           f"native fp32 MFMA peak is {MFMA_F32_PEAK_TFLOPS} TFLOP/s")
             elif x3:
                 peak, note = MFMA_BF16_PEAK_TFLOPS / 6.0, ("fp32 product = 6 bf16 MFMAs (exact 3-term split): "
                                                            "bf16 dense MFMA peak / 6 (builder-defined ceiling); the "

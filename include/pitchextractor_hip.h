@@ -92,6 +92,20 @@ int pe_gemm_nt_bf16(const float* A, long lda, const float* B, long ldb, float* C
  * below 2^-23 of each product, i.e. under the rounding of an fp32 product.  Same contract as pe_gemm_nt. */
 int pe_gemm_nt_x3(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
                   int K, const float* bias0, const float* bias1, int accumulate, void* stream);
+/* "h2": fp32 products from TWO fp16 terms per operand and three fp16 MFMAs per product block (half the matrix work of
+ * the x3 split).  x * s = hi + lo with hi = RN_f16(x s), lo = RN_f16(x s - hi); hi_a lo_b + lo_a hi_b + hi_a hi_b is
+ * accumulated in fp32 and lo_a lo_b (<= 2^-24 |a b|) dropped: per-product error <= 2^-21 |a b|, unbiased.  Each
+ * operand tensor carries a power-of-two scale s = 2^(140 - E), E = biased exponent of its largest magnitude, which
+ * the kernel derives from *amax_a / *amax_b (device words holding the IEEE bits of max |x|: pe_absmax, or the
+ * epilogue of the kernel that produced the tensor); a value smaller than the tensor's true maximum makes fp16
+ * overflow possible, a larger one only costs resolution (2^-38 of the stated maximum, absolute).  Same contract as
+ * pe_gemm_nt otherwise. */
+int pe_gemm_nt_h2(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
+                  int K, const float* bias0, const float* bias1, int accumulate, const unsigned* amax_a,
+                  const unsigned* amax_b, void* stream);
+/* out[0] = IEEE bits of max |x| over a [rows][cols] matrix with leading dimension ld (cols, ld % 4 == 0, x 16-byte
+ * aligned); zeroes out[0] first.  Exact and order-independent (integer max of the magnitudes' bit patterns). */
+int pe_absmax(const float* x, long rows, int cols, long ld, unsigned* out, void* stream);
 /* pe_gemm_nt_wf_*: the same product with B given as pe_wfrag_pack(B, ldb, N, K, terms) (see the convolution
  * section): the weight operand comes from L2 in MFMA fragment order, only A is staged through LDS. */
 int pe_gemm_nt_wf_x3(const float* A, long lda, const void* wfrag, float* C, long ldc, int M, int N, int K,
@@ -114,6 +128,9 @@ int pe_gemm_tn_x3(const float* A, long lda, const float* B, long ldb, float* C, 
                   int K, int accumulate, float* workspace, size_t workspace_bytes, void* stream);
 int pe_gemm_tn_bf16(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
                     int K, int accumulate, float* workspace, size_t workspace_bytes, void* stream);  /* mixed precision */
+int pe_gemm_tn_h2(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
+                  int K, int accumulate, float* workspace, size_t workspace_bytes, const unsigned* amax_a,
+                  const unsigned* amax_b, void* stream);   /* two-term fp16 split, see pe_gemm_nt_h2 */
 int pe_transpose2d(const float* in, float* out, int rows, int cols, void* stream);
 
 /* ---- 3x3 / pad 1 convolutions (model.py:23-28,157-161), channels-last -------
@@ -130,6 +147,9 @@ int pe_conv3x3_fwd_bf16(const float* x, const float* w_packed, float* y, int B, 
                         int accumulate, void* stream);   /* bf16 operands, fp32 accumulate (see pe_gemm_nt_bf16) */
 int pe_conv3x3_fwd_x3(const float* x, const float* w_packed, float* y, int B, int T, int F, int C, int N,
                       int accumulate, void* stream);     /* fp32-accurate, three-term bf16 split (see pe_gemm_nt_x3) */
+int pe_conv3x3_fwd_h2(const float* x, const float* w_packed, float* y, int B, int T, int F, int C, int N,
+                      int accumulate, const unsigned* amax_x, const unsigned* amax_w,
+                      void* stream);                       /* two scaled fp16 terms (see pe_gemm_nt_h2) */
 /* Weights pre-packed as MFMA B-operand fragments (x3: three exact bf16 terms, terms = 3; mixed precision: one
  * RNE-rounded term, terms = 1).  w is [N][K] row-major fp32 (K % 16 == 0); fragment (kb, nb, term) holds, for
  * lane 32 h + r, w[32 nb + r][16 kb + 8 h .. + 7] in 16 bytes, the 64 lanes contiguous (1 KB).  The halo
@@ -137,9 +157,14 @@ int pe_conv3x3_fwd_x3(const float* x, const float* w_packed, float* y, int B, in
  * pe_conv3x3_wf_supported: 1 if (F, C, N) is served by the fragment-fed kernel (else use pe_conv3x3_fwd_*). */
 size_t pe_wfrag_bytes(int N, int K, int terms);
 int pe_wfrag_pack(const float* w, long ld, int N, int K, int terms, void* wfrag, void* stream);
+/* "h2" form: two fp16 terms of w * 2^(140 - E) per weight, E from *amax (pe_absmax of w); pe_wfrag_bytes(N, K, 2). */
+int pe_wfrag_pack_h2(const float* w, long ld, int N, int K, const unsigned* amax, void* out, void* stream);
 int pe_conv3x3_wf_supported(int F, int C, int N);
 int pe_conv3x3_fwd_wf_x3(const float* x, const void* wfrag, float* y, int B, int T, int F, int C, int N,
                          int accumulate, double* bn_partials, void* stream);
+int pe_conv3x3_fwd_wf_h2(const float* x, const void* wfrag, float* y, int B, int T, int F, int C, int N,
+                         int accumulate, double* bn_partials, const unsigned* amax_x, const unsigned* amax_w,
+                         void* stream);                    /* wfrag from pe_wfrag_pack_h2 with the same *amax_w */
 int pe_conv3x3_fwd_wf_bf16(const float* x, const void* wfrag, float* y, int B, int T, int F, int C, int N,
                            int accumulate, double* bn_partials, void* stream);
 /* bn_partials (optional): [pe_conv3x3_wf_stat_parts(B,T,F)][2][N] doubles -- per pixel tile, the column sums and sums
@@ -151,6 +176,9 @@ int pe_conv3x3_wgrad(const float* x, const float* dy, float* dw_oihw, int B, int
                      int Cout, float* workspace, size_t workspace_bytes, void* stream);
 int pe_conv3x3_wgrad_x3(const float* x, const float* dy, float* dw_oihw, int B, int T, int F, int Cin,
                         int Cout, float* workspace, size_t workspace_bytes, void* stream);
+int pe_conv3x3_wgrad_h2(const float* x, const float* dy, float* dw_oihw, int B, int T, int F, int Cin, int Cout,
+                        float* workspace, size_t workspace_bytes, const unsigned* amax_x, const unsigned* amax_dy,
+                        void* stream);
 int pe_conv3x3_wgrad_bf16(const float* x, const float* dy, float* dw_oihw, int B, int T, int F, int Cin,
                           int Cout, float* workspace, size_t workspace_bytes, void* stream);   /* mixed precision */
 /* first convolution (1 -> 64 channels).  bn_partials (nullable): [pe_conv3x3_c1_stat_parts()][2][64] doubles that
@@ -292,6 +320,9 @@ int pe_lstm_whh_grad(const float* dgates, const float* y, long ldy, float* dwhh,
                      int reverse, float* workspace, size_t workspace_bytes, void* stream);
 int pe_lstm_whh_grad_x3(const float* dgates, const float* y, long ldy, float* dwhh, int B, int T, int H,
                      int reverse, float* workspace, size_t workspace_bytes, void* stream);   /* three-term bf16 split */
+int pe_lstm_whh_grad_h2(const float* dgates, const float* y, long ldy, float* dwhh, int B, int T, int H, int reverse,
+                        float* workspace, size_t workspace_bytes, const unsigned* amax_dgates, const unsigned* amax_y,
+                        void* stream);
 int pe_lstm_whh_grad_bf16(const float* dgates, const float* y, long ldy, float* dwhh, int B, int T, int H,
                      int reverse, float* workspace, size_t workspace_bytes, void* stream);   /* mixed precision */
 size_t pe_colsum_workspace_bytes(int cols);

@@ -42,6 +42,8 @@ PROTOTYPES = {
     "pe_gemm_nt": (_i, [_p, _l, _p, _l, _p, _l, _i, _i, _i, _p, _p, _i, _p]),
     "pe_gemm_nt_bf16": (_i, [_p, _l, _p, _l, _p, _l, _i, _i, _i, _p, _p, _i, _p]),
     "pe_gemm_nt_x3": (_i, [_p, _l, _p, _l, _p, _l, _i, _i, _i, _p, _p, _i, _p]),
+    "pe_gemm_nt_h2": (_i, [_p, _l, _p, _l, _p, _l, _i, _i, _i, _p, _p, _i, _p, _p, _p]),
+    "pe_absmax": (_i, [_p, _l, _i, _l, _p, _p]),
     "pe_gemm_nt_wf_x3": (_i, [_p, _l, _p, _p, _l, _i, _i, _i, _p, _p, _i, _p]),
     "pe_gemm_nt_wf_bf16": (_i, [_p, _l, _p, _p, _l, _i, _i, _i, _p, _p, _i, _p]),
     "pe_gemm_nt_wf_ablate": (_i, [_i, _p, _l, _p, _p, _l, _i, _i, _i, _p]),
@@ -50,12 +52,18 @@ PROTOTYPES = {
     "pe_gemm_tn": (_i, [_p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _p, _z, _p]),
     "pe_gemm_tn_x3": (_i, [_p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _p, _z, _p]),
     "pe_gemm_tn_bf16": (_i, [_p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _p, _z, _p]),
+    "pe_gemm_tn_h2": (_i, [_p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _p, _z, _p, _p, _p]),
     "pe_transpose2d": (_i, [_p, _p, _i, _i, _p]),
     "pe_conv3x3_repack": (_i, [_p, _p, _p, _i, _i, _p]),
     "pe_conv3x3_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "pe_conv3x3_fwd_bf16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "pe_conv3x3_fwd_x3": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "pe_conv3x3_fwd_h2": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "pe_wfrag_bytes": (_z, [_i, _i, _i]),
+    "pe_wfrag_pack_h2": (_i, [_p, _l, _i, _i, _p, _p, _p]),
+    "pe_conv3x3_fwd_wf_h2": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "pe_conv3x3_wgrad_h2": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p, _p, _p]),
+    "pe_lstm_whh_grad_h2": (_i, [_p, _p, _l, _p, _i, _i, _i, _i, _p, _z, _p, _p, _p]),
     "pe_wfrag_pack": (_i, [_p, _l, _i, _i, _i, _p, _p]),
     "pe_conv3x3_wf_supported": (_i, [_i, _i, _i]),
     "pe_conv3x3_fwd_wf_x3": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),

@@ -53,7 +53,8 @@ struct ConvEpi {
 
 template <class TL, int MODE>
 __global__ __launch_bounds__(256) void conv3x3_kernel(ConvLoader<TL::A_LOADS> al, RowLoader bl, ConvEpi ep,
-                                                      int K, int tiles_m, int tiles_n) {
+                                                      int K, int tiles_m, int tiles_n, const unsigned* amax_x,
+                                                      const unsigned* amax_w) {
   __shared__ __attribute__((aligned(16))) float As[TL::BM * nt_row_floats<MODE>()];
   __shared__ __attribute__((aligned(16))) float Bs[TL::BN * nt_row_floats<MODE>()];
   const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
@@ -62,20 +63,23 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvLoader<TL::A_LOADS> al
   bl.init(n0);
   f32x16 acc[TL::TM][TL::TN];
   zero_acc<TL>(acc);
-  nt_mainloop_mode<TL, MODE>(al, bl, K, As, Bs, acc);
-  for_each_acc<TL>(acc, [&](int r, int c, float v) { ep(m0 + r, n0 + c, v); });
+  H2Scales hs{1.f, 1.f, 1.f};
+  if constexpr (MODE == kSplit2) hs.load(amax_x, amax_w);
+  nt_mainloop_mode<TL, MODE>(al, bl, K, As, Bs, acc, hs.sa, hs.sb);
+  for_each_acc<TL>(acc, [&](int r, int c, float v) { ep(m0 + r, n0 + c, MODE == kSplit2 ? v * hs.inv : v); });
 }
 
 template <class TL, int MODE>
 int launch_conv(const float* x, const float* wp, float* y, int B, int T, int F, int C, int N, int accumulate,
-                hipStream_t st) {
+                hipStream_t st, const unsigned* amax_x = nullptr, const unsigned* amax_w = nullptr) {
   const int rows = B * T * F, K = 9 * C;
   ConvLoader<TL::A_LOADS> al;
   al.p = x; al.T = T; al.F = F; al.C = C; al.rows = rows;
   RowLoader bl{wp, (long)K, N, K, 0};
   ConvEpi ep{y, rows, N, accumulate, nullptr};
   const int tm = pe_cdiv(rows, TL::BM), tn = pe_cdiv(N, TL::BN);
-  hipLaunchKernelGGL((conv3x3_kernel<TL, MODE>), dim3(tm * tn), dim3(256), 0, st, al, bl, ep, K, tm, tn);
+  hipLaunchKernelGGL((conv3x3_kernel<TL, MODE>), dim3(tm * tn), dim3(256), 0, st, al, bl, ep, K, tm, tn, amax_x,
+                     amax_w);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }
@@ -291,7 +295,8 @@ int launch_conv_halo(const float* x, const float* wp, float* y, int B, int T, in
 // channel chunk (9 taps = 18 k-blocks) instead of per tap, no weight split, no weight LDS traffic.
 //   fragment (kb, nb, c), lane l = 32 h + r  <->  B[n = 32 nb + r][k = 16 kb + 8 h .. + 7] of term c.
 template <int NT>
-__global__ void wfrag_pack_kernel(const float* __restrict__ w, long ld, int N, int K, uint4* __restrict__ out) {
+__global__ void wfrag_pack_kernel(const float* __restrict__ w, long ld, int N, int K, uint4* __restrict__ out,
+                                  const unsigned* __restrict__ amax = nullptr) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int NB32 = (N + 31) >> 5, KB = K >> 4;
   const int lane = (int)(idx & 63);
@@ -310,6 +315,11 @@ __global__ void wfrag_pack_kernel(const float* __restrict__ w, long ld, int N, i
     dst[0] = make_uint4(a.hi.x, a.hi.y, b.hi.x, b.hi.y);
     dst[64] = make_uint4(a.mid.x, a.mid.y, b.mid.x, b.mid.y);
     dst[128] = make_uint4(a.lo.x, a.lo.y, b.lo.x, b.lo.y);
+  } else if constexpr (NT == 2) {
+    const float sc = h2_scale(*amax);
+    const Split2 a = split2(v0, sc), b = split2(v1, sc);
+    dst[0] = make_uint4(a.hi.x, a.hi.y, b.hi.x, b.hi.y);
+    dst[64] = make_uint4(a.lo.x, a.lo.y, b.lo.x, b.lo.y);
   } else {
     const bf16x4 a = to_bf16x4(v0), b = to_bf16x4(v1);
     const uint2 ua = __builtin_bit_cast(uint2, a), ub = __builtin_bit_cast(uint2, b);
@@ -321,8 +331,11 @@ template <int BN, int MODE, int PASSES, int D, bool FA2>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_wf_kernel(const float* __restrict__ x,
                                                                  const uint4* __restrict__ wf, ConvEpi ep, int T,
                                                                  int F, int C, int N, int P, int tiles_m,
-                                                                 int tiles_n) {
-  constexpr int NT = MODE == kSplit ? 3 : 1;
+                                                                 int tiles_n, const unsigned* amax_x,
+                                                                 const unsigned* amax_w) {
+  constexpr int NT = mode_terms<MODE>();
+  H2Scales hs{1.f, 1.f, 1.f};
+  if constexpr (MODE == kSplit2) hs.load(amax_x, amax_w);
   constexpr int TM = 2, TN = BN / 64, WN = BN / 2;
   constexpr int ZR = PASSES * 32;                                  // an all-zero row behind the window
   constexpr int AIMG = (ZR + 4) * 32;                              // bf16 elements per image
@@ -412,7 +425,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_wf_kernel(const float* __
   for (int cc = 0; cc < nchunks; ++cc) {
     __syncthreads();                                               // every wave is done with the previous window
 #pragma unroll
-    for (int ps = 0; ps < PASSES; ++ps) halo_store<NT>(As, AIMG, ps * 32 + srow, piece, ra[ps]);
+    for (int ps = 0; ps < PASSES; ++ps) halo_store<NT>(As, AIMG, ps * 32 + srow, piece, ra[ps], hs.sa);
     __syncthreads();
     if (cc + 1 < nchunks) fetch_a(cc + 1);
     // FA2: the activation fragments of the next k-block are read under this block's MFMAs (24 more registers)
@@ -432,13 +445,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_wf_kernel(const float* __
         load_fa(fa[0], blk >> 1, blk & 1);
       }
       const int fs = FA2 ? (blk & 1) : 0;
-      if constexpr (NT == 3) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) acc[i][j] = mfma_split(fa[fs][i], ring[s % D], acc[i][j]);
-      } else {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) acc[i][j] = mfma_bf16(fa[fs][i][0], ring[s % D][0], acc[i][j]);
-      }
+      for (int i = 0; i < TM; ++i) acc[i][j] = mfma_terms<NT>(fa[fs][i], ring[s % D], acc[i][j]);
       // hipcc otherwise sinks every prefetch down to its first use (seen in the .s: one step of lookahead
       // whatever D says); pinning the step boundaries keeps the loads D - 1 steps ahead of their MFMAs
       __builtin_amdgcn_sched_barrier(0);
@@ -460,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_wf_kernel(const float* __
         const int row = p0 + wm * 64 + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * h, col = n0 + wn * WN + j * 32 + r;
         if (row < ep.rows && col < ep.N) {
           float* d = ep.Y + (long)row * ep.N + col;
-          float v = acc[i][j][g];
+          float v = MODE == kSplit2 ? acc[i][j][g] * hs.inv : acc[i][j][g];
           if (ep.accumulate) v += *d;
           *d = v;
           s1[j] += (double)v;
@@ -495,12 +503,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_wf_kernel(const float* __
 
 template <int BN, int MODE, int PASSES, int D, bool FA2>
 int launch_conv_halo_wf(const float* x, const void* wf, float* y, int B, int T, int F, int C, int N, int accumulate,
-                        double* stats, hipStream_t st) {
+                        double* stats, hipStream_t st, const unsigned* amax_x = nullptr,
+                        const unsigned* amax_w = nullptr) {
   const int P = B * T * F;
   ConvEpi ep{y, P, N, accumulate, stats};
   const int tm = pe_cdiv(P, 128), tn = pe_cdiv(N, BN);
   hipLaunchKernelGGL((conv3x3_halo_wf_kernel<BN, MODE, PASSES, D, FA2>), dim3(tm * tn), dim3(256), 0, st, x,
-                     reinterpret_cast<const uint4*>(wf), ep, T, F, C, N, P, tm, tn);
+                     reinterpret_cast<const uint4*>(wf), ep, T, F, C, N, P, tm, tn, amax_x, amax_w);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }
@@ -667,11 +676,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_kernel(const float* __r
 // of one channel) come from ds_read_b64_tr_b16, and the border mask becomes a 16-bit AND mask per pixel:
 // Mk16[d][w][k] covers source row k + d of window w for column shift df = d - 1, so the 8 masks of a
 // fragment are one aligned 16-byte read.
-template <int NT>   // 3 = exact three-term split, 1 = operands rounded to bf16 (mixed precision)
+template <int NT>   // 3 = exact three-term split, 2 = two scaled fp16 terms, 1 = operands rounded to bf16 (mixed precision)
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(const float* __restrict__ dy,
                                                                    const float* __restrict__ x,
                                                                    float* __restrict__ ws, int T, int F, int Cin,
-                                                                   int Cout, int P, int k_per_split, int tiles_n) {
+                                                                   int Cout, int P, int k_per_split, int tiles_n,
+                                                                   const unsigned* amax_dy, const unsigned* amax_x) {
+  H2Scales hs{1.f, 1.f, 1.f};
+  if constexpr (NT == 2) hs.load(amax_dy, amax_x);
   constexpr int ST = 96;                                   // bf16 elements per staged row
   constexpr int YIMG = kBK * ST, XIMG = 102 * ST;
   __shared__ __attribute__((aligned(16))) __bf16 Ys[NT * YIMG];
@@ -714,12 +726,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(const float* 
       }
     }
   };
-  auto store3 = [&](__bf16* img, int img_elems, int off, const float4& v) {
+  auto store3 = [&](__bf16* img, int img_elems, int off, const float4& v, float scale) {
     if constexpr (NT == 3) {
       const Split3 sp = split3(v);
       *reinterpret_cast<uint2*>(img + off) = sp.hi;
       *reinterpret_cast<uint2*>(img + off + img_elems) = sp.mid;
       *reinterpret_cast<uint2*>(img + off + 2 * img_elems) = sp.lo;
+    } else if constexpr (NT == 2) {
+      const Split2 sp = split2(v, scale);
+      *reinterpret_cast<uint2*>(img + off) = sp.hi;
+      *reinterpret_cast<uint2*>(img + off + img_elems) = sp.lo;
     } else {
       *reinterpret_cast<bf16x4*>(img + off) = to_bf16x4(v);
     }
@@ -730,11 +746,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(const float* 
   for (int k0 = kb; k0 < ke; k0 += kBK) {
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 2; ++i) store3(Ys, YIMG, ((tid >> 4) + 16 * i) * ST + c4, ry[i]);
+    for (int i = 0; i < 2; ++i) store3(Ys, YIMG, ((tid >> 4) + 16 * i) * ST + c4, ry[i], hs.sa);
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
       const int wr = (tid >> 4) + 16 * i;
-      if (wr < 102) store3(Xs, XIMG, wr * ST + c4, rx[i]);
+      if (wr < 102) store3(Xs, XIMG, wr * ST + c4, rx[i], hs.sb);
     }
     if (tid < 102) {                                       // border masks of this k-tile's source rows
       const int w = tid / 34, row = tid - w * 34;
@@ -772,8 +788,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(const float* 
             v.x &= mk.x; v.y &= mk.y; v.z &= mk.z; v.w &= mk.w;
             fb[c] = __builtin_bit_cast(bf16x8, v);
           }
-          if constexpr (NT == 3) acc[w * 3 + d] = mfma_split(fa, fb, acc[w * 3 + d]);
-          else acc[w * 3 + d] = mfma_bf16(fa[0], fb[0], acc[w * 3 + d]);
+          acc[w * 3 + d] = mfma_terms<NT>(fa, fb, acc[w * 3 + d]);
         }
     }
   }
@@ -784,7 +799,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(const float* 
     for (int q = 0; q < 16; ++q) {
       const int co = m0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
       const int ci = n0 + wn * 32 + r;
-      dst[(long)co * Cin + ci] = acc[tp][q];
+      dst[(long)co * Cin + ci] = NT == 2 ? acc[tp][q] * hs.inv : acc[tp][q];
     }
   }
 }
@@ -993,11 +1008,13 @@ extern "C" int pe_transpose2d(const float* in, float* out, int rows, int cols, v
 
 template <int MODE>
 static int conv3x3_fwd_impl(const float* x, const float* w_packed, float* y, int B, int T, int F, int C, int N,
-                            int accumulate, void* stream) {
+                            int accumulate, void* stream, const unsigned* amax_x = nullptr,
+                            const unsigned* amax_w = nullptr) {
   if (!x || !w_packed || !y || B <= 0 || T <= 0 || F <= 0 || C <= 0 || N <= 0) return PE_E_ARG;
   if ((C % 32) != 0 || (long)B * T * F * (C > N ? C : N) >= (1L << 31)) return PE_E_UNSUPPORTED;
+  if (MODE == kSplit2 && (!amax_x || !amax_w)) return PE_E_ARG;
   hipStream_t st = pe_stream(stream);
-  if constexpr (MODE != kNative) {
+  if constexpr (MODE != kNative && MODE != kSplit2) {
     const int passes = conv_halo_passes(F, N);
     if (passes == 10) return launch_conv_halo<64, MODE, 10>(x, w_packed, y, B, T, F, C, N, accumulate, st);
     if (passes == 7) {
@@ -1006,10 +1023,11 @@ static int conv3x3_fwd_impl(const float* x, const float* w_packed, float* y, int
       return launch_conv_halo<128, MODE, 7>(x, w_packed, y, B, T, F, C, N, accumulate, st);
     }
   }
-  if (N <= 64) return launch_conv<Tile<256, 64, 4, 1>, MODE>(x, w_packed, y, B, T, F, C, N, accumulate, st);
+  if (N <= 64)
+    return launch_conv<Tile<256, 64, 4, 1>, MODE>(x, w_packed, y, B, T, F, C, N, accumulate, st, amax_x, amax_w);
   if (N % 192 == 0 && N % 128 != 0)
-    return launch_conv<Tile<128, 192, 2, 2>, MODE>(x, w_packed, y, B, T, F, C, N, accumulate, st);
-  return launch_conv<Tile<128, 128, 2, 2>, MODE>(x, w_packed, y, B, T, F, C, N, accumulate, st);
+    return launch_conv<Tile<128, 192, 2, 2>, MODE>(x, w_packed, y, B, T, F, C, N, accumulate, st, amax_x, amax_w);
+  return launch_conv<Tile<128, 128, 2, 2>, MODE>(x, w_packed, y, B, T, F, C, N, accumulate, st, amax_x, amax_w);
 }
 
 #ifndef PE_F16_BUILD
@@ -1029,12 +1047,17 @@ extern "C" int pe_conv3x3_fwd_x3(const float* x, const float* w_packed, float* y
                                  int N, int accumulate, void* stream) {
   return conv3x3_fwd_impl<kSplit>(x, w_packed, y, B, T, F, C, N, accumulate, stream);
 }
+
+extern "C" int pe_conv3x3_fwd_h2(const float* x, const float* w_packed, float* y, int B, int T, int F, int C,
+                                 int N, int accumulate, const unsigned* amax_x, const unsigned* amax_w, void* stream) {
+  return conv3x3_fwd_impl<kSplit2>(x, w_packed, y, B, T, F, C, N, accumulate, stream, amax_x, amax_w);
+}
 #endif
 
 // ---- weights pre-packed as MFMA fragments (x3: three bf16 terms; bf16: one rounded term)
 #ifndef PE_F16_BUILD
 extern "C" size_t pe_wfrag_bytes(int N, int K, int terms) {
-  if (N <= 0 || K <= 0 || (K & 15) || (terms != 1 && terms != 3)) return 0;
+  if (N <= 0 || K <= 0 || (K & 15) || terms < 1 || terms > 3) return 0;
   return (size_t)((N + 31) / 32) * (K / 16) * terms * 1024;
 }
 
@@ -1048,6 +1071,17 @@ extern "C" int pe_wfrag_pack(const float* w, long ld, int N, int K, int terms, v
   else
     hipLaunchKernelGGL(wfrag_pack_kernel<1>, dim3(pe_cdiv(threads, 256)), dim3(256), 0, pe_stream(stream), w, ld, N, K,
                        reinterpret_cast<uint4*>(out));
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+
+// two scaled fp16 terms per weight ("h2"): the scale comes from *amax (pe_absmax of w)
+extern "C" int pe_wfrag_pack_h2(const float* w, long ld, int N, int K, const unsigned* amax, void* out, void* stream) {
+  if (!w || !out || !amax || N <= 0 || K <= 0 || ld < K) return PE_E_ARG;
+  if ((K & 15) || (ld & 3)) return PE_E_UNSUPPORTED;
+  const long threads = (long)((N + 31) / 32) * (K / 16) * 64;
+  hipLaunchKernelGGL(wfrag_pack_kernel<2>, dim3(pe_cdiv(threads, 256)), dim3(256), 0, pe_stream(stream), w, ld, N, K,
+                     reinterpret_cast<uint4*>(out), amax);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }
@@ -1074,16 +1108,20 @@ extern "C" int pe_wfrag_pack_f16(const float* w, long ld, int N, int K, void* ou
 #endif
 template <int MODE>
 static int conv3x3_fwd_wf_impl(const float* x, const void* wfrag, float* y, int B, int T, int F, int C, int N,
-                               int accumulate, double* stats, void* stream) {
+                               int accumulate, double* stats, void* stream, const unsigned* amax_x = nullptr,
+                               const unsigned* amax_w = nullptr) {
   if (!x || !wfrag || !y || B <= 0 || T <= 0 || F <= 0 || C <= 0 || N <= 0) return PE_E_ARG;
   if ((C % 32) != 0 || (long)B * T * F * (C > N ? C : N) >= (1L << 31)) return PE_E_UNSUPPORTED;
+  if (MODE == kSplit2 && (!amax_x || !amax_w)) return PE_E_ARG;
   hipStream_t st = pe_stream(stream);
   const int passes = conv_halo_passes(F, N);
-  if (passes == 10) return launch_conv_halo_wf<64, MODE, 10, 6, true>(x, wfrag, y, B, T, F, C, N, accumulate, stats, st);
+  if (passes == 10)
+    return launch_conv_halo_wf<64, MODE, 10, 6, true>(x, wfrag, y, B, T, F, C, N, accumulate, stats, st, amax_x, amax_w);
   if (passes == 7) {
     if (N % 192 == 0 && N % 128 != 0)
-      return launch_conv_halo_wf<192, MODE, 7, 3, false>(x, wfrag, y, B, T, F, C, N, accumulate, stats, st);
-    return launch_conv_halo_wf<128, MODE, 7, 3, true>(x, wfrag, y, B, T, F, C, N, accumulate, stats, st);
+      return launch_conv_halo_wf<192, MODE, 7, 3, MODE == kSplit2>(x, wfrag, y, B, T, F, C, N, accumulate, stats, st,
+                                                                  amax_x, amax_w);
+    return launch_conv_halo_wf<128, MODE, 7, 3, true>(x, wfrag, y, B, T, F, C, N, accumulate, stats, st, amax_x, amax_w);
   }
   return PE_E_UNSUPPORTED;
 }
@@ -1092,6 +1130,12 @@ static int conv3x3_fwd_wf_impl(const float* x, const void* wfrag, float* y, int 
 extern "C" int pe_conv3x3_fwd_wf_x3(const float* x, const void* wfrag, float* y, int B, int T, int F, int C, int N,
                                     int accumulate, double* bn_partials, void* stream) {
   return conv3x3_fwd_wf_impl<kSplit>(x, wfrag, y, B, T, F, C, N, accumulate, bn_partials, stream);
+}
+
+extern "C" int pe_conv3x3_fwd_wf_h2(const float* x, const void* wfrag, float* y, int B, int T, int F, int C, int N,
+                                    int accumulate, double* bn_partials, const unsigned* amax_x,
+                                    const unsigned* amax_w, void* stream) {
+  return conv3x3_fwd_wf_impl<kSplit2>(x, wfrag, y, B, T, F, C, N, accumulate, bn_partials, stream, amax_x, amax_w);
 }
 #endif
 
@@ -1111,8 +1155,10 @@ extern "C" size_t pe_conv3x3_wgrad_workspace_bytes(int B, int T, int F, int Cin,
 
 template <int MODE>
 static int conv3x3_wgrad_impl(const float* x, const float* dy, float* dw_oihw, int B, int T, int F, int Cin,
-                              int Cout, float* workspace, size_t workspace_bytes, void* stream) {
+                              int Cout, float* workspace, size_t workspace_bytes, void* stream,
+                              const unsigned* amax_x = nullptr, const unsigned* amax_dy = nullptr) {
   if (!x || !dy || !dw_oihw || B <= 0 || T <= 0 || F <= 0 || Cin <= 0 || Cout <= 0) return PE_E_ARG;
+  if (MODE == kSplit2 && (!amax_x || !amax_dy)) return PE_E_ARG;
   if ((Cin & 3) || (Cout & 3)) return PE_E_UNSUPPORTED;
   if (!workspace || workspace_bytes < pe_conv3x3_wgrad_workspace_bytes(B, T, F, Cin, Cout)) return PE_E_WORKSPACE;
   int bm, bn, splits, kps;
@@ -1122,10 +1168,13 @@ static int conv3x3_wgrad_impl(const float* x, const float* dy, float* dw_oihw, i
     const int P = B * T * F, tn = Cin / 64;
     if (MODE == kSplit)
       hipLaunchKernelGGL(conv3x3_wgrad9_x3_kernel<3>, dim3((Cout / 64) * tn * splits), dim3(256), 0, st, dy, x,
-                         workspace, T, F, Cin, Cout, P, kps, tn);
+                         workspace, T, F, Cin, Cout, P, kps, tn, nullptr, nullptr);
+    else if (MODE == kSplit2)
+      hipLaunchKernelGGL(conv3x3_wgrad9_x3_kernel<2>, dim3((Cout / 64) * tn * splits), dim3(256), 0, st, dy, x,
+                         workspace, T, F, Cin, Cout, P, kps, tn, amax_dy, amax_x);
     else if (MODE == kBf16)
       hipLaunchKernelGGL(conv3x3_wgrad9_x3_kernel<1>, dim3((Cout / 64) * tn * splits), dim3(256), 0, st, dy, x,
-                         workspace, T, F, Cin, Cout, P, kps, tn);
+                         workspace, T, F, Cin, Cout, P, kps, tn, nullptr, nullptr);
     else
       hipLaunchKernelGGL(conv3x3_wgrad9_kernel<0>, dim3((Cout / 64) * tn * splits), dim3(256), 0, st, dy, x,
                          workspace, T, F, Cin, Cout, P, kps, tn);
@@ -1159,6 +1208,13 @@ extern "C" int PE_HALF(pe_conv3x3_wgrad)(const float* x, const float* dy, float*
 extern "C" int pe_conv3x3_wgrad_x3(const float* x, const float* dy, float* dw_oihw, int B, int T, int F, int Cin,
                                    int Cout, float* workspace, size_t workspace_bytes, void* stream) {
   return conv3x3_wgrad_impl<kSplit>(x, dy, dw_oihw, B, T, F, Cin, Cout, workspace, workspace_bytes, stream);
+}
+
+extern "C" int pe_conv3x3_wgrad_h2(const float* x, const float* dy, float* dw_oihw, int B, int T, int F, int Cin,
+                                   int Cout, float* workspace, size_t workspace_bytes, const unsigned* amax_x,
+                                   const unsigned* amax_dy, void* stream) {
+  return conv3x3_wgrad_impl<kSplit2>(x, dy, dw_oihw, B, T, F, Cin, Cout, workspace, workspace_bytes, stream, amax_x,
+                                     amax_dy);
 }
 
 static int c1_grid(int B, int T, int F) {

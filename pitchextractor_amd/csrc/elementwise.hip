@@ -512,6 +512,32 @@ size_t reduce_lds(int C) { return (size_t)(256 / (C / 4)) * 2 * C * sizeof(doubl
 
 bool bn_channels_ok(int C) { return C >= 4 && (C % 4) == 0 && C <= 1024; }
 
+// ---------------------------------------------------------------- largest magnitude of a tensor (h2 operand scale)
+// out[0] = max(out[0], IEEE bits of max |x|) over a row-strided [rows][cols] matrix (cols % 4 == 0).  The bit
+// patterns of non-negative floats order like unsigned integers, so the cross-workgroup combine is an integer
+// atomicMax: exact and independent of the order of arrival (NaN / inf operands give the largest patterns and poison
+// the product they feed, as they would any other path).  The caller zeroes out[0] (pe_absmax does).
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long rows, int cols4, long ld,
+                                                     unsigned* __restrict__ out) {
+  const long n4 = rows * cols4;
+  unsigned m = 0u;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long r = i / cols4;
+    const int c = (int)(i - r * cols4);
+    const float4 v = *reinterpret_cast<const float4*>(x + r * ld + c * 4);
+    m = max(m, __float_as_uint(v.x) & 0x7fffffffu);
+    m = max(m, __float_as_uint(v.y) & 0x7fffffffu);
+    m = max(m, __float_as_uint(v.z) & 0x7fffffffu);
+    m = max(m, __float_as_uint(v.w) & 0x7fffffffu);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+  __shared__ unsigned red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(out, max(max(red[0], red[1]), max(red[2], red[3])));
+}
+
 }  // namespace
 
 extern "C" size_t pe_bn_workspace_bytes(int C) { return (size_t)kMaxPartials * 2 * C * sizeof(double); }
@@ -681,6 +707,19 @@ extern "C" int pe_copy2d(const float* src, long lds, float* dst, long ldd, long 
   if ((cols & 3) || (lds & 3) || (ldd & 3)) return PE_E_UNSUPPORTED;
   hipLaunchKernelGGL(copy2d_kernel, dim3(ew_grid(rows * (cols / 4))), dim3(256), 0, pe_stream(stream), src, lds, dst,
                      ldd, rows, cols, accumulate);
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+
+extern "C" int pe_absmax(const float* x, long rows, int cols, long ld, unsigned* out, void* stream) {
+  if (!x || !out || rows < 0 || cols <= 0 || ld < cols) return PE_E_ARG;
+  if ((cols & 3) || (ld & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) return PE_E_UNSUPPORTED;
+  hipStream_t st = pe_stream(stream);
+  PE_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(unsigned), st));
+  if (rows == 0) return PE_OK;
+  const long n4 = rows * (cols / 4);
+  const int grid = (int)(n4 / 2048 < 1 ? 1 : n4 / 2048 > 2048 ? 2048 : n4 / 2048);     // >= 8 float4 per thread
+  hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, st, x, rows, cols / 4, ld, out);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }

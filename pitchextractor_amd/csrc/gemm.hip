@@ -34,7 +34,8 @@ struct StoreEpi {
 
 template <class TL, int MODE>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(RowLoader al, RowLoader bl, StoreEpi ep, int K,
-                                                      int tiles_m, int tiles_n) {
+                                                      int tiles_m, int tiles_n, const unsigned* amax_a,
+                                                      const unsigned* amax_b) {
   __shared__ __attribute__((aligned(16))) float As[TL::BM * nt_row_floats<MODE>()];
   __shared__ __attribute__((aligned(16))) float Bs[TL::BN * nt_row_floats<MODE>()];
   const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
@@ -43,8 +44,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(RowLoader al, RowLoader bl
   bl.init(n0);
   f32x16 acc[TL::TM][TL::TN];
   zero_acc<TL>(acc);
-  nt_mainloop_mode<TL, MODE>(al, bl, K, As, Bs, acc);
-  for_each_acc<TL>(acc, [&](int r, int c, float v) { ep(m0 + r, n0 + c, v); });
+  H2Scales hs{1.f, 1.f, 1.f};
+  if constexpr (MODE == kSplit2) hs.load(amax_a, amax_b);
+  nt_mainloop_mode<TL, MODE>(al, bl, K, As, Bs, acc, hs.sa, hs.sb);
+  for_each_acc<TL>(acc, [&](int r, int c, float v) { ep(m0 + r, n0 + c, MODE == kSplit2 ? v * hs.inv : v); });
 }
 
 // The same product with the operand roles swapped inside the tile engine (the NT main loop is symmetric in its two
@@ -53,8 +56,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(RowLoader al, RowLoader bl
 // store instructions, bias fetched once per column quad).  Bit-identical sums.  Needs N % 4 == 0 and a 16-byte
 // aligned C with ldc % 4 == 0 (checked by the host).
 template <class TL, int MODE>
-__global__ __launch_bounds__(256, (MODE == kSplit && TL::BM == 128 && TL::BN == 128) ? 3 : 1)
-void gemm_nt_t_kernel(RowLoader al, RowLoader bl, StoreEpi ep, int K, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(256, ((MODE == kSplit || MODE == kSplit2) && TL::BM == 128 && TL::BN == 128) ? 3 : 1)
+void gemm_nt_t_kernel(RowLoader al, RowLoader bl, StoreEpi ep, int K, int tiles_m, int tiles_n,
+                      const unsigned* amax_a, const unsigned* amax_b) {
   using TT = Tile<TL::BN, TL::BM, TL::WAVES_N, TL::WAVES_M>;
   __shared__ __attribute__((aligned(16))) float As[TL::BM * nt_row_floats<MODE>()];
   __shared__ __attribute__((aligned(16))) float Bs[TL::BN * nt_row_floats<MODE>()];
@@ -64,7 +68,9 @@ void gemm_nt_t_kernel(RowLoader al, RowLoader bl, StoreEpi ep, int K, int tiles_
   bl.init(n0);
   f32x16 acc[TT::TM][TT::TN];
   zero_acc<TT>(acc);
-  nt_mainloop_mode<TT, MODE, true>(bl, al, K, Bs, As, acc);
+  H2Scales hs{1.f, 1.f, 1.f};
+  if constexpr (MODE == kSplit2) hs.load(amax_a, amax_b);
+  nt_mainloop_mode<TT, MODE, true>(bl, al, K, Bs, As, acc, hs.sb, hs.sa);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wn = wv / TT::WAVES_N, wm = wv % TT::WAVES_N;          // TT's "rows" are output columns
   const int r = lane & 31, h = lane >> 5;
@@ -83,6 +89,7 @@ void gemm_nt_t_kernel(RowLoader al, RowLoader bl, StoreEpi ep, int K, int tiles_
         if (row >= ep.M) continue;
         float4* dst = reinterpret_cast<float4*>(ep.C + (long)row * ep.ldc + col);
         float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+        if constexpr (MODE == kSplit2) { v.x *= hs.inv; v.y *= hs.inv; v.z *= hs.inv; v.w *= hs.inv; }
         if (ep.bias0) { v.x += b0.x; v.y += b0.y; v.z += b0.z; v.w += b0.w; }
         if (ep.bias1) { v.x += b1.x; v.y += b1.y; v.z += b1.z; v.w += b1.w; }
         if (ep.accumulate) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
@@ -281,13 +288,17 @@ int launch_nt_pipe(const RowLoader& al, const RowLoader& bl, const StoreEpi& ep,
 
 template <class TL, int MODE>
 int launch_nt(const RowLoader& al, const RowLoader& bl, const StoreEpi& ep, int M, int N, int K,
-              hipStream_t st) {
+              hipStream_t st, const unsigned* amax_a = nullptr, const unsigned* amax_b = nullptr) {
   const int tm = pe_cdiv(M, TL::BM), tn = pe_cdiv(N, TL::BN);
   static const bool off = getenv("PE_GEMM_NT_SCALAR_EPILOGUE") != nullptr;     // A/B switch (tools/ab_gemm.py)
   const bool vec = !off && MODE != kNative && (N & 3) == 0 && (ep.ldc & 3) == 0 &&
                    (reinterpret_cast<uintptr_t>(ep.C) & 15) == 0;
-  if (vec) hipLaunchKernelGGL((gemm_nt_t_kernel<TL, MODE>), dim3(tm * tn), dim3(256), 0, st, al, bl, ep, K, tm, tn);
-  else hipLaunchKernelGGL((gemm_nt_kernel<TL, MODE>), dim3(tm * tn), dim3(256), 0, st, al, bl, ep, K, tm, tn);
+  if (vec)
+    hipLaunchKernelGGL((gemm_nt_t_kernel<TL, MODE>), dim3(tm * tn), dim3(256), 0, st, al, bl, ep, K, tm, tn, amax_a,
+                       amax_b);
+  else
+    hipLaunchKernelGGL((gemm_nt_kernel<TL, MODE>), dim3(tm * tn), dim3(256), 0, st, al, bl, ep, K, tm, tn, amax_a,
+                       amax_b);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }
@@ -423,7 +434,8 @@ int launch_nt_wf(const RowLoader& al, const void* wf, const StoreEpi& ep, int M,
 template <int BM, int BN, int MODE>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(KRowLoader<BM> al, KRowLoader<BN> bl, float* out,
                                                       long ldo, long split_stride, int M, int N, int K,
-                                                      int k_per_split, int tiles_n, int accumulate) {
+                                                      int k_per_split, int tiles_n, int accumulate,
+                                                      const unsigned* amax_a, const unsigned* amax_b) {
   __shared__ __attribute__((aligned(16))) float As[tn_lds_floats<MODE, BM>()];
   __shared__ __attribute__((aligned(16))) float Bs[tn_lds_floats<MODE, BN>()];
   // 1-D grid over (split, tile) with every XCD taking a CONTIGUOUS run of it: the tiles of one k-split then share
@@ -444,10 +456,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(KRowLoader<BM> al, KRowLoa
     for (int j = 0; j < BN / 64; ++j)
 #pragma unroll
       for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
-  tn_mainloop_mode<MODE, BM, BN>(al, bl, kb, ke, As, Bs, acc);
+  H2Scales hs{1.f, 1.f, 1.f};
+  if constexpr (MODE == kSplit2) hs.load(amax_a, amax_b);
+  tn_mainloop_mode<MODE, BM, BN>(al, bl, kb, ke, As, Bs, acc, hs.sa, hs.sb);
   float* dst = out + (long)split_id * split_stride;
   tn_for_each_acc<BM, BN>(acc, [&](int r, int c, float v) {
     const int row = m0 + r, col = n0 + c;
+    if constexpr (MODE == kSplit2) v *= hs.inv;
     if (row < M && col < N) {
       float* d = dst + (long)row * ldo + col;
       if (accumulate) v += *d;
@@ -471,7 +486,7 @@ __global__ void splitk_reduce_kernel(const float* ws, long split_stride, int spl
 void tn_plan(int M, int N, int K, int bm, int bn, int mode, int* splits, int* k_per_split) {
   const int tiles = pe_cdiv(M, bm) * pe_cdiv(N, bn);
   // resident workgroups: 3 per CU (native), 2 per CU when the three-term images fill the LDS
-  const int s = pe_pick_splits(tiles, K, 512, mode == kSplit ? 512 : 768);   // (bf16: LDS is small, 768 too)
+  const int s = pe_pick_splits(tiles, K, 512, (mode == kSplit || mode == kSplit2) ? 512 : 768);   // (bf16: LDS is small, 768 too)
   int kps = pe_cdiv(K, s);
   kps = (kps + kBK - 1) / kBK * kBK;
   *splits = pe_cdiv(K, kps);
@@ -480,7 +495,8 @@ void tn_plan(int M, int N, int K, int bm, int bn, int mode, int* splits, int* k_
 
 template <int BM, int BN, int MODE>
 int launch_tn(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, int K,
-              int accumulate, float* ws, size_t ws_bytes, hipStream_t st) {
+              int accumulate, float* ws, size_t ws_bytes, hipStream_t st, const unsigned* amax_a = nullptr,
+              const unsigned* amax_b = nullptr) {
   int splits, kps;
   tn_plan(M, N, K, BM, BN, MODE, &splits, &kps);
   KRowLoader<BM> al{A, lda, M, 0};
@@ -488,14 +504,14 @@ int launch_tn(const float* A, long lda, const float* B, long ldb, float* C, long
   const int tm = pe_cdiv(M, BM), tn = pe_cdiv(N, BN);
   if (splits == 1) {
     hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, MODE>), dim3(tm * tn, 1), dim3(256), 0, st, al, bl, C, ldc, 0L, M, N,
-                       K, kps, tn, accumulate);
+                       K, kps, tn, accumulate, amax_a, amax_b);
     PE_LAUNCH_CHECK();
     return PE_OK;
   }
   const size_t need = (size_t)splits * M * N * sizeof(float);
   if (!ws || ws_bytes < need) return PE_E_WORKSPACE;
   hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, MODE>), dim3(tm * tn * splits), dim3(256), 0, st, al, bl, ws, (long)N,
-                     (long)M * N, M, N, K, kps, tn, 0);
+                     (long)M * N, M, N, K, kps, tn, 0, amax_a, amax_b);
   PE_LAUNCH_CHECK();
   const long total = (long)M * N;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(pe_cdiv(total / 4, 256)), dim3(256), 0, st, ws, (long)M * N, splits,
@@ -518,8 +534,10 @@ extern "C" int pe_gemm_nt_pipeline(int enable) {
 
 template <int MODE>
 static int gemm_nt_impl(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
-                        int K, const float* bias0, const float* bias1, int accumulate, void* stream) {
+                        int K, const float* bias0, const float* bias1, int accumulate, void* stream,
+                        const unsigned* amax_a = nullptr, const unsigned* amax_b = nullptr) {
   if (!A || !B || !C || M < 0 || N < 0 || K <= 0) return PE_E_ARG;
+  if (MODE == kSplit2 && (!amax_a || !amax_b)) return PE_E_ARG;
   if (M == 0 || N == 0) return PE_OK;
   if ((K & 3) || (lda & 3) || (ldb & 3) || !aligned16(A) || !aligned16(B)) return PE_E_UNSUPPORTED;
   RowLoader al{A, lda, M, K, 0};
@@ -534,12 +552,12 @@ static int gemm_nt_impl(const float* A, long lda, const float* B, long ldb, floa
     if (!pipe_off && N % 128 == 0 && K >= 256 && K % 32 == 0 && M >= 256 && (ldc & 3) == 0 && aligned16(C) && fits32)
       return launch_nt_pipe(al, bl, ep, M, N, K, st);
   }
-  if (N <= 32) return launch_nt<Tile<128, 32, 4, 1>, MODE>(al, bl, ep, M, N, K, st);
-  if (N <= 64) return launch_nt<Tile<256, 64, 4, 1>, MODE>(al, bl, ep, M, N, K, st);
+  if (N <= 32) return launch_nt<Tile<128, 32, 4, 1>, MODE>(al, bl, ep, M, N, K, st, amax_a, amax_b);
+  if (N <= 64) return launch_nt<Tile<256, 64, 4, 1>, MODE>(al, bl, ep, M, N, K, st, amax_a, amax_b);
   static const bool narrow = getenv("PE_GEMM_NT_TILE128") != nullptr;                 // A/B switch
   if (N % 192 == 0 && (N % 128 != 0 || MODE != kNative) && !(narrow && N % 128 == 0))   // bf16-term modes: the wider tile stages 17 % fewer rows per MFMA
-    return launch_nt<Tile<128, 192, 2, 2>, MODE>(al, bl, ep, M, N, K, st);
-  return launch_nt<Tile<128, 128, 2, 2>, MODE>(al, bl, ep, M, N, K, st);
+    return launch_nt<Tile<128, 192, 2, 2>, MODE>(al, bl, ep, M, N, K, st, amax_a, amax_b);
+  return launch_nt<Tile<128, 128, 2, 2>, MODE>(al, bl, ep, M, N, K, st, amax_a, amax_b);
 }
 
 #ifndef PE_F16_BUILD
@@ -559,6 +577,12 @@ extern "C" int PE_HALF(pe_gemm_nt)(const float* A, long lda, const float* B, lon
 extern "C" int pe_gemm_nt_x3(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
                              int K, const float* bias0, const float* bias1, int accumulate, void* stream) {
   return gemm_nt_impl<kSplit>(A, lda, B, ldb, C, ldc, M, N, K, bias0, bias1, accumulate, stream);
+}
+
+extern "C" int pe_gemm_nt_h2(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
+                             int K, const float* bias0, const float* bias1, int accumulate, const unsigned* amax_a,
+                             const unsigned* amax_b, void* stream) {
+  return gemm_nt_impl<kSplit2>(A, lda, B, ldb, C, ldc, M, N, K, bias0, bias1, accumulate, stream, amax_a, amax_b);
 }
 #endif
 
@@ -626,18 +650,24 @@ extern "C" size_t pe_gemm_tn_workspace_bytes(int M, int N, int K) {
 
 template <int MODE>
 static int gemm_tn_impl(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
-                        int K, int accumulate, float* workspace, size_t workspace_bytes, void* stream) {
+                        int K, int accumulate, float* workspace, size_t workspace_bytes, void* stream,
+                        const unsigned* amax_a = nullptr, const unsigned* amax_b = nullptr) {
   if (!A || !B || !C || M < 0 || N < 0 || K <= 0) return PE_E_ARG;
+  if (MODE == kSplit2 && (!amax_a || !amax_b)) return PE_E_ARG;
   if (M == 0 || N == 0) return PE_OK;
   if ((M & 3) || (N & 3) || (lda & 3) || (ldb & 3) || !aligned16(A) || !aligned16(B)) return PE_E_UNSUPPORTED;
   hipStream_t st = pe_stream(stream);
   if (M <= 64 && N <= 64)
-    return launch_tn<64, 64, MODE>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, st);
+    return launch_tn<64, 64, MODE>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, st, amax_a,
+                                   amax_b);
   if (M <= 64)
-    return launch_tn<64, 128, MODE>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, st);
+    return launch_tn<64, 128, MODE>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, st, amax_a,
+                                    amax_b);
   if (N <= 64)
-    return launch_tn<128, 64, MODE>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, st);
-  return launch_tn<128, 128, MODE>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, st);
+    return launch_tn<128, 64, MODE>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, st, amax_a,
+                                    amax_b);
+  return launch_tn<128, 128, MODE>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, st, amax_a,
+                                   amax_b);
 }
 
 #ifndef PE_F16_BUILD
@@ -649,6 +679,13 @@ extern "C" int pe_gemm_tn(const float* A, long lda, const float* B, long ldb, fl
 extern "C" int pe_gemm_tn_x3(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
                              int K, int accumulate, float* workspace, size_t workspace_bytes, void* stream) {
   return gemm_tn_impl<kSplit>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, stream);
+}
+
+extern "C" int pe_gemm_tn_h2(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
+                             int K, int accumulate, float* workspace, size_t workspace_bytes, const unsigned* amax_a,
+                             const unsigned* amax_b, void* stream) {
+  return gemm_tn_impl<kSplit2>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, stream, amax_a,
+                               amax_b);
 }
 #endif
 

@@ -26,6 +26,8 @@ constexpr int kBK = 32;
 constexpr int kNative = 0;    // v_mfma_f32_32x32x2_f32
 constexpr int kBf16 = 1;      // operands rounded to bf16 (mixed precision)
 constexpr int kSplit = 2;     // fp32 as three bf16 terms, six bf16 MFMAs per product block (fp32-accurate)
+constexpr int kSplit2 = 3;    // fp32 as two scaled fp16 terms, three fp16 MFMAs per product block ("h2", below)
+template <int MODE> constexpr int mode_terms() { return MODE == kSplit ? 3 : MODE == kSplit2 ? 2 : 1; }
 constexpr int kLdsStride = kBK + 4;
 
 template <int BM_, int BN_, int WAVES_M_, int WAVES_N_>
@@ -295,6 +297,81 @@ __device__ __forceinline__ f32x16 mfma_split_swapped(const bf16x8 (&a)[3], const
   return c;
 }
 
+// ------------------------------------------------------------------ fp32 as two scaled fp16 terms ("h2")
+// fp16 carries 11 significand bits, so TWO terms hold 22: x * s = hi + lo (+ a residual <= 2^-22 |x s|), hi =
+// RN_f16(x s), lo = RN_f16(x s - hi) (the subtraction is exact in fp32).  a * b is then hi_a hi_b + hi_a lo_b +
+// lo_a hi_b (every product exact in the fp32 accumulator of v_mfma_f32_32x32x16_f16) with lo_a lo_b <= 2^-24 |a b|
+// dropped: THREE MFMAs per product block instead of the six of the bf16 split, for a per-product error <= 2^-21
+// |a b|, unbiased (round to nearest) and so averaging out over a sum; the accumulation rounding of a K-long fp32
+// sum, common to every fp32 path, is ~2^-22 sqrt(K) |a b|.  What fp16 lacks is exponent range (5 bits), so every
+// operand TENSOR carries a power-of-two scale s = 2^(140 - E), E = the biased exponent of its largest magnitude
+// (pe_absmax, or the producing kernel's epilogue): max |x| s lies in [2^13, 2^14), hi stays a normal fp16 down to
+// 2^-28 of the tensor's maximum and a subnormal with absolute resolution 2^-38 max below that.  The epilogue
+// multiplies the accumulator by 1 / (s_a s_b), again a power of two: nothing but exponents change.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x16 mfma_f16(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// scale of a tensor whose largest magnitude has the IEEE bits `amax_bits` (sign bit clear)
+__device__ __host__ __forceinline__ unsigned h2_scale_exp(unsigned amax_bits) {
+  int es = 267 - (int)((amax_bits >> 23) & 0xffu);                  // biased exponent of 2^(140 - E)
+  es = es < 1 ? 1 : es > 253 ? 253 : es;                            // all-zero / subnormal tensors: 2^126
+  return (unsigned)es;
+}
+__device__ __forceinline__ float h2_scale(unsigned amax_bits) { return __uint_as_float(h2_scale_exp(amax_bits) << 23); }
+__device__ __forceinline__ float h2_inv_scale(unsigned amax_bits) {
+  return __uint_as_float((254u - h2_scale_exp(amax_bits)) << 23);
+}
+
+struct H2Scales {                                                   // s_a, s_b and 1 / (s_a s_b) of one product
+  float sa, sb, inv;
+  __device__ __forceinline__ void load(const unsigned* amax_a, const unsigned* amax_b) {
+    const unsigned ba = __builtin_amdgcn_readfirstlane(*amax_a), bb = __builtin_amdgcn_readfirstlane(*amax_b);
+    sa = h2_scale(ba); sb = h2_scale(bb);
+    inv = h2_inv_scale(ba) * h2_inv_scale(bb);
+  }
+};
+
+struct Split2 { uint2 hi, lo; };                                    // 4 consecutive k of one row, packed fp16 pairs
+
+__device__ __forceinline__ Split2 split2(const float4& v, float s) {
+  typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+  typedef float f2v __attribute__((ext_vector_type(2)));
+  const f2v t0 = {v.x * s, v.y * s}, t1 = {v.z * s, v.w * s};
+  const h2v h0 = __builtin_convertvector(t0, h2v), h1 = __builtin_convertvector(t1, h2v);
+  const f2v r0 = t0 - __builtin_convertvector(h0, f2v), r1 = t1 - __builtin_convertvector(h1, f2v);
+  const h2v l0 = __builtin_convertvector(r0, h2v), l1 = __builtin_convertvector(r1, h2v);
+  Split2 o;
+  o.hi = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
+  o.lo = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
+  return o;
+}
+
+// acc += a * b from the two fp16 terms of each operand, small products first
+__device__ __forceinline__ f32x16 mfma_split2(const bf16x8 (&a)[2], const bf16x8 (&b)[2], f32x16 c) {
+  c = mfma_f16(a[1], b[0], c);
+  c = mfma_f16(a[0], b[1], c);
+  c = mfma_f16(a[0], b[0], c);
+  return c;
+}
+// the same three products in the same order when the caller has swapped the roles of its two operands
+__device__ __forceinline__ f32x16 mfma_split2_swapped(const bf16x8 (&a)[2], const bf16x8 (&b)[2], f32x16 c) {
+  c = mfma_f16(a[0], b[1], c);
+  c = mfma_f16(a[1], b[0], c);
+  c = mfma_f16(a[0], b[0], c);
+  return c;
+}
+
+// product block of an NT-term operand pair: NT = 3 bf16 split, 2 fp16 split, 1 rounded 16-bit operands
+template <int NT, bool SW = false>
+__device__ __forceinline__ f32x16 mfma_terms(const bf16x8 (&a)[NT], const bf16x8 (&b)[NT], f32x16 c) {
+  if constexpr (NT == 3) return SW ? mfma_split_swapped(a, b, c) : mfma_split(a, b, c);
+  else if constexpr (NT == 2) return SW ? mfma_split2_swapped(a, b, c) : mfma_split2(a, b, c);
+  else return mfma_bf16(a[0], b[0], c);
+}
+
 // bf16-term images [row][32 k] with NO padding: 16-byte chunk c of a row sits at chunk c ^ ((row >> 2) & 3), which
 // keeps ds_read_b128 fragment reads (32 consecutive rows at any row offset) and the ds_write_b64 staging stores
 // conflict-free (MI355X_MICROARCH.md, LDS lane groups).
@@ -304,24 +381,29 @@ __device__ __forceinline__ int swz_off(int row, int chunk) {        // in bf16 e
 
 // 4 consecutive k (piece = float4 index 0..7 within the 32-k row) of one row -> NT term images
 template <int NT>
-__device__ __forceinline__ void halo_store(__bf16* img, int img_elems, int row, int piece, const float4& v) {
+__device__ __forceinline__ void halo_store(__bf16* img, int img_elems, int row, int piece, const float4& v,
+                                           float scale = 1.0f) {
   const int off = swz_off(row, piece >> 1) + (piece & 1) * 4;
   if constexpr (NT == 3) {
     const Split3 sp = split3(v);
     *reinterpret_cast<uint2*>(img + off) = sp.hi;
     *reinterpret_cast<uint2*>(img + off + img_elems) = sp.mid;
     *reinterpret_cast<uint2*>(img + off + 2 * img_elems) = sp.lo;
+  } else if constexpr (NT == 2) {
+    const Split2 sp = split2(v, scale);
+    *reinterpret_cast<uint2*>(img + off) = sp.hi;
+    *reinterpret_cast<uint2*>(img + off + img_elems) = sp.lo;
   } else {
     *reinterpret_cast<bf16x4*>(img + off) = to_bf16x4(v);
   }
 }
 
-template <class TL, bool SW = false, class AL, class BL>
+template <class TL, bool SW = false, int NT = 3, class AL, class BL>
 __device__ __forceinline__ void nt_mainloop_split(AL& al, BL& bl, int K, float* As_f, float* Bs_f,
-                                                  f32x16 (&acc)[TL::TM][TL::TN]) {
-  // unpadded, XOR-swizzled term images (swz_off): 64 B per row and term, so a 128 x 128 tile takes 48 KB and three
-  // workgroups share a CU (the padded 80-byte rows allowed two)
-  constexpr int A_IMG = TL::BM * kBK, B_IMG = TL::BN * kBK;   // bf16 elements per image
+                                                  f32x16 (&acc)[TL::TM][TL::TN], float sa = 1.0f, float sb = 1.0f) {
+  // unpadded, XOR-swizzled term images (swz_off): 64 B per row and term, so a 128 x 128 tile takes 48 KB (three
+  // terms) and three workgroups share a CU (the padded 80-byte rows allowed two)
+  constexpr int A_IMG = TL::BM * kBK, B_IMG = TL::BN * kBK;   // 16-bit elements per image
   __bf16* As = reinterpret_cast<__bf16*>(As_f);
   __bf16* Bs = reinterpret_cast<__bf16*>(Bs_f);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -338,9 +420,9 @@ __device__ __forceinline__ void nt_mainloop_split(AL& al, BL& bl, int K, float* 
   for (int kt = 0; kt < nk; ++kt) {
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < TL::A_LOADS; ++i) halo_store<3>(As, A_IMG, srow + 32 * i, piece, ra[i]);
+    for (int i = 0; i < TL::A_LOADS; ++i) halo_store<NT>(As, A_IMG, srow + 32 * i, piece, ra[i], sa);
 #pragma unroll
-    for (int i = 0; i < TL::B_LOADS; ++i) halo_store<3>(Bs, B_IMG, srow + 32 * i, piece, rb[i]);
+    for (int i = 0; i < TL::B_LOADS; ++i) halo_store<NT>(Bs, B_IMG, srow + 32 * i, piece, rb[i], sb);
     __syncthreads();
     if (kt + 1 < nk) {
 #pragma unroll
@@ -350,22 +432,21 @@ __device__ __forceinline__ void nt_mainloop_split(AL& al, BL& bl, int K, float* 
     }
 #pragma unroll
     for (int kk = 0; kk < kBK / 16; ++kk) {
-      bf16x8 fa[TL::TM][3], fb[TL::TN][3];
+      bf16x8 fa[TL::TM][NT], fb[TL::TN][NT];
 #pragma unroll
       for (int i = 0; i < TL::TM; ++i)
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
+        for (int c = 0; c < NT; ++c)
           fa[i][c] = *reinterpret_cast<const bf16x8*>(As + c * A_IMG + swz_off(wm * TL::WM + i * 32 + r, kk * 2 + h));
 #pragma unroll
       for (int j = 0; j < TL::TN; ++j)
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
+        for (int c = 0; c < NT; ++c)
           fb[j][c] = *reinterpret_cast<const bf16x8*>(Bs + c * B_IMG + swz_off(wn * TL::WN + j * 32 + r, kk * 2 + h));
 #pragma unroll
       for (int i = 0; i < TL::TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TL::TN; ++j)
-          acc[i][j] = SW ? mfma_split_swapped(fa[i], fb[j], acc[i][j]) : mfma_split(fa[i], fb[j], acc[i][j]);
+        for (int j = 0; j < TL::TN; ++j) acc[i][j] = mfma_terms<NT, SW>(fa[i], fb[j], acc[i][j]);
     }
   }
 }
@@ -379,13 +460,16 @@ __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
-template <int MODE> constexpr int nt_row_floats() { return MODE == kSplit ? kSplitRowFloats : kLdsStride; }
+template <int MODE> constexpr int nt_row_floats() {
+  return MODE == kSplit ? kSplitRowFloats : MODE == kSplit2 ? 2 * kBK / 2 : kLdsStride;
+}
 
 template <class TL, int MODE, bool SW = false, class AL, class BL>
 __device__ __forceinline__ void nt_mainloop_mode(AL& al, BL& bl, int K, float* As, float* Bs,
-                                                 f32x16 (&acc)[TL::TM][TL::TN]) {
+                                                 f32x16 (&acc)[TL::TM][TL::TN], float sa = 1.0f, float sb = 1.0f) {
   if constexpr (MODE == kBf16) nt_mainloop_bf16<TL>(al, bl, K, As, Bs, acc);
-  else if constexpr (MODE == kSplit) nt_mainloop_split<TL, SW>(al, bl, K, As, Bs, acc);
+  else if constexpr (MODE == kSplit) nt_mainloop_split<TL, SW, 3>(al, bl, K, As, Bs, acc);
+  else if constexpr (MODE == kSplit2) nt_mainloop_split<TL, SW, 2>(al, bl, K, As, Bs, acc, sa, sb);
   else nt_mainloop<TL>(al, bl, K, As, Bs, acc);
 }
 
@@ -572,15 +656,19 @@ __device__ __forceinline__ bf16x8 tr_fragment(const __bf16* p, int stride) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-// NT = 3: the exact three-term split; NT = 1: operands rounded to bf16 (mixed precision)
+// NT = 3: the exact three-term split; 2: two scaled fp16 terms; 1: operands rounded to bf16 (mixed precision)
 template <int COLS, int NT>
-__device__ __forceinline__ void tn_split_store(__bf16* img, int off, const float4& v) {
+__device__ __forceinline__ void tn_split_store(__bf16* img, int off, const float4& v, float scale = 1.0f) {
   constexpr int IMG = kBK * tn_split_stride<COLS>();
   if constexpr (NT == 3) {
     const Split3 sp = split3(v);
     *reinterpret_cast<uint2*>(img + off) = sp.hi;
     *reinterpret_cast<uint2*>(img + off + IMG) = sp.mid;
     *reinterpret_cast<uint2*>(img + off + 2 * IMG) = sp.lo;
+  } else if constexpr (NT == 2) {
+    const Split2 sp = split2(v, scale);
+    *reinterpret_cast<uint2*>(img + off) = sp.hi;
+    *reinterpret_cast<uint2*>(img + off + IMG) = sp.lo;
   } else {
     *reinterpret_cast<bf16x4*>(img + off) = to_bf16x4(v);
   }
@@ -588,7 +676,7 @@ __device__ __forceinline__ void tn_split_store(__bf16* img, int off, const float
 
 template <int BM, int BN, int NT, class AL, class BL>
 __device__ __forceinline__ void tn_mainloop_split(AL& al, BL& bl, int k_begin, int k_end, float* As_f, float* Bs_f,
-                                                  f32x16 (&acc)[BM / 64][BN / 64]) {
+                                                  f32x16 (&acc)[BM / 64][BN / 64], float sa = 1.0f, float sb = 1.0f) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int SA = TnGeom<BM>::SLOTS, SB = TnGeom<BN>::SLOTS;
   constexpr int STA = tn_split_stride<BM>(), STB = tn_split_stride<BN>();
@@ -610,9 +698,9 @@ __device__ __forceinline__ void tn_mainloop_split(AL& al, BL& bl, int k_begin, i
   for (int k0 = k_begin; k0 < k_end; k0 += kBK) {
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < SA; ++i) tn_split_store<BM, NT>(As, sta + i * TnGeom<BM>::ROWS * STA, ra[i]);
+    for (int i = 0; i < SA; ++i) tn_split_store<BM, NT>(As, sta + i * TnGeom<BM>::ROWS * STA, ra[i], sa);
 #pragma unroll
-    for (int i = 0; i < SB; ++i) tn_split_store<BN, NT>(Bs, stb + i * TnGeom<BN>::ROWS * STB, rb[i]);
+    for (int i = 0; i < SB; ++i) tn_split_store<BN, NT>(Bs, stb + i * TnGeom<BN>::ROWS * STB, rb[i], sb);
     __syncthreads();
     if (k0 + kBK < k_end) {
 #pragma unroll
@@ -634,22 +722,21 @@ __device__ __forceinline__ void tn_mainloop_split(AL& al, BL& bl, int k_begin, i
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          if constexpr (NT == 3) acc[i][j] = mfma_split(fa[i], fb[j], acc[i][j]);
-          else acc[i][j] = mfma_bf16(fa[i][0], fb[j][0], acc[i][j]);
-        }
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_terms<NT>(fa[i], fb[j], acc[i][j]);
     }
   }
 }
 
 template <int MODE, int COLS> constexpr int tn_lds_floats() {
-  return MODE == kSplit ? tn_split_floats<COLS, 3>() : MODE == kBf16 ? tn_split_floats<COLS, 1>() : kBK * COLS;
+  return MODE == kSplit ? tn_split_floats<COLS, 3>() : MODE == kSplit2 ? tn_split_floats<COLS, 2>()
+       : MODE == kBf16 ? tn_split_floats<COLS, 1>() : kBK * COLS;
 }
 
 template <int MODE, int BM, int BN, class AL, class BL>
 __device__ __forceinline__ void tn_mainloop_mode(AL& al, BL& bl, int k_begin, int k_end, float* As, float* Bs,
-                                                 f32x16 (&acc)[BM / 64][BN / 64]) {
+                                                 f32x16 (&acc)[BM / 64][BN / 64], float sa = 1.0f, float sb = 1.0f) {
   if constexpr (MODE == kSplit) tn_mainloop_split<BM, BN, 3>(al, bl, k_begin, k_end, As, Bs, acc);
+  else if constexpr (MODE == kSplit2) tn_mainloop_split<BM, BN, 2>(al, bl, k_begin, k_end, As, Bs, acc, sa, sb);
   else if constexpr (MODE == kBf16) tn_mainloop_split<BM, BN, 1>(al, bl, k_begin, k_end, As, Bs, acc);
   else tn_mainloop<BM, BN>(al, bl, k_begin, k_end, As, Bs, acc);
 }

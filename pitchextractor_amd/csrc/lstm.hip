@@ -196,7 +196,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(const BwdCells cells
 template <int BM, int BN, int MODE>
 __global__ __launch_bounds__(256) void lstm_whh_grad_kernel(KRowLoader<BM> al, ShiftedTimeLoader<BN> bl, float* out,
                                                             long ldo, long split_stride, int M, int N, int K,
-                                                            int k_per_split, int tiles_n) {
+                                                            int k_per_split, int tiles_n, const unsigned* amax_a,
+                                                            const unsigned* amax_b) {
   __shared__ __attribute__((aligned(16))) float As[tn_lds_floats<MODE, BM>()];
   __shared__ __attribute__((aligned(16))) float Bs[tn_lds_floats<MODE, BN>()];
   // 1-D grid over (split, tile) with every XCD taking a CONTIGUOUS run of it: the tiles of one k-split then share
@@ -217,11 +218,13 @@ __global__ __launch_bounds__(256) void lstm_whh_grad_kernel(KRowLoader<BM> al, S
     for (int j = 0; j < BN / 64; ++j)
 #pragma unroll
       for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
-  tn_mainloop_mode<MODE, BM, BN>(al, bl, kb, ke, As, Bs, acc);
+  H2Scales hs{1.f, 1.f, 1.f};
+  if constexpr (MODE == kSplit2) hs.load(amax_a, amax_b);
+  tn_mainloop_mode<MODE, BM, BN>(al, bl, kb, ke, As, Bs, acc, hs.sa, hs.sb);
   float* dst = out + (long)split_id * split_stride;
   tn_for_each_acc<BM, BN>(acc, [&](int r, int c, float v) {
     const int row = m0 + r, col = n0 + c;
-    if (row < M && col < N) dst[(long)row * ldo + col] = v;
+    if (row < M && col < N) dst[(long)row * ldo + col] = MODE == kSplit2 ? v * hs.inv : v;
   });
 }
 
@@ -235,7 +238,7 @@ __global__ void slab_reduce_kernel(const float* ws, long n, int splits, float* o
 
 void whh_plan(int M, int N, int K, int mode, int* splits, int* kps) {
   const int tiles = pe_cdiv(M, 128) * pe_cdiv(N, 128);
-  const int s = pe_pick_splits(tiles, K, 512, mode == kSplit ? 512 : 768);
+  const int s = pe_pick_splits(tiles, K, 512, (mode == kSplit || mode == kSplit2) ? 512 : 768);
   int k = pe_cdiv(K, s);
   k = (k + kBK - 1) / kBK * kBK;
   *kps = k;
@@ -348,8 +351,10 @@ extern "C" size_t pe_lstm_whh_grad_workspace_bytes(int B, int T, int H) {
 // dW_hh[4H][H] = sum_{b,t} dgates[b][t][:]^T . y[b][t -/+ 1][:]   (y = this direction's output slice)
 template <int MODE>
 static int whh_grad_impl(const float* dgates, const float* y, long ldy, float* dwhh, int B, int T, int H,
-                         int reverse, float* workspace, size_t workspace_bytes, void* stream) {
+                         int reverse, float* workspace, size_t workspace_bytes, void* stream,
+                         const unsigned* amax_dg = nullptr, const unsigned* amax_y = nullptr) {
   if (!dgates || !y || !dwhh || B <= 0 || T <= 0 || H <= 0) return PE_E_ARG;
+  if (MODE == kSplit2 && (!amax_dg || !amax_y)) return PE_E_ARG;
   if ((H & 3) || (ldy & 3)) return PE_E_UNSUPPORTED;
   const int M = 4 * H, N = H, K = B * T;
   int splits, kps;
@@ -362,7 +367,7 @@ static int whh_grad_impl(const float* dgates, const float* y, long ldy, float* d
   const int tm = pe_cdiv(M, 128), tn = pe_cdiv(N, 128);
   hipStream_t st = pe_stream(stream);
   hipLaunchKernelGGL((lstm_whh_grad_kernel<128, 128, MODE>), dim3(tm * tn * splits), dim3(256), 0, st, al, bl,
-                     workspace, (long)N, (long)M * N, M, N, K, kps, tn);
+                     workspace, (long)N, (long)M * N, M, N, K, kps, tn, amax_dg, amax_y);
   PE_LAUNCH_CHECK();
   const long n = (long)M * N;
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(pe_cdiv(n / 4, 256)), dim3(256), 0, st, workspace, n, splits, dwhh);
@@ -379,6 +384,13 @@ extern "C" int pe_lstm_whh_grad(const float* dgates, const float* y, long ldy, f
 extern "C" int pe_lstm_whh_grad_x3(const float* dgates, const float* y, long ldy, float* dwhh, int B, int T, int H,
                                    int reverse, float* workspace, size_t workspace_bytes, void* stream) {
   return whh_grad_impl<kSplit>(dgates, y, ldy, dwhh, B, T, H, reverse, workspace, workspace_bytes, stream);
+}
+
+extern "C" int pe_lstm_whh_grad_h2(const float* dgates, const float* y, long ldy, float* dwhh, int B, int T, int H,
+                                   int reverse, float* workspace, size_t workspace_bytes, const unsigned* amax_dgates,
+                                   const unsigned* amax_y, void* stream) {
+  return whh_grad_impl<kSplit2>(dgates, y, ldy, dwhh, B, T, H, reverse, workspace, workspace_bytes, stream,
+                                amax_dgates, amax_y);
 }
 #endif
 

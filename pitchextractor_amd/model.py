@@ -208,31 +208,39 @@ def _res_forward(blk: _ResBlock, x, pool, train, need_grad, slope, x_stats=None)
     s.x = x
     s.bn_pre = _bn(blk.pre_conv[0], x, train, x_stats)
     s.p = ops.bn_act_pool_fwd(x, s.bn_pre, pool=pool, slope=slope)
-    out = ops.gemm_nt(_flat2(s.p), blk.conv1by1.weight.view(blk.cout, blk.cin)).view(*s.p.shape[:3], blk.cout)
+    s.am_p = ops.amax_for(s.p)          # "h2" products: one absmax word per operand tensor, shared by its readers
+    out = ops.gemm_nt(_flat2(s.p), blk.conv1by1.weight.view(blk.cout, blk.cin), amax_a=s.am_p)
+    out = out.view(*s.p.shape[:3], blk.cout)
     wf0, s.wd0 = ops.conv3x3_repack(blk.conv[0].weight, True, need_grad)
-    s.c, c_stats = ops.conv3x3_fwd(s.p, wf0, bn_stats=train)
+    s.c, c_stats = ops.conv3x3_fwd(s.p, wf0, bn_stats=train, amax=s.am_p)
     s.bn_mid = _bn(blk.conv[1], s.c, train, c_stats)
     s.a = ops.bn_act_pool_fwd(s.c, s.bn_mid, pool=1, slope=slope)
+    s.am_a = ops.amax_for(s.a)
     wf3, s.wd3 = ops.conv3x3_repack(blk.conv[3].weight, True, need_grad)
-    _, out_stats = ops.conv3x3_fwd(s.a, wf3, out=out, accumulate=True, bn_stats=train)   # conv(x) + conv1by1(x), model.py:171-172
+    _, out_stats = ops.conv3x3_fwd(s.a, wf3, out=out, accumulate=True, bn_stats=train,   # conv(x) + conv1by1(x), model.py:171-172
+                                   amax=s.am_a)
     return out, s, out_stats
 
 
 def _res_backward(blk: _ResBlock, s, d_out, pool, slope, grads, side):
     """d_out: grad of the block output.  Returns grad wrt the block input (dense, overwritten).  The three weight
     gradients go through `side` (_SideWork)."""
-    side.run(lambda: (ops.conv3x3_wgrad(s.a, d_out, grads[blk.conv[3].weight]),
-                      ops.gemm_tn(_flat2(d_out), _flat2(s.p), out=grads[blk.conv1by1.weight].view(blk.cout, blk.cin))),
-             d_out, on=OVERLAP_CONV_WGRAD)
+    am_do = ops.amax_for(d_out)
+    side.run(lambda: (ops.conv3x3_wgrad(s.a, d_out, grads[blk.conv[3].weight], amax_x=s.am_a, amax_dy=am_do),
+                      ops.gemm_tn(_flat2(d_out), _flat2(s.p), out=grads[blk.conv1by1.weight].view(blk.cout, blk.cin),
+                                  amax_a=am_do, amax_b=s.am_p)),
+             d_out, am_do, on=OVERLAP_CONV_WGRAD)
     with ops.timer_tag("dgrad"):
-        d_a = ops.conv3x3_fwd(d_out, s.wd3)
+        d_a = ops.conv3x3_fwd(d_out, s.wd3, amax=am_do)
     d_c = ops.bn_act_pool_bwd(s.c, d_a, s.bn_mid, grads[blk.conv[1].weight], grads[blk.conv[1].bias], pool=1,
                               slope=slope, dx=d_a)
-    side.run(lambda: ops.conv3x3_wgrad(s.p, d_c, grads[blk.conv[0].weight]), d_c, on=OVERLAP_CONV_WGRAD)
+    am_dc = ops.amax_for(d_c)
+    side.run(lambda: ops.conv3x3_wgrad(s.p, d_c, grads[blk.conv[0].weight], amax_x=s.am_p, amax_dy=am_dc), d_c, am_dc,
+             on=OVERLAP_CONV_WGRAD)
     with ops.timer_tag("dgrad"):
-        d_p = ops.conv3x3_fwd(d_c, s.wd0)
+        d_p = ops.conv3x3_fwd(d_c, s.wd0, amax=am_dc)
     w1t = ops.transpose2d(blk.conv1by1.weight.view(blk.cout, blk.cin))
-    ops.gemm_nt(_flat2(d_out), w1t, out=_flat2(d_p), accumulate=True)
+    ops.gemm_nt(_flat2(d_out), w1t, out=_flat2(d_p), accumulate=True, amax_a=am_do)
     return ops.bn_act_pool_bwd(s.x, d_p, s.bn_pre, grads[blk.pre_conv[0].weight], grads[blk.pre_conv[0].bias],
                                pool=pool, slope=slope)
 
@@ -285,10 +293,15 @@ def _lstm_forward(models, xs, train, need_grad, drop: _DropoutCfg):
         lay.gates, lay.cbuf, lay.y, lay.mask = [], [], [], []
         ys = [torch.empty((B, T, ND * H), dtype=torch.float32, device=cur[0].device) for _ in models]
         whh, gts, ysl, cbs, rev = [], [], [], [], []
+        # "h2" products: layer 0 reads the conv stack's features (one absmax pass each); deeper layers read LSTM
+        # outputs, |h| < 1, scaled by the inter-layer dropout's 1 / (1 - p): a bound serves as the scale source
+        lay.am_x = [ops.amax_for(cur[mi]) if layer == 0 else
+                    ops.amax_bound(1.0 / (1.0 - (sm.dropout if train else 0.0)), cur[mi].device)
+                    for mi, sm in enumerate(models)]
         for mi, sm in enumerate(models):
             for d in range(ND):
                 w_ih, w_hh, b_ih, b_hh = sm.model.cell(layer, d)
-                g = ops.gemm_nt(_flat2(cur[mi]), w_ih, bias0=b_ih, bias1=b_hh).view(B, T, 4 * H)
+                g = ops.gemm_nt(_flat2(cur[mi]), w_ih, bias0=b_ih, bias1=b_hh, amax_a=lay.am_x[mi]).view(B, T, 4 * H)
                 cb = torch.empty((B, T, H), dtype=torch.float32, device=g.device)
                 whh.append(w_hh); gts.append(g); cbs.append(cb); rev.append(d)
                 ysl.append(ys[mi][:, :, d * H:(d + 1) * H])
@@ -394,29 +407,32 @@ def _lstm_backward(models, saved, dys, grads, side):
         brows = [torch.empty((nrows, 4 * H), dtype=torch.float32, device=dev) for _ in whh_t] if nrows else None
         have_db = ops.lstm_bwd(whh_t, lay.gates, lay.cbuf, dsl, dcs, rev, B, T, H,     # gates now hold d(pre-activations)
                                dbias_rows=brows)
+        am_dg = [ops.amax_for(gt) for gt in lay.gates]                  # "h2": scale source of each cell's gate gradients
         # the data gradients first (the next layer's recurrence waits for them) ...
         dxs = []
         for mi, sm in enumerate(models):
             dx = torch.empty_like(lay.x[mi])
             for d in range(ND):
                 w_ih = sm.model.cell(layer, d)[0]
-                ops.gemm_nt(_flat2(lay.gates[mi * ND + d]), ops.transpose2d(w_ih), out=_flat2(dx), accumulate=(d > 0))
+                ops.gemm_nt(_flat2(lay.gates[mi * ND + d]), ops.transpose2d(w_ih), out=_flat2(dx), accumulate=(d > 0),
+                            amax_a=am_dg[mi * ND + d])
             dxs.append(dx)
 
         # ... the weight / bias gradients need nothing downstream: on the (low-priority) side stream they fill the
         # CUs the next layer's persistent recurrence leaves idle (192 of 256) and then the gaps of the conv backward
-        def weight_grads(layer=layer, lay=lay, brows=brows, have_db=have_db):
+        def weight_grads(layer=layer, lay=lay, brows=brows, have_db=have_db, am_dg=am_dg):
             for mi, sm in enumerate(models):
                 x2 = _flat2(lay.x[mi])
                 for d in range(ND):
                     w_ih, w_hh, b_ih, b_hh = sm.model.cell(layer, d)
                     dg = lay.gates[mi * ND + d]
                     dg2 = _flat2(dg)
-                    ops.gemm_tn(dg2, x2, out=grads[w_ih])
-                    ops.lstm_whh_grad(dg, lay.y[mi][:, :, d * H:(d + 1) * H], grads[w_hh], d, B, T, H)
+                    ops.gemm_tn(dg2, x2, out=grads[w_ih], amax_a=am_dg[mi * ND + d], amax_b=lay.am_x[mi])
+                    ops.lstm_whh_grad(dg, lay.y[mi][:, :, d * H:(d + 1) * H], grads[w_hh], d, B, T, H,
+                                      amax_dg=am_dg[mi * ND + d])
                     ops.colsum(brows[mi * ND + d] if have_db else dg2, grads[b_ih], grads[b_hh])
 
-        side.run(weight_grads, brows, on=OVERLAP_LSTM_WGRAD)   # (brows: alive until the side stream has read them)
+        side.run(weight_grads, brows, am_dg, on=OVERLAP_LSTM_WGRAD)   # (kept alive until the side stream has read them)
         dys = dxs
     return dys
 
@@ -759,8 +775,9 @@ class JDCNet(nn.Module):
         s.y0, y0_stats = ops.conv3x3_c1_fwd(x_btf, cbk[0].weight, bn_stats=train)
         s.bn0 = _bn(cbk[1], s.y0, train, y0_stats)
         s.a0 = ops.bn_act_pool_fwd(s.y0, s.bn0, pool=1, slope=slope)
+        s.am_a0 = ops.amax_for(s.a0)
         wf, s.wd_cb = ops.conv3x3_repack(cbk[3].weight, True, need_grad)
-        s.cb, st_cb = ops.conv3x3_fwd(s.a0, wf, bn_stats=train)                      # convblock_out
+        s.cb, st_cb = ops.conv3x3_fwd(s.a0, wf, bn_stats=train, amax=s.am_a0)        # convblock_out
         s.rb1, s.r1, st1 = _res_forward(self.res_block1, s.cb, 2, train, need_grad, slope, st_cb)
         s.rb2, s.r2, st2 = _res_forward(self.res_block2, s.rb1, 2, train, need_grad, slope, st1)
         s.rb3, s.r3, st3 = _res_forward(self.res_block3, s.rb2, 2, train, need_grad, slope, st2)
@@ -876,9 +893,11 @@ class JDCNet(nn.Module):
         ops.maxpool_bwd_add(s.cb, d_concat, d_cb, 40, coff=0)
 
         cbk = self.conv_block
-        side.run(lambda: ops.conv3x3_wgrad(s.a0, d_cb, g[cbk[3].weight]), d_cb, on=OVERLAP_CONV_WGRAD)
+        am_dcb = ops.amax_for(d_cb)
+        side.run(lambda: ops.conv3x3_wgrad(s.a0, d_cb, g[cbk[3].weight], amax_x=s.am_a0, amax_dy=am_dcb), d_cb, am_dcb,
+                 on=OVERLAP_CONV_WGRAD)
         with ops.timer_tag("dgrad"):
-            d_a0 = ops.conv3x3_fwd(d_cb, s.wd_cb)
+            d_a0 = ops.conv3x3_fwd(d_cb, s.wd_cb, amax=am_dcb)
         d_y0 = ops.bn_act_pool_bwd(s.y0, d_a0, s.bn0, g[cbk[1].weight], g[cbk[1].bias], pool=1, slope=slope, dx=d_a0)
         ops.conv3x3_c1_wgrad(s.x_btf, d_y0, g[cbk[0].weight])
         side.join()                             # every weight gradient is final from here on

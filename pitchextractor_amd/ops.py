@@ -125,17 +125,74 @@ HALF_DTYPE = "bf16"
 #   "x3"     every fp32 operand is split exactly into three bf16 terms and six cross products are
 #            accumulated in fp32 on the bf16 MFMA pipe (16x the fp32 MFMA rate on gfx950); measured
 #            error against fp64 is the same as the native path's (tests/test_ops_gpu.py).  Default.
+#   "h2"     every fp32 operand becomes TWO fp16 terms of the tensor scaled by a power of two (absmax below) and
+#            three cross products are accumulated in fp32: half the matrix work of "x3", per-product error
+#            <= 2^-21 (csrc/gemm_engine.h).
 #   "native" v_mfma_f32_32x32x2_f32.
-FP32_MATMUL = os.environ.get("PE_FP32_MATMUL", "x3")
+FP32_MATMUL = os.environ.get("PE_FP32_MATMUL", "h2")
+_FP32_MODES = ("native", "x3", "h2")
+
+
+_UNIT_AMAX: dict = {}
+
+
+def _unit_amax(device):
+    """absmax word of a tensor known to lie in [-1, 1] (LSTM outputs): the bits of 1.0f, no pass over the data."""
+    key = torch.device(device)
+    if key not in _UNIT_AMAX:
+        _UNIT_AMAX[key] = torch.full((1,), 0x3F800000, dtype=torch.int32, device=key)
+    return _UNIT_AMAX[key]
+
+
+def h2_active() -> bool:
+    """True when fp32 products run as two scaled fp16 terms, i.e. when GEMM / conv operands need an absmax word."""
+    return (not MATMUL_BF16) and FP32_MATMUL == "h2"
+
+
+def amax_for(t):
+    """absmax(t) in "h2" mode, else None: what model code hands on to the products that read ``t``."""
+    return absmax(t) if h2_active() else None
+
+
+_BOUND_AMAX: dict = {}
+
+
+def amax_bound(bound: float, device):
+    """absmax word for a tensor known to satisfy |x| <= bound (no pass over the data); None outside "h2" mode."""
+    if not h2_active():
+        return None
+    key = (torch.device(device), float(bound))
+    if key not in _BOUND_AMAX:
+        import struct
+        bits = struct.unpack("<i", struct.pack("<f", float(bound)))[0]
+        _BOUND_AMAX[key] = torch.full((1,), bits, dtype=torch.int32, device=key[0])
+    return _BOUND_AMAX[key]
+
+
+def absmax(t, out=None):
+    """uint32 device word = IEEE bits of max |t| (t: float32, 1-D / 2-D row-strided / dense N-D): the scale source of
+    an "h2" operand."""
+    _f32c(t, "absmax operand")
+    if t.dim() == 2 and t.stride(1) == 1:
+        rows, cols, ld = _rows2d(t, "absmax operand")
+    else:
+        _chk(t.is_contiguous(), "absmax: expected a dense tensor or a row-strided matrix")
+        cols = t.shape[-1] if t.dim() > 1 else t.numel()
+        rows, ld = t.numel() // max(cols, 1), cols
+    if out is None:
+        out = torch.empty((1,), dtype=torch.int32, device=t.device)
+    _chk(out.is_cuda and out.dtype == torch.int32 and out.numel() == 1, "absmax: out is an int32 device word")
+    _call("pe_absmax", t.data_ptr(), rows, cols, ld, out.data_ptr(), _s())
+    return out
 
 
 def _tn_suffix():
     """Weight-gradient / k-major products: bf16 operands under mixed precision (what autocast's backward does),
     otherwise fp32-accurate (native or three-term split)."""
-    _chk(FP32_MATMUL in ("native", "x3"), "ops.FP32_MATMUL must be 'native' or 'x3'")
+    _chk(FP32_MATMUL in _FP32_MODES, "ops.FP32_MATMUL must be 'native', 'x3' or 'h2'")
     if MATMUL_BF16:
         return "_" + HALF_DTYPE
-    return "_x3" if FP32_MATMUL == "x3" else ""
+    return "_" + FP32_MATMUL if FP32_MATMUL != "native" else ""
 
 
 # which persistent LSTM recurrences use the three-term split when FP32_MATMUL == "x3" (tools/bench_lstm.py)
@@ -145,16 +202,16 @@ LSTM_X3 = {"fwd": os.environ.get("PE_LSTM_X3_FWD", "1") == "1", "bwd": os.enviro
 def _lstm_suffix(which):
     if MATMUL_BF16:
         return "_" + HALF_DTYPE        # mixed precision: 16-bit recurrent products (as autocast runs nn.LSTM)
-    return "_x3" if (FP32_MATMUL == "x3" and LSTM_X3[which]) else ""
+    # "h2" products need a tensor-wide scale before the first element is produced; the recurrences make their
+    # operands step by step, so they keep the three-term bf16 split in that mode
+    return "_x3" if (FP32_MATMUL in ("x3", "h2") and LSTM_X3[which]) else ""
 
 
 def _nt_suffix():
     if MATMUL_BF16:
         return "_" + HALF_DTYPE
-    if FP32_MATMUL == "x3":
-        return "_x3"
-    _chk(FP32_MATMUL == "native", "ops.FP32_MATMUL must be 'native' or 'x3'")
-    return ""
+    _chk(FP32_MATMUL in _FP32_MODES, "ops.FP32_MATMUL must be 'native', 'x3' or 'h2'")
+    return "_" + FP32_MATMUL if FP32_MATMUL != "native" else ""
 
 
 class matmul_bf16:
@@ -184,8 +241,9 @@ class matmul_bf16:
 GEMM_WFRAG = os.environ.get("PE_GEMM_WFRAG", "0") == "1"
 
 
-def gemm_nt(A, B, bias0=None, bias1=None, out=None, accumulate=False):
-    """out[M,N] = A[M,K] @ B[N,K]^T + bias0 + bias1 (+ out)."""
+def gemm_nt(A, B, bias0=None, bias1=None, out=None, accumulate=False, amax_a=None, amax_b=None):
+    """out[M,N] = A[M,K] @ B[N,K]^T + bias0 + bias1 (+ out).  ``amax_*``: the operands' absmax words when the caller
+    already has them ("h2" mode; computed here otherwise)."""
     M, K, lda = _rows2d(A, "A")
     N, K2, ldb = _rows2d(B, "B")
     _chk(K == K2, "gemm_nt: K mismatch")
@@ -204,12 +262,19 @@ def gemm_nt(A, B, bias0=None, bias1=None, out=None, accumulate=False):
         _call("pe_gemm_nt_wf" + sfx, A.data_ptr(), lda, wf.data_ptr(), out.data_ptr(), ldc, M, N, K,
               _lib.ptr(bias0), _lib.ptr(bias1), int(bool(accumulate)), _s(), work=2.0 * M * N * K)
         return out
+    if sfx == "_h2":
+        amax_a = absmax(A) if amax_a is None else amax_a
+        amax_b = absmax(B) if amax_b is None else amax_b
+        _call("pe_gemm_nt_h2", A.data_ptr(), lda, B.data_ptr(), ldb, out.data_ptr(), ldc, M, N, K,
+              _lib.ptr(bias0), _lib.ptr(bias1), int(bool(accumulate)), amax_a.data_ptr(), amax_b.data_ptr(), _s(),
+              work=2.0 * M * N * K)
+        return out
     _call("pe_gemm_nt" + sfx, A.data_ptr(), lda, B.data_ptr(), ldb, out.data_ptr(), ldc, M, N, K,
           _lib.ptr(bias0), _lib.ptr(bias1), int(bool(accumulate)), _s(), work=2.0 * M * N * K)
     return out
 
 
-def gemm_tn(A, B, out=None, accumulate=False):
+def gemm_tn(A, B, out=None, accumulate=False, amax_a=None, amax_b=None):
     """out[M,N] = A[K,M]^T @ B[K,N] (+ out); deterministic split-K."""
     K, M, lda = _rows2d(A, "A")
     K2, N, ldb = _rows2d(B, "B")
@@ -222,6 +287,13 @@ def gemm_tn(A, B, out=None, accumulate=False):
     lib = _lib.load()
     need = lib.pe_gemm_tn_workspace_bytes(M, N, K)
     ws = workspace(need, A.device)
+    if _tn_suffix() == "_h2":
+        amax_a = absmax(A) if amax_a is None else amax_a
+        amax_b = absmax(B) if amax_b is None else amax_b
+        _call("pe_gemm_tn_h2", A.data_ptr(), lda, B.data_ptr(), ldb, out.data_ptr(), ldc, M, N, K,
+              int(bool(accumulate)), ws.data_ptr(), ws.numel(), amax_a.data_ptr(), amax_b.data_ptr(), _s(),
+              work=2.0 * M * N * K)
+        return out
     _call("pe_gemm_tn" + _tn_suffix(), A.data_ptr(), lda, B.data_ptr(), ldb, out.data_ptr(), ldc, M, N, K,
           int(bool(accumulate)), ws.data_ptr(), ws.numel(), _s(), work=2.0 * M * N * K)
     return out
@@ -244,26 +316,30 @@ CONV_WFRAG = os.environ.get("PE_CONV_WFRAG", "1") == "1"
 
 
 class PackedWeight:
-    """One packed 3x3 weight: ``fp32`` [N, 9*C] (native MFMA path, fallback shapes) and, in the x3 / bf16 / f16 modes,
-    ``frag`` = the same matrix as 16-bit MFMA fragments (``terms`` = 3 exact bf16 terms or 1 rounded term of
-    ``half``)."""
+    """One packed 3x3 weight: ``fp32`` [N, 9*C] (native MFMA path, fallback shapes) and, in the x3 / h2 / bf16 / f16
+    modes, ``frag`` = the same matrix as 16-bit MFMA fragments (``terms`` = 3 exact bf16 terms, 2 scaled fp16 terms
+    with ``amax`` = the weight's absmax word, or 1 rounded term of ``half``)."""
 
-    def __init__(self, fp32, frag=None, terms=0, half=None):
-        self.fp32, self.frag, self.terms, self.half = fp32, frag, terms, half
+    def __init__(self, fp32, frag=None, terms=0, half=None, amax=None):
+        self.fp32, self.frag, self.terms, self.half, self.amax = fp32, frag, terms, half, amax
 
     @property
     def shape(self):
         return self.fp32.shape
 
 
-def wfrag_pack(w2d, terms):
-    """[N, K] float32 (K % 16 == 0) -> fragment-ordered bf16 terms (uint8 buffer)."""
+def wfrag_pack(w2d, terms, amax=None):
+    """[N, K] float32 (K % 16 == 0) -> fragment-ordered 16-bit terms (uint8 buffer); terms == 2 needs the weight's
+    absmax word."""
     N, K, ld = _rows2d(w2d, "w")
     lib = _lib.load()
     nbytes = lib.pe_wfrag_bytes(N, K, terms)
-    _chk(nbytes > 0, "wfrag_pack: K must be a multiple of 16 and terms 1 or 3")
+    _chk(nbytes > 0, "wfrag_pack: K must be a multiple of 16 and terms 1, 2 or 3")
     out = torch.empty((nbytes,), dtype=torch.uint8, device=w2d.device)
-    if terms == 1 and MATMUL_BF16 and HALF_DTYPE == "f16":
+    if terms == 2:
+        _chk(amax is not None, "wfrag_pack: two-term fragments need amax")
+        _call("pe_wfrag_pack_h2", w2d.data_ptr(), ld, N, K, amax.data_ptr(), out.data_ptr(), _s())
+    elif terms == 1 and MATMUL_BF16 and HALF_DTYPE == "f16":
         _call("pe_wfrag_pack_f16", w2d.data_ptr(), ld, N, K, out.data_ptr(), _s())
     else:
         _call("pe_wfrag_pack", w2d.data_ptr(), ld, N, K, int(terms), out.data_ptr(), _s())
@@ -272,7 +348,7 @@ def wfrag_pack(w2d, terms):
 
 def _mode_terms():
     sfx = _nt_suffix()
-    return 3 if sfx == "_x3" else 1 if sfx in ("_bf16", "_f16") else 0
+    return 3 if sfx == "_x3" else 2 if sfx == "_h2" else 1 if sfx in ("_bf16", "_f16") else 0
 
 
 def conv3x3_repack(w, want_fwd=True, want_dgrad=True):
@@ -284,19 +360,21 @@ def conv3x3_repack(w, want_fwd=True, want_dgrad=True):
     wd = torch.empty((ci, 9 * co), dtype=torch.float32, device=w.device) if want_dgrad else None
     _call("pe_conv3x3_repack", w.data_ptr(), _lib.ptr(wf), _lib.ptr(wd), co, ci, _s())
     terms = _mode_terms() if CONV_WFRAG else 0
+    amax = absmax(w.view(co, ci * 9)) if _mode_terms() == 2 else None   # forward and data-gradient forms share it
     out = []
     for t in (wf, wd):
         if t is None:
             out.append(None)
         elif terms and t.shape[1] % 16 == 0:
-            out.append(PackedWeight(t, wfrag_pack(t, terms), terms, HALF_DTYPE if terms == 1 else None))
+            out.append(PackedWeight(t, wfrag_pack(t, terms, amax), terms, HALF_DTYPE if terms == 1 else None, amax))
         else:
-            out.append(PackedWeight(t))
+            out.append(PackedWeight(t, amax=amax))
     return out[0], out[1]
 
 
-def conv3x3_fwd(x, w_packed, out=None, accumulate=False, bn_stats=None):
+def conv3x3_fwd(x, w_packed, out=None, accumulate=False, bn_stats=None, amax=None):
     """x [B,T,F,C], w_packed [N, 9*C] (tensor or PackedWeight) -> y [B,T,F,N] (+= when accumulate).
+    ``amax``: x's absmax word when the caller has it ("h2" mode; computed here otherwise).
     ``bn_stats`` True / False (not None) returns (y, partials): with True the fragment-fed kernel leaves the BatchNorm
     column sums of its final outputs behind ([tiles, 2, N] float64, for ``bn_train_stats(..., partials=)``);
     partials is None when not asked for or when another kernel ran."""
@@ -312,6 +390,10 @@ def conv3x3_fwd(x, w_packed, out=None, accumulate=False, bn_stats=None):
         out = torch.empty((B, T, F, N), dtype=torch.float32, device=x.device)
     _chk(_dense(out, "out").shape == (B, T, F, N), "conv3x3_fwd: out shape")
     sfx = _nt_suffix()
+    h2 = ()
+    if sfx == "_h2":
+        amax_w = pw.amax if pw.amax is not None else absmax(w32)
+        h2 = ((absmax(x) if amax is None else amax).data_ptr(), amax_w.data_ptr())
     if (pw.frag is not None and pw.terms == _mode_terms() and CONV_WFRAG
             and (pw.terms != 1 or pw.half == HALF_DTYPE) and _lib.load().pe_conv3x3_wf_supported(F, Cc, N)):
         parts = None
@@ -319,14 +401,14 @@ def conv3x3_fwd(x, w_packed, out=None, accumulate=False, bn_stats=None):
             parts = torch.empty((_lib.load().pe_conv3x3_wf_stat_parts(B, T, F), 2, N), dtype=torch.float64,
                                 device=x.device)
         _call("pe_conv3x3_fwd_wf" + sfx, x.data_ptr(), pw.frag.data_ptr(), out.data_ptr(), B, T, F, Cc, N,
-              int(bool(accumulate)), _lib.ptr(parts), _s(), work=2.0 * B * T * F * N * 9 * Cc)
+              int(bool(accumulate)), _lib.ptr(parts), *h2, _s(), work=2.0 * B * T * F * N * 9 * Cc)
         return (out, parts) if bn_stats is not None else out
     _call("pe_conv3x3_fwd" + sfx, x.data_ptr(), w32.data_ptr(), out.data_ptr(), B, T, F, Cc, N,
-          int(bool(accumulate)), _s(), work=2.0 * B * T * F * N * 9 * Cc)
+          int(bool(accumulate)), *h2, _s(), work=2.0 * B * T * F * N * 9 * Cc)
     return (out, None) if bn_stats is not None else out
 
 
-def conv3x3_wgrad(x, dy, dw):
+def conv3x3_wgrad(x, dy, dw, amax_x=None, amax_dy=None):
     """dw (OIHW view, contiguous) = grad of conv3x3 wrt weights."""
     x = _dense(x, "x")
     dy = _dense(dy, "dy")
@@ -337,8 +419,11 @@ def conv3x3_wgrad(x, dy, dw):
     _chk(dw.shape == (Co, Ci, 3, 3), "conv3x3_wgrad: dw shape")
     lib = _lib.load()
     ws = workspace(lib.pe_conv3x3_wgrad_workspace_bytes(B, T, F, Ci, Co), x.device)
+    h2 = ()
+    if _tn_suffix() == "_h2":
+        h2 = ((absmax(x) if amax_x is None else amax_x).data_ptr(), (absmax(dy) if amax_dy is None else amax_dy).data_ptr())
     _call("pe_conv3x3_wgrad" + _tn_suffix(), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, T, F, Ci, Co,
-          ws.data_ptr(), ws.numel(), _s(), work=2.0 * B * T * F * Co * 9 * Ci)
+          ws.data_ptr(), ws.numel(), *h2, _s(), work=2.0 * B * T * F * Co * 9 * Ci)
     return dw
 
 
@@ -654,15 +739,20 @@ def lstm_bwd_dbias_rows(n, B, T, H, ld, device) -> int:
     return int(_lib.load().pe_lstm_bwd_persistent_dbias_rows(terms, n, B, T, H, ld))
 
 
-def lstm_whh_grad(dgates, y_slice, dwhh, reverse, B, T, H):
+def lstm_whh_grad(dgates, y_slice, dwhh, reverse, B, T, H, amax_dg=None, amax_y=None):
     _chk(_dense(dgates, "dgates").shape == (B, T, 4 * H), "dgates shape")
     ys = _f32c(y_slice, "y")
     _chk(ys.shape == (B, T, H) and ys.stride(2) == 1 and ys.stride(0) == T * ys.stride(1), "y slice layout")
     _chk(_dense(dwhh, "dwhh").shape == (4 * H, H), "dwhh shape")
     lib = _lib.load()
     ws = workspace(lib.pe_lstm_whh_grad_workspace_bytes(B, T, H), dgates.device)
+    h2 = ()
+    if _tn_suffix() == "_h2":
+        if amax_y is None:                 # |h| < 1 by construction (o * tanh(c)): a constant bound is a valid amax
+            amax_y = _unit_amax(dgates.device)
+        h2 = ((absmax(dgates) if amax_dg is None else amax_dg).data_ptr(), amax_y.data_ptr())
     _call("pe_lstm_whh_grad" + _tn_suffix(), dgates.data_ptr(), ys.data_ptr(), ys.stride(1), dwhh.data_ptr(), B, T, H,
-          int(bool(reverse)), ws.data_ptr(), ws.numel(), _s(), work=2.0 * B * T * 4 * H * H)
+          int(bool(reverse)), ws.data_ptr(), ws.numel(), *h2, _s(), work=2.0 * B * T * 4 * H * H)
     return dwhh
 
 

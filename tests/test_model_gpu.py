@@ -52,7 +52,7 @@ def test_state_dict_layout_matches_reference(G, hip_device):
     assert all(p.data_ptr() >= net.flat_parameters.data_ptr() for p in net.parameters())
 
 
-@pytest.mark.parametrize("fp32_mode", ["x3", "native"])
+@pytest.mark.parametrize("fp32_mode", ["h2", "x3", "native"])
 @pytest.mark.parametrize("tag,nc,hidden", [("nc1", 1, 384), ("nc360", 360, 64)])
 def test_eval_forward_matches_reference_golden(G, hip_device, tag, nc, hidden, fp32_mode, monkeypatch):
     monkeypatch.setattr(ops, "FP32_MATMUL", fp32_mode)
@@ -64,7 +64,7 @@ def test_eval_forward_matches_reference_golden(G, hip_device, tag, nc, hidden, f
     close(det, G[f"{tag}_eval_det"], 1e-4)
 
 
-@pytest.fixture(scope="module", params=["x3", "native"])
+@pytest.fixture(scope="module", params=["h2", "x3", "native"])
 def train_pass(hip_device, request):
     prev, ops.FP32_MATMUL = ops.FP32_MATMUL, request.param
     try:
@@ -259,7 +259,7 @@ def _hip_step_grads(state, x, f0, sil, device):
     return cls, det, out3[0].item(), {n: p.grad.detach().clone() for n, p in net.named_parameters()}
 
 
-@pytest.mark.parametrize("fp32_mode", ["x3", "native"])
+@pytest.mark.parametrize("fp32_mode", ["h2", "x3", "native"])
 def test_full_size_training_step_matches_oracle_by_tiling(hip_device, oracle_b8, fp32_mode, monkeypatch):
     """BASELINE config[1] size (B = 256, train mode, default BiLSTM) against the float64 oracle.
 

@@ -39,7 +39,7 @@ def nchw(x):
 # ------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("M,N,K", [(300, 1536, 384), (1000, 64, 576), (257, 192, 96), (130, 20, 64),
                                    (64, 128, 32), (5, 360, 768), (1024, 256, 640), (33, 1, 4)])
-@pytest.mark.parametrize("fp32_mode", ["native", "x3"])
+@pytest.mark.parametrize("fp32_mode", ["native", "x3", "h2"])
 def test_gemm_nt(hip_device, M, N, K, fp32_mode, monkeypatch):
     monkeypatch.setattr(ops, "FP32_MATMUL", fp32_mode)
     A, B = rnd(M, K, seed=1), rnd(N, K, seed=2)
@@ -130,14 +130,56 @@ def test_x3_split_is_as_accurate_as_native_fp32(hip_device):
     mag = A.double().abs() @ B.double().abs().T                      # condition-free error scale
     errs = {}
     prev = ops.FP32_MATMUL
-    for mode in ("native", "x3"):
+    for mode in ("native", "x3", "h2"):
         ops.FP32_MATMUL = mode
         try:
             got = ops.gemm_nt(A.to(hip_device), B.to(hip_device)).cpu().double()
         finally:
             ops.FP32_MATMUL = prev
         errs[mode] = ((got - ref).abs() / mag).max().item()
-    assert errs["native"] < 2e-5 and errs["x3"] <= 2 * errs["native"], errs
+    assert errs["native"] < 2e-5 and errs["x3"] <= 2 * errs["native"] and errs["h2"] <= 2 * errs["native"], errs
+
+
+def test_absmax_is_exact_and_covers_strided_views(hip_device):
+    """pe_absmax: the IEEE bits of max |x|, exact (integer max of bit patterns), for dense tensors and row-strided
+    views, including a maximum sitting in the last element, a negative maximum and an all-zero tensor."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1000, 64, generator=g)
+    x[999, 63] = -77.25
+    xd = x.to(hip_device)
+    bits = lambda v: torch.tensor(v, dtype=torch.float32).view(torch.int32).item()     # noqa: E731
+    assert ops.absmax(xd).item() == bits(77.25)
+    assert ops.absmax(xd[:, 16:48]).item() == bits(float(x[:, 16:48].abs().max()))
+    assert ops.absmax(xd.view(10, 100, 64)).item() == bits(77.25)
+    assert ops.absmax(torch.zeros(8, 4, device=hip_device)).item() == 0
+    big = torch.randn(3000, 1024, generator=g)
+    assert ops.absmax(big.to(hip_device)).item() == bits(float(big.abs().max()))
+
+
+@pytest.mark.parametrize("scale_a,scale_b", [(1e-30, 1e20), (3e15, 2e-12), (1.0, 1e-36), (7e-17, 7e-17)])
+def test_h2_products_over_the_exponent_range(hip_device, scale_a, scale_b, monkeypatch):
+    """The two-term fp16 split takes its range from the per-tensor power-of-two scale: operands far outside fp16's
+    own range (1e-30 .. 1e20, products down to 1e-39) and a 2^40 spread INSIDE one operand come out with the error
+    of the native fp32 path, for the NT and the TN product."""
+    monkeypatch.setattr(ops, "FP32_MATMUL", "h2")
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 256, 192, 512
+    A = torch.randn(M, K, generator=g) * torch.exp2(-40 * torch.rand(M, K, generator=g)) * scale_a
+    B = torch.randn(N, K, generator=g) * scale_b
+    ref = A.double() @ B.double().T
+    mag = A.double().abs() @ B.double().abs().T
+    got = ops.gemm_nt(A.to(hip_device), B.to(hip_device)).cpu().double()
+    assert torch.isfinite(got).all()
+    assert ((got - ref).abs() / mag).max().item() < 2e-6
+    got_tn = ops.gemm_tn(A.t().contiguous().to(hip_device), B.t().contiguous().to(hip_device)).cpu().double()
+    assert ((got_tn - ref).abs() / mag).max().item() < 2e-6
+
+
+def test_h2_all_zero_operand(hip_device, monkeypatch):
+    monkeypatch.setattr(ops, "FP32_MATMUL", "h2")
+    A = torch.zeros(128, 64, device=hip_device)
+    B = torch.randn(96, 64, device=hip_device)
+    assert torch.equal(ops.gemm_nt(A, B), torch.zeros(128, 96, device=hip_device))
 
 
 def test_weight_gradient_products_bf16_operands(hip_device):
@@ -168,7 +210,7 @@ def test_gemm_nt_strided_rows(hip_device):
 
 
 @pytest.mark.parametrize("K,M,N", [(5000, 64, 64), (3001, 192, 128), (777, 1536, 96), (20000, 128, 64), (64, 4, 8)])
-@pytest.mark.parametrize("fp32_mode", ["native", "x3"])
+@pytest.mark.parametrize("fp32_mode", ["native", "x3", "h2"])
 def test_gemm_tn(hip_device, K, M, N, fp32_mode, monkeypatch):
     monkeypatch.setattr(ops, "FP32_MATMUL", fp32_mode)
     A, B = rnd(K, M, seed=1), rnd(K, N, seed=2)
@@ -195,7 +237,7 @@ def test_transpose2d(hip_device):
                                           (1, 3, 80, 64, 64), (1, 5, 45, 64, 128), (1, 4, 50, 64, 128),
                                           (2, 1, 33, 96, 160),
                                           (2, 64, 40, 64, 64), (2, 48, 40, 128, 128)])   # > 2048 pixels: split-K slabs
-@pytest.mark.parametrize("fp32_mode", ["native", "x3"])
+@pytest.mark.parametrize("fp32_mode", ["native", "x3", "h2"])
 def test_conv3x3_fwd_dgrad_wgrad(hip_device, B, T, Fq, Ci, Co, fp32_mode, monkeypatch):
     monkeypatch.setattr(ops, "FP32_MATMUL", fp32_mode)
     x = rnd(B, Ci, T, Fq, seed=1).double().requires_grad_(True)
@@ -431,7 +473,7 @@ def test_lstm_layer_bidirectional(hip_device, B, T, In, H, persistent, monkeypat
     dcar = [torch.empty(B, H, device=dev) for _ in range(2)]
     # the k-split recurrence kernel also emits the bias gradients as per-batch-tile rows (H = 384, persistent)
     nrows = ops.lstm_bwd_dbias_rows(2, B, T, H, dsl[0].stride(1), dev)
-    assert (nrows > 0) == (persistent and H == 384 and ops.FP32_MATMUL == "x3")
+    assert (nrows > 0) == (persistent and H == 384 and ops.FP32_MATMUL in ("x3", "h2"))
     brows = [torch.full((nrows, 4 * H), float("nan"), device=dev) for _ in range(2)] if nrows else None
     assert ops.lstm_bwd(whh_t, gates, cbuf, dsl, dcar, [0, 1], B, T, H, dbias_rows=brows) == (nrows > 0)
     dx = torch.empty(B, T, In, device=dev)
