@@ -225,7 +225,8 @@ int pe_lstm_fwd_persistent_f16(int ncells, const float* const* whh, float* const
                            unsigned* sync, void* stream);
 int pe_lstm_bwd_persistent_f16(int ncells, const float* const* whh_t, float* const* gates,
                            const float* const* cbuf, const float* const* dy, const int* reverse, long lddy,
-                           int B, int T, int H, float* const* dbias_rows, unsigned* sync, void* stream);
+                           int B, int T, int H, float* const* dbias_rows, unsigned* const* dgates_amax,
+                           unsigned* sync, void* stream);
 int pe_lstm_whh_grad_f16(const float* dgates, const float* y, long ldy, float* dwhh, int B, int T, int H,
                      int reverse, float* workspace, size_t workspace_bytes, void* stream);
 int pe_wfrag_pack_f16(const float* w, long ld, int N, int K, void* wfrag, void* stream);
@@ -236,7 +237,11 @@ int pe_wfrag_pack_f16(const float* w, long ld, int N, int K, void* wfrag, void* 
  * unbiased variance, plus the fused affine scale = gamma*invstd, shift = beta - mean*scale.
  * pe_bn_act_pool_fwd: y = maxpool_k(lrelu(x*scale + shift)) written at
  *   y[(row*Fout + fo)*ldy + coff + c] (model.py:36-41,148-153).
- * pe_bn_act_pool_bwd: gradient of that block w.r.t. x, gamma, beta (train-mode BN). */
+ * pe_bn_act_pool_bwd: gradient of that block w.r.t. x, gamma, beta (train-mode BN).
+ * amax_out (optional, these two and pe_maxpool_bwd_add): a device word the caller zeroed; the pass max-merges the
+ *   IEEE bits of the largest magnitude it stored into it (atomicMax), which is the scale source an "h2" product
+ *   reading the output needs (pe_gemm_nt_h2) -- no separate pe_absmax pass.  pe_maxpool_bwd_add merges the values it
+ *   rewrote into dx's word: the result bounds max |dx| from above. */
 size_t pe_bn_workspace_bytes(int C);
 int pe_bn_train_stats(const float* x, long n_pix, int C, const float* gamma, const float* beta, float eps,
                       float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
@@ -248,16 +253,16 @@ int pe_bn_finalize_stats(const double* partials, int nparts, long n_pix, int C, 
 int pe_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
                       const float* running_var, float eps, int C, float* scale, float* shift, void* stream);
 int pe_bn_act_pool_fwd(const float* x, const float* scale, const float* shift, float slope, float* y,
-                       long rows, int Fin, int C, int pool, long ldy, int coff, void* stream);
+                       long rows, int Fin, int C, int pool, long ldy, int coff, unsigned* amax_out, void* stream);
 int pe_bn_act_pool_bwd(const float* x, const float* dy, const float* scale, const float* shift,
                        const float* mean, const float* invstd, float slope, float* dx, float* dgamma,
                        float* dbeta, long rows, int Fin, int C, int pool, long lddy, int coff,
-                       void* workspace, size_t workspace_bytes, void* stream);
+                       void* workspace, size_t workspace_bytes, unsigned* amax_out, void* stream);
 /* detector-branch MaxPool2d((1,40|20|10)) (model.py:45-49,103-105) into a channel slice */
 int pe_maxpool_fwd(const float* x, float* y, long rows, int Fin, int C, int pool, long ldy, int coff,
                    void* stream);
 int pe_maxpool_bwd_add(const float* x, const float* dy, float* dx, long rows, int Fin, int C, int pool,
-                       long lddy, int coff, void* stream);
+                       long lddy, int coff, unsigned* amax_out, void* stream);
 /* nn.Dropout (model.py:40,56; LSTM inter-layer): Philox4x32-10 keyed by (seed, offset + quad index);
  * mask bytes (1 = kept) can be exported (mask_out) or replayed (mask_in). */
 int pe_dropout_fwd(const float* x, long ldx, float* y, long ldy, const unsigned char* mask_in,
@@ -294,11 +299,14 @@ int pe_lstm_fwd_persistent(int ncells, const float* const* whh, float* const* ga
                            unsigned* sync, void* stream);
 int pe_lstm_bwd_persistent(int ncells, const float* const* whh_t, float* const* gates,
                            const float* const* cbuf, const float* const* dy, const int* reverse, long lddy,
-                           int B, int T, int H, float* const* dbias_rows, unsigned* sync, void* stream);
+                           int B, int T, int H, float* const* dbias_rows, unsigned* const* dgates_amax,
+                           unsigned* sync, void* stream);
 /* dbias_rows (nullable): per cell a [pe_lstm_bwd_persistent_dbias_rows()][4H] buffer that receives the per-batch-tile
  * column sums of the gate gradients (their row sum is dL/db_ih = dL/db_hh), replacing a pe_colsum pass over the
  * [B*T][4H] gradient tensor.  Written only when the query below returns non-zero for the configuration
- * (terms: 0 pe_lstm_bwd_persistent, 3 _x3, 1 _bf16 / _f16). */
+ * (terms: 0 pe_lstm_bwd_persistent, 3 _x3, 1 _bf16 / _f16).
+ * dgates_amax (nullable): per cell a device word the caller zeroed; under the same condition the kernel max-merges
+ * the IEEE bits of the largest gate-gradient magnitude into it (the "h2" scale source of the dX / dW products). */
 int pe_lstm_bwd_persistent_dbias_rows(int terms, int ncells, int B, int T, int H, long lddy);
 /* same recurrences with the recurrent products as the exact three-term bf16 split (H % 64 == 0; other
  * hidden sizes run the native fp32 MFMA form) */
@@ -307,14 +315,16 @@ int pe_lstm_fwd_persistent_x3(int ncells, const float* const* whh, float* const*
                            unsigned* sync, void* stream);
 int pe_lstm_bwd_persistent_x3(int ncells, const float* const* whh_t, float* const* gates,
                            const float* const* cbuf, const float* const* dy, const int* reverse, long lddy,
-                           int B, int T, int H, float* const* dbias_rows, unsigned* sync, void* stream);
+                           int B, int T, int H, float* const* dbias_rows, unsigned* const* dgates_amax,
+                           unsigned* sync, void* stream);
 /* mixed precision: W_hh and the h / dgates rows rounded to bf16, fp32 accumulate and cell state */
 int pe_lstm_fwd_persistent_bf16(int ncells, const float* const* whh, float* const* gates, float* const* y,
                            float* const* cbuf, const int* reverse, long ldy, int B, int T, int H,
                            unsigned* sync, void* stream);
 int pe_lstm_bwd_persistent_bf16(int ncells, const float* const* whh_t, float* const* gates,
                            const float* const* cbuf, const float* const* dy, const int* reverse, long lddy,
-                           int B, int T, int H, float* const* dbias_rows, unsigned* sync, void* stream);
+                           int B, int T, int H, float* const* dbias_rows, unsigned* const* dgates_amax,
+                           unsigned* sync, void* stream);
 size_t pe_lstm_whh_grad_workspace_bytes(int B, int T, int H);
 int pe_lstm_whh_grad(const float* dgates, const float* y, long ldy, float* dwhh, int B, int T, int H,
                      int reverse, float* workspace, size_t workspace_bytes, void* stream);

@@ -80,10 +80,10 @@ PROTOTYPES = {
     "pe_conv3x3_wf_stat_parts": (_i, [_i, _i, _i]),
     "pe_bn_finalize_stats": (_i, [_p, _i, _l, _i, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _z, _p]),
     "pe_bn_eval_affine": (_i, [_p, _p, _p, _p, _f, _i, _p, _p, _p]),
-    "pe_bn_act_pool_fwd": (_i, [_p, _p, _p, _f, _p, _l, _i, _i, _i, _l, _i, _p]),
-    "pe_bn_act_pool_bwd": (_i, [_p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _l, _i, _i, _i, _l, _i, _p, _z, _p]),
+    "pe_bn_act_pool_fwd": (_i, [_p, _p, _p, _f, _p, _l, _i, _i, _i, _l, _i, _p, _p]),
+    "pe_bn_act_pool_bwd": (_i, [_p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _l, _i, _i, _i, _l, _i, _p, _z, _p, _p]),
     "pe_maxpool_fwd": (_i, [_p, _p, _l, _i, _i, _i, _l, _i, _p]),
-    "pe_maxpool_bwd_add": (_i, [_p, _p, _p, _l, _i, _i, _i, _l, _i, _p]),
+    "pe_maxpool_bwd_add": (_i, [_p, _p, _p, _l, _i, _i, _i, _l, _i, _p, _p]),
     "pe_dropout_fwd": (_i, [_p, _l, _p, _l, _p, _p, _l, _i, _f, _u64, _u64, _p]),
     "pe_nhwc_to_seq": (_i, [_p, _l, _i, _p, _l, _i, _p]),
     "pe_seq_to_nhwc": (_i, [_p, _p, _l, _i, _l, _i, _i, _p]),
@@ -93,12 +93,12 @@ PROTOTYPES = {
     "pe_lstm_persistent_sync_bytes": (_z, [_i, _i]),
     "pe_lstm_persistent_supported": (_i, [_i, _i, _i]),
     "pe_lstm_fwd_persistent": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _p, _p]),
-    "pe_lstm_bwd_persistent": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _pp, _p, _p]),
+    "pe_lstm_bwd_persistent": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _pp, _pp, _p, _p]),
     "pe_lstm_fwd_persistent_x3": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _p, _p]),
     "pe_lstm_bwd_persistent_dbias_rows": (_i, [_i, _i, _i, _i, _i, _l]),
-    "pe_lstm_bwd_persistent_x3": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _pp, _p, _p]),
+    "pe_lstm_bwd_persistent_x3": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _pp, _pp, _p, _p]),
     "pe_lstm_fwd_persistent_bf16": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _p, _p]),
-    "pe_lstm_bwd_persistent_bf16": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _pp, _p, _p]),
+    "pe_lstm_bwd_persistent_bf16": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _pp, _pp, _p, _p]),
     "pe_lstm_whh_grad_workspace_bytes": (_z, [_i, _i, _i]),
     "pe_lstm_whh_grad": (_i, [_p, _p, _l, _p, _i, _i, _i, _i, _p, _z, _p]),
     "pe_lstm_whh_grad_x3": (_i, [_p, _p, _l, _p, _i, _i, _i, _i, _p, _z, _p]),
@@ -137,7 +137,7 @@ PROTOTYPES = {
     "pe_conv3x3_fwd_wf_f16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "pe_conv3x3_wgrad_f16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
     "pe_lstm_fwd_persistent_f16": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _p, _p]),
-    "pe_lstm_bwd_persistent_f16": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _pp, _p, _p]),
+    "pe_lstm_bwd_persistent_f16": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _pp, _pp, _p, _p]),
     "pe_lstm_whh_grad_f16": (_i, [_p, _p, _l, _p, _i, _i, _i, _i, _p, _z, _p]),
     "pe_wfrag_pack_f16": (_i, [_p, _l, _i, _i, _p, _p]),
     "pe_nonfinite_flag": (_i, [_p, _l, _p, _p]),

@@ -105,16 +105,40 @@ __global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const flo
   shift[c] = beta[c] - rm[c] * sc;
 }
 
+// ---------------------------------------------------------------- "h2" scale source from the producing pass
+// A pass that writes a tensor a later fp32 product reads can leave the tensor's largest magnitude behind: every
+// thread keeps max |v| of what it stores (v_max_f32 with |.| source modifiers), the workgroup folds it and one
+// no-return atomicMax per workgroup merges the IEEE bit patterns (ordered like unsigned integers) into *amax, a
+// word the caller zeroed.  Exact and order-independent; the separate pe_absmax pass over the tensor disappears.
+__device__ __forceinline__ float amax4(float m, const float4& v) {
+  return fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+}
+
+__device__ __forceinline__ void amax_commit(float m, unsigned* __restrict__ amax) {
+  if (amax == nullptr) return;                                   // (uniform across the grid)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  __shared__ float amax_red[4];
+  if ((threadIdx.x & 63) == 0) amax_red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float w = fmaxf(fmaxf(amax_red[0], amax_red[1]), fmaxf(amax_red[2], amax_red[3]));
+    atomicMax(amax, __float_as_uint(w));
+  }
+}
+
 // ---------------------------------------------------------------- BN -> LReLU -> MaxPool(1,k) forward
 // x: [rows][Fin][C]; y: pixel (row, fo) at y[(row*Fout + fo)*ldy + coff + c]
 __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const float* __restrict__ x,
                                                               const float* __restrict__ scale,
                                                               const float* __restrict__ shift, float slope,
                                                               float* __restrict__ y, long n_out_pix, int Fin, int C,
-                                                              int pool, long ldy, int coff) {
+                                                              int pool, long ldy, int coff,
+                                                              unsigned* __restrict__ amax) {
   const int quads = C >> 2;
   const int Fout = Fin / pool;
   const long total = n_out_pix * quads;
+  float am = 0.f;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int q = (int)(i % quads);
     const long op = i / quads;
@@ -135,7 +159,9 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const float* __res
       else { m.x = fmaxf(m.x, a.x); m.y = fmaxf(m.y, a.y); m.z = fmaxf(m.z, a.z); m.w = fmaxf(m.w, a.w); }
     }
     *reinterpret_cast<float4*>(y + op * ldy + coff + q * 4) = m;
+    am = amax4(am, m);
   }
+  amax_commit(am, amax);
 }
 
 // dz for the input pixel (row, f) of a BN->LReLU->MaxPool block, recomputed from x and dy.
@@ -223,9 +249,11 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int n
 
 // dx = gamma*invstd * (dz - mean(dz) - xhat * mean(dz*xhat));  scale == gamma*invstd
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a, const float* __restrict__ c1,
-                                                           const float* __restrict__ c2, float* __restrict__ dx) {
+                                                           const float* __restrict__ c2, float* __restrict__ dx,
+                                                           unsigned* __restrict__ amax) {
   const int quads = a.C >> 2;
   const long total = a.n_in_pix * quads;
+  float am = 0.f;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int c = (int)(i % quads) * 4;
     const long p = i / quads;
@@ -242,7 +270,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a, co
     o.z = sc.z * (dz.z - k1.z - (v.z - mu.z) * is.z * k2.z);
     o.w = sc.w * (dz.w - k1.w - (v.w - mu.w) * is.w * k2.w);
     *reinterpret_cast<float4*>(dx + p * a.C + c) = o;
+    am = amax4(am, o);
   }
+  amax_commit(am, amax);
 }
 
 // Window form of the two backward passes for POOL in {1, 2, 4}: one thread owns a whole pool window of a
@@ -315,9 +345,11 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_win_kernel(const BnBwdArgs
 template <int POOL>
 __global__ __launch_bounds__(256) void bn_bwd_apply_win_kernel(const BnBwdArgs a, long n_items, int nwin,
                                                                const float* __restrict__ c1,
-                                                               const float* __restrict__ c2, float* __restrict__ dx) {
+                                                               const float* __restrict__ c2, float* __restrict__ dx,
+                                                               unsigned* __restrict__ amax) {
   const int quads = a.C >> 2;
   const long total = n_items * quads;
+  float am = 0.f;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const long item = i / quads;
     const int c = (int)(i - item * quads) * 4;
@@ -337,8 +369,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_win_kernel(const BnBwdArgs a
       o.z = sc.z * (w.dz[j].z - k1.z - (w.v[j].z - mu.z) * is.z * k2.z);
       o.w = sc.w * (w.dz[j].w - k1.w - (w.v[j].w - mu.w) * is.w * k2.w);
       *reinterpret_cast<float4*>(dx + (w.p0 + j) * a.C + c) = o;
+      am = amax4(am, o);
     }
   }
+  amax_commit(am, amax);
 }
 
 // ---------------------------------------------------------------- plain MaxPool(1,k) (detector taps)
@@ -375,10 +409,11 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
 __global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const float* __restrict__ x,
                                                               const float* __restrict__ dy, float* __restrict__ dx,
                                                               long n_out_pix, int Fin, int C, int pool, long lddy,
-                                                              int coff) {
+                                                              int coff, unsigned* __restrict__ amax) {
   // one thread per (window, channel quad): float4 loads, four window rows in flight, first maximum wins
   const int Fout = Fin / pool, quads = C >> 2;
   const long total = n_out_pix * quads;
+  float am = 0.f;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const long op = i / quads;
     const int c = (int)(i - op * quads) * 4;
@@ -409,11 +444,15 @@ __global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const float* __res
     }
     const float4 g = *reinterpret_cast<const float4*>(dy + op * lddy + coff + c);
     float* dp = dx + (row * Fin + (long)fo * pool) * C + c;
-    dp[(long)a0 * C] += g.x;
-    dp[(long)a1 * C + 1] += g.y;
-    dp[(long)a2 * C + 2] += g.z;
-    dp[(long)a3 * C + 3] += g.w;
+    const float4 nv = make_float4(dp[(long)a0 * C] + g.x, dp[(long)a1 * C + 1] + g.y, dp[(long)a2 * C + 2] + g.z,
+                                  dp[(long)a3 * C + 3] + g.w);
+    dp[(long)a0 * C] = nv.x;
+    dp[(long)a1 * C + 1] = nv.y;
+    dp[(long)a2 * C + 2] = nv.z;
+    dp[(long)a3 * C + 3] = nv.w;
+    am = amax4(am, nv);          // merged into dx's word: an upper bound of max |dx| (elements that shrank keep their old share)
   }
+  amax_commit(am, amax);
 }
 
 // ---------------------------------------------------------------- dropout (Philox4x32-10)
@@ -599,12 +638,13 @@ extern "C" int pe_bn_eval_affine(const float* gamma, const float* beta, const fl
 }
 
 extern "C" int pe_bn_act_pool_fwd(const float* x, const float* scale, const float* shift, float slope, float* y,
-                                  long rows, int Fin, int C, int pool, long ldy, int coff, void* stream) {
+                                  long rows, int Fin, int C, int pool, long ldy, int coff, unsigned* amax_out,
+                                  void* stream) {
   if (!x || !scale || !shift || !y || rows <= 0 || Fin <= 0 || pool <= 0) return PE_E_ARG;
   if (!bn_channels_ok(C) || (ldy & 3) || (coff & 3)) return PE_E_UNSUPPORTED;
   const long n_out = rows * (Fin / pool);
   hipLaunchKernelGGL(bn_act_pool_fwd_kernel, dim3(ew_grid(n_out * (C / 4))), dim3(256), 0, pe_stream(stream), x, scale,
-                     shift, slope, y, n_out, Fin, C, pool, ldy, coff);
+                     shift, slope, y, n_out, Fin, C, pool, ldy, coff, amax_out);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }
@@ -612,7 +652,7 @@ extern "C" int pe_bn_act_pool_fwd(const float* x, const float* scale, const floa
 extern "C" int pe_bn_act_pool_bwd(const float* x, const float* dy, const float* scale, const float* shift,
                                   const float* mean, const float* invstd, float slope, float* dx, float* dgamma,
                                   float* dbeta, long rows, int Fin, int C, int pool, long lddy, int coff,
-                                  void* workspace, size_t workspace_bytes, void* stream) {
+                                  void* workspace, size_t workspace_bytes, unsigned* amax_out, void* stream) {
   if (!x || !dy || !scale || !shift || !mean || !invstd || !dx || !dgamma || !dbeta || rows <= 0) return PE_E_ARG;
   if (!bn_channels_ok(C) || (lddy & 3) || (coff & 3) || pool <= 0) return PE_E_UNSUPPORTED;
   const size_t need = pe_bn_workspace_bytes(C) + 2 * (size_t)C * sizeof(float);
@@ -640,13 +680,16 @@ extern "C" int pe_bn_act_pool_bwd(const float* x, const float* dy, const float* 
   PE_LAUNCH_CHECK();
   const int agrid = ew_grid((win ? n_items : a.n_in_pix) * (C / 4));
   if (pool == 1)
-    hipLaunchKernelGGL(bn_bwd_apply_win_kernel<1>, dim3(agrid), dim3(256), 0, st, a, n_items, nwin, c1, c2, dx);
+    hipLaunchKernelGGL(bn_bwd_apply_win_kernel<1>, dim3(agrid), dim3(256), 0, st, a, n_items, nwin, c1, c2, dx,
+                       amax_out);
   else if (pool == 2)
-    hipLaunchKernelGGL(bn_bwd_apply_win_kernel<2>, dim3(agrid), dim3(256), 0, st, a, n_items, nwin, c1, c2, dx);
+    hipLaunchKernelGGL(bn_bwd_apply_win_kernel<2>, dim3(agrid), dim3(256), 0, st, a, n_items, nwin, c1, c2, dx,
+                       amax_out);
   else if (pool == 4)
-    hipLaunchKernelGGL(bn_bwd_apply_win_kernel<4>, dim3(agrid), dim3(256), 0, st, a, n_items, nwin, c1, c2, dx);
+    hipLaunchKernelGGL(bn_bwd_apply_win_kernel<4>, dim3(agrid), dim3(256), 0, st, a, n_items, nwin, c1, c2, dx,
+                       amax_out);
   else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(agrid), dim3(256), 0, st, a, c1, c2, dx);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(agrid), dim3(256), 0, st, a, c1, c2, dx, amax_out);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }
@@ -663,12 +706,12 @@ extern "C" int pe_maxpool_fwd(const float* x, float* y, long rows, int Fin, int 
 }
 
 extern "C" int pe_maxpool_bwd_add(const float* x, const float* dy, float* dx, long rows, int Fin, int C, int pool,
-                                  long lddy, int coff, void* stream) {
+                                  long lddy, int coff, unsigned* amax_out, void* stream) {
   if (!x || !dy || !dx || rows <= 0 || Fin <= 0 || pool <= 0 || C <= 0) return PE_E_ARG;
   if ((C & 3) || (lddy & 3) || (coff & 3)) return PE_E_UNSUPPORTED;
   const long n_out = rows * (Fin / pool);
   hipLaunchKernelGGL(maxpool_bwd_add_kernel, dim3(ew_grid(n_out * (C / 4))), dim3(256), 0, pe_stream(stream), x, dy,
-                     dx, n_out, Fin, C, pool, lddy, coff);
+                     dx, n_out, Fin, C, pool, lddy, coff, amax_out);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }

@@ -57,6 +57,7 @@ struct PBwdCells {
   const float* c[kMaxCells];
   const float* dy[kMaxCells];
   float* dbias[kMaxCells];               // optional [batch tiles][4H] column sums of the gate gradients (k-split kernel)
+  unsigned* amax[kMaxCells];             // optional zeroed words: largest gate-gradient magnitude per cell (k-split kernel)
   int reverse[kMaxCells];
 };
 
@@ -1285,6 +1286,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_ks_kernel(const PB
   // bias gradient = column sums of the gate gradients: every thread keeps the running sums of its 4 gates x 4
   // columns over all steps and both halves; folded over the 32 rows of a half at the end of the kernel
   float4 bsum[4];
+  float gmax = 0.f;                 // largest gate-gradient magnitude this thread produced: the "h2" scale source of
+                                    // the dX / dW_ih / dW_hh products that read the gradient tensor
 #pragma unroll
   for (int g = 0; g < 4; ++g) bsum[g] = make_float4(0.f, 0.f, 0.f, 0.f);
   dcar[0] = dcar[1] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1376,6 +1379,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_ks_kernel(const PB
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       bsum[g].x += og4[g].x; bsum[g].y += og4[g].y; bsum[g].z += og4[g].z; bsum[g].w += og4[g].w;
+      gmax = fmaxf(gmax, fmaxf(fmaxf(fabsf(og4[g].x), fabsf(og4[g].y)), fmaxf(fabsf(og4[g].z), fabsf(og4[g].w))));
     }
     // local k = g * 32 + 4 pq + e  ->  block kb = 2 g + (pq >> 2), lane half (pq >> 1) & 1, position (pq & 1) * 4 + e;
     // split here, once, instead of in each of the four product waves
@@ -1563,6 +1567,11 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_ks_kernel(const PB
       const int g = (tid >> 2) & 3;
       cells.dbias[cell][(long)bt * K + g * H + j0 + 4 * (tid >> 4) + (tid & 3)] = sum;
     }
+  }
+  if (cells.amax[cell] != nullptr) {                 // one no-return atomicMax per wave on the cell's word (bit patterns
+#pragma unroll                                         // of non-negative floats order like unsigned integers)
+    for (int off = 32; off > 0; off >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, off, 64));
+    if (lane == 0) atomicMax(cells.amax[cell], __float_as_uint(gmax));
   }
   if constexpr (STAMP) {
     if (tid == 0)
@@ -1772,7 +1781,8 @@ static bool bwd_ks_eligible(int terms, int ncells, int B, int T, int H, long ldd
 
 static int lstm_bwd_persistent_impl(int terms, int ncells, const float* const* whh_t, float* const* gates,
                                     const float* const* cbuf, const float* const* dy, const int* reverse, long lddy,
-                                    int B, int T, int H, float* const* dbias_rows, unsigned* sync, void* stream) {
+                                    int B, int T, int H, float* const* dbias_rows, unsigned* const* dgates_amax,
+                                    unsigned* sync, void* stream) {
   if (!whh_t || !gates || !cbuf || !dy || !reverse || !sync || T <= 0) return PE_E_ARG;
   if (!pe_lstm_persistent_supported(ncells, B, H) || (lddy & 3)) return PE_E_UNSUPPORTED;
   if ((size_t)B * T * 4 * H * sizeof(float) >= (1ull << 32)) return PE_E_UNSUPPORTED;
@@ -1782,6 +1792,7 @@ static int lstm_bwd_persistent_impl(int terms, int ncells, const float* const* w
     cells.whh_t[i] = whh_t[i]; cells.gates[i] = gates[i]; cells.c[i] = cbuf[i]; cells.dy[i] = dy[i];
     cells.reverse[i] = reverse[i];
     cells.dbias[i] = dbias_rows ? dbias_rows[i] : nullptr;
+    cells.amax[i] = dgates_amax ? dgates_amax[i] : nullptr;
   }
   hipStream_t st = pe_stream(stream);
   PE_CHECK_HIP(hipMemsetAsync(sync + kCtrStride, 0, (size_t)(sync_words(ncells, B) - kCtrStride) * 4, st));
@@ -1810,9 +1821,10 @@ static int lstm_bwd_persistent_impl(int terms, int ncells, const float* const* w
 #ifndef PE_F16_BUILD
 extern "C" int pe_lstm_bwd_persistent(int ncells, const float* const* whh_t, float* const* gates,
                                       const float* const* cbuf, const float* const* dy, const int* reverse,
-                                      long lddy, int B, int T, int H, float* const* dbias_rows, unsigned* sync,
-                                      void* stream) {
-  return lstm_bwd_persistent_impl(0, ncells, whh_t, gates, cbuf, dy, reverse, lddy, B, T, H, dbias_rows, sync, stream);
+                                      long lddy, int B, int T, int H, float* const* dbias_rows,
+                                      unsigned* const* dgates_amax, unsigned* sync, void* stream) {
+  return lstm_bwd_persistent_impl(0, ncells, whh_t, gates, cbuf, dy, reverse, lddy, B, T, H, dbias_rows, dgates_amax, sync,
+                                  stream);
 }
 
 // Rows ([ceil(B / 64)][4H] per cell) that pe_lstm_bwd_persistent* (terms: 0 native, 3 split, 1 bf16 / fp16 operands)
@@ -1824,9 +1836,10 @@ extern "C" int pe_lstm_bwd_persistent_dbias_rows(int terms, int ncells, int B, i
 
 extern "C" int pe_lstm_bwd_persistent_x3(int ncells, const float* const* whh_t, float* const* gates,
                                          const float* const* cbuf, const float* const* dy, const int* reverse,
-                                         long lddy, int B, int T, int H, float* const* dbias_rows, unsigned* sync,
-                                         void* stream) {
-  return lstm_bwd_persistent_impl(3, ncells, whh_t, gates, cbuf, dy, reverse, lddy, B, T, H, dbias_rows, sync, stream);
+                                         long lddy, int B, int T, int H, float* const* dbias_rows,
+                                         unsigned* const* dgates_amax, unsigned* sync, void* stream) {
+  return lstm_bwd_persistent_impl(3, ncells, whh_t, gates, cbuf, dy, reverse, lddy, B, T, H, dbias_rows, dgates_amax, sync,
+                                  stream);
 }
 #endif
 
@@ -1838,7 +1851,8 @@ extern "C" int PE_HALF(pe_lstm_fwd_persistent)(int ncells, const float* const* w
 
 extern "C" int PE_HALF(pe_lstm_bwd_persistent)(int ncells, const float* const* whh_t, float* const* gates,
                                            const float* const* cbuf, const float* const* dy, const int* reverse,
-                                           long lddy, int B, int T, int H, float* const* dbias_rows, unsigned* sync,
-                                           void* stream) {
-  return lstm_bwd_persistent_impl(1, ncells, whh_t, gates, cbuf, dy, reverse, lddy, B, T, H, dbias_rows, sync, stream);
+                                           long lddy, int B, int T, int H, float* const* dbias_rows,
+                                           unsigned* const* dgates_amax, unsigned* sync, void* stream) {
+  return lstm_bwd_persistent_impl(1, ncells, whh_t, gates, cbuf, dy, reverse, lddy, B, T, H, dbias_rows, dgates_amax, sync,
+                                  stream);
 }

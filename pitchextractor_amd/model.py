@@ -207,42 +207,44 @@ def _res_forward(blk: _ResBlock, x, pool, train, need_grad, slope, x_stats=None)
     s = _Ctx()
     s.x = x
     s.bn_pre = _bn(blk.pre_conv[0], x, train, x_stats)
-    s.p = ops.bn_act_pool_fwd(x, s.bn_pre, pool=pool, slope=slope)
-    s.am_p = ops.amax_for(s.p)          # "h2" products: one absmax word per operand tensor, shared by its readers
+    s.am_p = ops.amax_word()            # "h2" products: one absmax word per operand tensor, left by its producer
+    s.p = ops.bn_act_pool_fwd(x, s.bn_pre, pool=pool, slope=slope, amax_out=s.am_p)
     out = ops.gemm_nt(_flat2(s.p), blk.conv1by1.weight.view(blk.cout, blk.cin), amax_a=s.am_p)
     out = out.view(*s.p.shape[:3], blk.cout)
     wf0, s.wd0 = ops.conv3x3_repack(blk.conv[0].weight, True, need_grad)
     s.c, c_stats = ops.conv3x3_fwd(s.p, wf0, bn_stats=train, amax=s.am_p)
     s.bn_mid = _bn(blk.conv[1], s.c, train, c_stats)
-    s.a = ops.bn_act_pool_fwd(s.c, s.bn_mid, pool=1, slope=slope)
-    s.am_a = ops.amax_for(s.a)
+    s.am_a = ops.amax_word()
+    s.a = ops.bn_act_pool_fwd(s.c, s.bn_mid, pool=1, slope=slope, amax_out=s.am_a)
     wf3, s.wd3 = ops.conv3x3_repack(blk.conv[3].weight, True, need_grad)
     _, out_stats = ops.conv3x3_fwd(s.a, wf3, out=out, accumulate=True, bn_stats=train,   # conv(x) + conv1by1(x), model.py:171-172
                                    amax=s.am_a)
     return out, s, out_stats
 
 
-def _res_backward(blk: _ResBlock, s, d_out, pool, slope, grads, side):
-    """d_out: grad of the block output.  Returns grad wrt the block input (dense, overwritten).  The three weight
-    gradients go through `side` (_SideWork)."""
-    am_do = ops.amax_for(d_out)
+def _res_backward(blk: _ResBlock, s, d_out, pool, slope, grads, side, am_do=None):
+    """d_out: grad of the block output (am_do: its absmax word if the producer left one).  Returns (grad wrt the block
+    input (dense, overwritten), its absmax word).  The three weight gradients go through `side` (_SideWork)."""
+    if am_do is None:
+        am_do = ops.amax_for(d_out)
     side.run(lambda: (ops.conv3x3_wgrad(s.a, d_out, grads[blk.conv[3].weight], amax_x=s.am_a, amax_dy=am_do),
                       ops.gemm_tn(_flat2(d_out), _flat2(s.p), out=grads[blk.conv1by1.weight].view(blk.cout, blk.cin),
                                   amax_a=am_do, amax_b=s.am_p)),
              d_out, am_do, on=OVERLAP_CONV_WGRAD)
     with ops.timer_tag("dgrad"):
         d_a = ops.conv3x3_fwd(d_out, s.wd3, amax=am_do)
+    am_dc = ops.amax_word()
     d_c = ops.bn_act_pool_bwd(s.c, d_a, s.bn_mid, grads[blk.conv[1].weight], grads[blk.conv[1].bias], pool=1,
-                              slope=slope, dx=d_a)
-    am_dc = ops.amax_for(d_c)
+                              slope=slope, dx=d_a, amax_out=am_dc)
     side.run(lambda: ops.conv3x3_wgrad(s.p, d_c, grads[blk.conv[0].weight], amax_x=s.am_p, amax_dy=am_dc), d_c, am_dc,
              on=OVERLAP_CONV_WGRAD)
     with ops.timer_tag("dgrad"):
         d_p = ops.conv3x3_fwd(d_c, s.wd0, amax=am_dc)
     w1t = ops.transpose2d(blk.conv1by1.weight.view(blk.cout, blk.cin))
     ops.gemm_nt(_flat2(d_out), w1t, out=_flat2(d_p), accumulate=True, amax_a=am_do)
+    am_dx = ops.amax_word()
     return ops.bn_act_pool_bwd(s.x, d_p, s.bn_pre, grads[blk.pre_conv[0].weight], grads[blk.pre_conv[0].bias],
-                               pool=pool, slope=slope)
+                               pool=pool, slope=slope, amax_out=am_dx), am_dx
 
 
 class _DropoutCfg:
@@ -405,9 +407,12 @@ def _lstm_backward(models, saved, dys, grads, side):
         # bias gradients come out of the recurrence kernel as per-batch-tile rows where it supports that
         nrows = ops.lstm_bwd_dbias_rows(len(whh_t), B, T, H, dsl[0].stride(1), dev)
         brows = [torch.empty((nrows, 4 * H), dtype=torch.float32, device=dev) for _ in whh_t] if nrows else None
+        # "h2": the scale source of each cell's gate gradients comes out of the recurrence kernel where it can emit it
+        am_dg = [ops.amax_word() for _ in whh_t] if (nrows and ops.h2_active()) else None
         have_db = ops.lstm_bwd(whh_t, lay.gates, lay.cbuf, dsl, dcs, rev, B, T, H,     # gates now hold d(pre-activations)
-                               dbias_rows=brows)
-        am_dg = [ops.amax_for(gt) for gt in lay.gates]                  # "h2": scale source of each cell's gate gradients
+                               dbias_rows=brows, amax_out=am_dg)
+        if am_dg is None:                                               # (else one pass per tensor; None outside "h2")
+            am_dg = [ops.amax_for(gt) for gt in lay.gates]
         # the data gradients first (the next layer's recurrence waits for them) ...
         dxs = []
         for mi, sm in enumerate(models):
@@ -774,8 +779,8 @@ class JDCNet(nn.Module):
         cbk = self.conv_block
         s.y0, y0_stats = ops.conv3x3_c1_fwd(x_btf, cbk[0].weight, bn_stats=train)
         s.bn0 = _bn(cbk[1], s.y0, train, y0_stats)
-        s.a0 = ops.bn_act_pool_fwd(s.y0, s.bn0, pool=1, slope=slope)
-        s.am_a0 = ops.amax_for(s.a0)
+        s.am_a0 = ops.amax_word()
+        s.a0 = ops.bn_act_pool_fwd(s.y0, s.bn0, pool=1, slope=slope, amax_out=s.am_a0)
         wf, s.wd_cb = ops.conv3x3_repack(cbk[3].weight, True, need_grad)
         s.cb, st_cb = ops.conv3x3_fwd(s.a0, wf, bn_stats=train, amax=s.am_a0)        # convblock_out
         s.rb1, s.r1, st1 = _res_forward(self.res_block1, s.cb, 2, train, need_grad, slope, st_cb)
@@ -874,7 +879,8 @@ class JDCNet(nn.Module):
         _dropout_bwd(d_concat.view(-1, 640)[:, 384:640], p_blk if s.mask_pool is not None else 0.0, s.mask_pool,
                      out2d=_flat2(d_pool))
         bnp = self.pool_block[0]
-        d_rb3 = ops.bn_act_pool_bwd(s.rb3, d_pool, s.bnp, g[bnp.weight], g[bnp.bias], pool=4, slope=slope)
+        am3 = ops.amax_word()
+        d_rb3 = ops.bn_act_pool_bwd(s.rb3, d_pool, s.bnp, g[bnp.weight], g[bnp.bias], pool=4, slope=slope, amax_out=am3)
 
         cuts = self._dp_cuts if self._dp is not None else None
 
@@ -882,18 +888,19 @@ class JDCNet(nn.Module):
             if cuts is not None:
                 self._dp.reduce_range(cuts[k], cuts[k + 1], after=side.pending_stream())
 
-        d_rb2 = _res_backward(self.res_block3, s.r3, d_rb3, 2, slope, g, side)
+        # each block-input gradient leaves its absmax word behind; the detector tap's max-pool gradient, added in place
+        # afterwards, merges the values it rewrote into the same word
+        d_rb2, am2 = _res_backward(self.res_block3, s.r3, d_rb3, 2, slope, g, side, am3)
         block_done(3)                       # res_block3 + pool_block + detector_conv
-        ops.maxpool_bwd_add(s.rb2, d_concat, d_rb2, 10, coff=192)
-        d_rb1 = _res_backward(self.res_block2, s.r2, d_rb2, 2, slope, g, side)
+        ops.maxpool_bwd_add(s.rb2, d_concat, d_rb2, 10, coff=192, amax_out=am2)
+        d_rb1, am1 = _res_backward(self.res_block2, s.r2, d_rb2, 2, slope, g, side, am2)
         block_done(2)
-        ops.maxpool_bwd_add(s.rb1, d_concat, d_rb1, 20, coff=64)
-        d_cb = _res_backward(self.res_block1, s.r1, d_rb1, 2, slope, g, side)
+        ops.maxpool_bwd_add(s.rb1, d_concat, d_rb1, 20, coff=64, amax_out=am1)
+        d_cb, am_dcb = _res_backward(self.res_block1, s.r1, d_rb1, 2, slope, g, side, am1)
         block_done(1)
-        ops.maxpool_bwd_add(s.cb, d_concat, d_cb, 40, coff=0)
+        ops.maxpool_bwd_add(s.cb, d_concat, d_cb, 40, coff=0, amax_out=am_dcb)
 
         cbk = self.conv_block
-        am_dcb = ops.amax_for(d_cb)
         side.run(lambda: ops.conv3x3_wgrad(s.a0, d_cb, g[cbk[3].weight], amax_x=s.am_a0, amax_dy=am_dcb), d_cb, am_dcb,
                  on=OVERLAP_CONV_WGRAD)
         with ops.timer_tag("dgrad"):

@@ -154,6 +154,23 @@ def amax_for(t):
     return absmax(t) if h2_active() else None
 
 
+_AMAX_POOL: dict = {}
+
+
+def amax_word():
+    """A zeroed int32 device word for a producing pass to max-merge its output's absmax into ("h2" mode; None
+    otherwise).  Words are cut from a 256-word block zeroed by one fill; a block lives as long as any of its words."""
+    if not h2_active():
+        return None
+    key = (torch.cuda.current_device(), _lib.stream_ptr())
+    blk = _AMAX_POOL.get(key)
+    if blk is None or blk[1] >= blk[0].numel():
+        blk = [torch.zeros(256, dtype=torch.int32, device="cuda"), 0]
+        _AMAX_POOL[key] = blk
+    blk[1] += 1
+    return blk[0][blk[1] - 1:blk[1]]
+
+
 _BOUND_AMAX: dict = {}
 
 
@@ -518,7 +535,8 @@ def _slice_target(out, B, T, Fo, Cc, coff):
     return ld
 
 
-def bn_act_pool_fwd(x, st: BnState, pool=1, slope=0.01, out=None, coff=0):
+def bn_act_pool_fwd(x, st: BnState, pool=1, slope=0.01, out=None, coff=0, amax_out=None):
+    """``amax_out``: a zeroed word from ``amax_word()``; the pass leaves the absmax of its output there."""
     x = _dense(x, "x")
     B, T, F, Cc = x.shape
     Fo = F // pool
@@ -526,11 +544,11 @@ def bn_act_pool_fwd(x, st: BnState, pool=1, slope=0.01, out=None, coff=0):
         out = torch.empty((B, T, Fo, Cc), dtype=torch.float32, device=x.device)
     ld = _slice_target(out, B, T, Fo, Cc, coff)
     _call("pe_bn_act_pool_fwd", x.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), slope, out.data_ptr(),
-          B * T, F, Cc, pool, ld, coff, _s())
+          B * T, F, Cc, pool, ld, coff, _lib.ptr(amax_out), _s())
     return out
 
 
-def bn_act_pool_bwd(x, dy, st: BnState, dgamma, dbeta, pool=1, slope=0.01, coff=0, dx=None):
+def bn_act_pool_bwd(x, dy, st: BnState, dgamma, dbeta, pool=1, slope=0.01, coff=0, dx=None, amax_out=None):
     x = _dense(x, "x")
     B, T, F, Cc = x.shape
     ld = _slice_target(dy, B, T, F // pool, Cc, coff)
@@ -542,7 +560,7 @@ def bn_act_pool_bwd(x, dy, st: BnState, dgamma, dbeta, pool=1, slope=0.01, coff=
     ws = workspace(lib.pe_bn_workspace_bytes(Cc) + 8 * Cc, x.device)
     _call("pe_bn_act_pool_bwd", x.data_ptr(), dy.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(),
           st.mean.data_ptr(), st.invstd.data_ptr(), slope, dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
-          B * T, F, Cc, pool, ld, coff, ws.data_ptr(), ws.numel(), _s())
+          B * T, F, Cc, pool, ld, coff, ws.data_ptr(), ws.numel(), _lib.ptr(amax_out), _s())
     return dx
 
 
@@ -557,12 +575,13 @@ def maxpool_fwd(x, pool, out=None, coff=0):
     return out
 
 
-def maxpool_bwd_add(x, dy, dx, pool, coff=0):
+def maxpool_bwd_add(x, dy, dx, pool, coff=0, amax_out=None):
     x = _dense(x, "x")
     B, T, F, Cc = x.shape
     ld = _slice_target(dy, B, T, F // pool, Cc, coff)
     _chk(_dense(dx, "dx").shape == x.shape, "dx shape")
-    _call("pe_maxpool_bwd_add", x.data_ptr(), dy.data_ptr(), dx.data_ptr(), B * T, F, Cc, pool, ld, coff, _s())
+    _call("pe_maxpool_bwd_add", x.data_ptr(), dy.data_ptr(), dx.data_ptr(), B * T, F, Cc, pool, ld, coff,
+          _lib.ptr(amax_out), _s())
     return dx
 
 
@@ -696,10 +715,12 @@ def lstm_fwd(whh, gates, y_slices, cbuf, reverse, B, T, H):
           _int_array(reverse), ldy, B, T, H, _s(), work=2.0 * n * B * (T - 1) * 4 * H * H)
 
 
-def lstm_bwd(whh_t, gates, cbuf, dy_slices, dcarry, reverse, B, T, H, dbias_rows=None):
+def lstm_bwd(whh_t, gates, cbuf, dy_slices, dcarry, reverse, B, T, H, dbias_rows=None, amax_out=None):
     """Backward recurrences of len(whh_t) cells; gates become d(pre-activation gates) in place.  dbias_rows: optional
     list of [lstm_bwd_dbias_rows(...)][4H] buffers, one per cell, that receive the per-batch-tile column sums of the
-    gate gradients (only pass it when that query is non-zero); returns True if they were written."""
+    gate gradients (only pass it when that query is non-zero); returns True if they were written.  amax_out: optional
+    list of zeroed words (``amax_word()``), one per cell, filled with the gate gradients' absmax under the same
+    condition (else untouched: take ``absmax`` of the tensors)."""
     n = len(whh_t)
     _chk(1 <= n <= 4 and len(gates) == len(dy_slices) == len(cbuf) == len(reverse) == len(dcarry) == n,
          "lstm_bwd: cell lists")
@@ -722,6 +743,7 @@ def lstm_bwd(whh_t, gates, cbuf, dy_slices, dcarry, reverse, B, T, H, dbias_rows
                  "lstm_bwd: dbias_rows shape")
         _call("pe_lstm_bwd_persistent" + _lstm_suffix("bwd"), n, _ptr_array(whh_t), _ptr_array(gates), _ptr_array(cbuf),
               _ptr_array(dy_slices), _int_array(reverse), ld, B, T, H, _ptr_array(dbias_rows) if rows else None,
+              _ptr_array(amax_out) if (rows and amax_out is not None) else None,
               sync.data_ptr(), _s(), work=2.0 * n * B * (T - 1) * 4 * H * H)
         return bool(rows)
     _call("pe_lstm_bwd", n, _ptr_array(whh_t), _ptr_array(gates), _ptr_array(cbuf), _ptr_array(dy_slices),

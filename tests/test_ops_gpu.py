@@ -407,6 +407,30 @@ def test_maxpool_taps(hip_device, C, Fq, pool, coff):
     close(nchw(dx - base), x.grad, 1e-6)
 
 
+@pytest.mark.parametrize("pool", [1, 2, 4])
+def test_bn_pool_passes_leave_the_absmax_of_their_output(hip_device, pool):
+    """amax_out of bn_act_pool_fwd / bn_act_pool_bwd: exactly the IEEE bits of max |output|; maxpool_bwd_add merges
+    an upper bound of the updated tensor's maximum into the same word."""
+    B, T, Fq, C = 3, 17, 20, 64
+    x = (rnd(B, T, Fq, C, seed=1) * 3).to(hip_device)
+    gamma, beta = rnd(C, seed=2).to(hip_device) + 1.5, rnd(C, seed=3).to(hip_device)
+    rm, rv = torch.zeros(C, device=hip_device), torch.ones(C, device=hip_device)
+    st = ops.bn_train_stats(x, gamma, beta, rm, rv)
+    bits = lambda t: t.abs().max().view(torch.int32).item()                 # noqa: E731
+    w = torch.zeros(1, dtype=torch.int32, device=hip_device)
+    y = ops.bn_act_pool_fwd(x, st, pool=pool, amax_out=w)
+    assert w.item() == bits(y)
+    dy = rnd(B, T, Fq // pool, C, seed=4).to(hip_device)
+    w2 = torch.zeros(1, dtype=torch.int32, device=hip_device)
+    dg, db = torch.empty(C, device=hip_device), torch.empty(C, device=hip_device)
+    dx = ops.bn_act_pool_bwd(x, dy, st, dg, db, pool=pool, amax_out=w2)
+    assert w2.item() == bits(dx)
+    if Fq % 10 == 0:
+        wide = (rnd(B, T, 2, 640, seed=5) * 50).to(hip_device)
+        ops.maxpool_bwd_add(x, wide, dx, 10, coff=64, amax_out=w2)
+        assert w2.item() >= bits(dx) and w2.view(torch.float32).item() <= 2.0 * dx.abs().max().item()
+
+
 def test_dropout_mask_export_replay_and_rate(hip_device):
     x = rnd(4096, 512, seed=1).to(hip_device)
     y, mask = ops.dropout(x, 0.5, seed=123, offset=0)
@@ -475,7 +499,11 @@ def test_lstm_layer_bidirectional(hip_device, B, T, In, H, persistent, monkeypat
     nrows = ops.lstm_bwd_dbias_rows(2, B, T, H, dsl[0].stride(1), dev)
     assert (nrows > 0) == (persistent and H == 384 and ops.FP32_MATMUL in ("x3", "h2"))
     brows = [torch.full((nrows, 4 * H), float("nan"), device=dev) for _ in range(2)] if nrows else None
-    assert ops.lstm_bwd(whh_t, gates, cbuf, dsl, dcar, [0, 1], B, T, H, dbias_rows=brows) == (nrows > 0)
+    amx = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(2)] if nrows else None
+    assert ops.lstm_bwd(whh_t, gates, cbuf, dsl, dcar, [0, 1], B, T, H, dbias_rows=brows, amax_out=amx) == (nrows > 0)
+    if nrows:        # ... and the largest gate-gradient magnitude per cell (scale source of the "h2" products), exactly
+        for d in range(2):
+            assert amx[d].item() == gates[d].abs().max().view(torch.int32).item()
     dx = torch.empty(B, T, In, device=dev)
     for d, sfx in enumerate(("", "_reverse")):
         dg = gates[d].view(-1, 4 * H)
