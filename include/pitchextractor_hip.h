@@ -103,6 +103,8 @@ int pe_gemm_nt_x3(const float* A, long lda, const float* B, long ldb, float* C, 
 int pe_gemm_nt_h2(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
                   int K, const float* bias0, const float* bias1, int accumulate, const unsigned* amax_a,
                   const unsigned* amax_b, void* stream);
+/* Experiment switches for tools/ (kernel variants under A/B measurement); the product path never calls it. */
+int pe_tune_set(int key, int value);
 /* out[0] = IEEE bits of max |x| over a [rows][cols] matrix with leading dimension ld (cols, ld % 4 == 0, x 16-byte
  * aligned); zeroes out[0] first.  Exact and order-independent (integer max of the magnitudes' bit patterns). */
 int pe_absmax(const float* x, long rows, int cols, long ld, unsigned* out, void* stream);
@@ -363,9 +365,11 @@ int pe_f0_bins_ce_loss(const float* logits, long ldl, int C, const float* f0, co
                        const float* sil, float lambda_f0, long R, float grad_scale, float* out4,
                        float* d_logits, long ldd, float* d_sil_pred, float* workspace, size_t workspace_bytes,
                        void* stream);
+/* skip_if_nonzero (nullable): a device float; when it is non-zero at execution time the launch updates nothing (the
+ * trainer's fault word, agreed across ranks inside the gradient all-reduce: no host round trip before the update). */
 int pe_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr,
                   float beta1, float beta2, float eps, float weight_decay, double bias_correction1,
-                  double bias_correction2, float grad_scale, void* stream);
+                  double bias_correction2, float grad_scale, const float* skip_if_nonzero, void* stream);
 /* GradScaler support (reference trainer.py:241-244): *flag = 1 if any of x[0..n) is inf or nan, else 0. */
 int pe_nonfinite_flag(const float* x, long n, int* flag, void* stream);
 

@@ -44,6 +44,7 @@ PROTOTYPES = {
     "pe_gemm_nt_x3": (_i, [_p, _l, _p, _l, _p, _l, _i, _i, _i, _p, _p, _i, _p]),
     "pe_gemm_nt_h2": (_i, [_p, _l, _p, _l, _p, _l, _i, _i, _i, _p, _p, _i, _p, _p, _p]),
     "pe_absmax": (_i, [_p, _l, _i, _l, _p, _p]),
+    "pe_tune_set": (_i, [_i, _i]),
     "pe_gemm_nt_wf_x3": (_i, [_p, _l, _p, _p, _l, _i, _i, _i, _p, _p, _i, _p]),
     "pe_gemm_nt_wf_bf16": (_i, [_p, _l, _p, _p, _l, _i, _i, _i, _p, _p, _i, _p]),
     "pe_gemm_nt_wf_ablate": (_i, [_i, _p, _l, _p, _p, _l, _i, _i, _i, _p]),
@@ -141,7 +142,7 @@ PROTOTYPES = {
     "pe_lstm_whh_grad_f16": (_i, [_p, _p, _l, _p, _i, _i, _i, _i, _p, _z, _p]),
     "pe_wfrag_pack_f16": (_i, [_p, _l, _i, _i, _p, _p]),
     "pe_nonfinite_flag": (_i, [_p, _l, _p, _p]),
-    "pe_adamw_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _d, _d, _f, _p]),
+    "pe_adamw_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _d, _d, _f, _p, _p]),
 }
 
 

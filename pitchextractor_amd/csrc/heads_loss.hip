@@ -255,7 +255,10 @@ __global__ __launch_bounds__(256) void nonfinite_kernel(const float* __restrict_
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, long n,
-                                                    const AdamArgs a) {
+                                                    const AdamArgs a, const float* __restrict__ skip) {
+  // device-side predicate: a step whose status word is non-zero (a persistent-LSTM hand-off timed out on some rank)
+  // leaves parameters and moments untouched; the host learns of it with the loss scalars and redoes the step
+  if (skip != nullptr && *skip != 0.0f) return;
   const long n4 = n >> 2;
   const float decay = 1.0f - a.lr * a.weight_decay;
   const float w1 = 1.0f - a.beta1, w2 = 1.0f - a.beta2;
@@ -363,7 +366,7 @@ extern "C" int pe_f0_bins_ce_loss(const float* logits, long ldl, int C, const fl
 
 extern "C" int pe_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr,
                              float beta1, float beta2, float eps, float weight_decay, double bias_correction1,
-                             double bias_correction2, float grad_scale, void* stream) {
+                             double bias_correction2, float grad_scale, const float* skip_if_nonzero, void* stream) {
   if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0) return PE_E_ARG;
   if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return PE_E_UNSUPPORTED;
   AdamArgs a;
@@ -375,7 +378,7 @@ extern "C" int pe_adamw_step(float* param, const float* grad, float* exp_avg, fl
   if (g > 8192) g = 8192;
   if (g < 1) g = 1;
   hipLaunchKernelGGL(adamw_kernel, dim3((int)g), dim3(256), 0, pe_stream(stream), param, grad, exp_avg, exp_avg_sq, n,
-                     a);
+                     a, skip_if_nonzero);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }

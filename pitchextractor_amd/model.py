@@ -695,7 +695,10 @@ class JDCNet(nn.Module):
         for p in params:
             offsets.append(total)
             total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
-        flat = torch.zeros(total, dtype=torch.float32, device=device)
+        # one spare aligned slot behind the last parameter: in the GRADIENT buffer it carries the step's status word
+        # (status_slot), so that it rides in the gradient all-reduce and reaches the fused AdamW on the device
+        self._status_off = total
+        flat = torch.zeros(total + _ALIGN, dtype=torch.float32, device=device)
         for p, off in zip(params, offsets):
             view = flat[off:off + p.numel()].view_as(p)
             view.copy_(p.data)
@@ -748,6 +751,19 @@ class JDCNet(nn.Module):
         if self._grad_flat is None or self._grad_flat.device != self._flat.device:
             self._grad_flat = torch.zeros_like(self._flat, requires_grad=False)
         return self._grad_flat
+
+    def status_slot(self) -> torch.Tensor:
+        """1-element view of the flat gradient buffer behind the last parameter: 0 after a clean backward, non-zero
+        when a persistent-LSTM hand-off timed out in this step (summed over ranks by the gradient all-reduce).  The
+        fused AdamW skips its update on the device when it is set; the trainer reads it with the loss scalars."""
+        return self.flat_gradients()[self._status_off:self._status_off + 1]
+
+    def _write_status(self, dev):
+        slot, word = self.status_slot(), ops.persistent_lstm_error_word(dev)
+        if word is None:
+            slot.zero_()
+        else:
+            slot.copy_(word != 0)
 
     def _grad_views(self):
         gflat = self.flat_gradients()
@@ -858,6 +874,7 @@ class JDCNet(nn.Module):
             dseq_d = _tf_backward(models[1], s.tf_d, dyd.view(B, T, D), g, side)
             dseq_c = _tf_backward(models[0], s.tf_c, dyc.view(B, T, D), g, side)
 
+        self._write_status(dev)             # every recurrence of this step has been queued: its fault word is final
         if self._dp is not None:            # temporal heads + output heads are final once the side stream has
             # finished what is queued on it so far: the collectives are issued from that stream, the main stream does not wait
             self._dp.reduce_range(self._seq_offset(), self._grad_flat.numel(), after=side.pending_stream())

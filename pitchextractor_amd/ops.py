@@ -862,14 +862,17 @@ def nonfinite_flag(x, flag=None):
     return flag
 
 
-def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0,
+               skip_flag=None):
+    """``skip_flag``: optional 1-element float32 device tensor; non-zero at execution time = update nothing."""
     n = param.numel()
     for t, nme in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
         _chk(_dense(t, nme).numel() == n, f"{nme}: size")
     bc1 = 1.0 - float(beta1) ** int(step)
     bc2 = 1.0 - float(beta2) ** int(step)
     _call("pe_adamw_step", param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), n,
-          float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), bc1, bc2, float(grad_scale), _s())
+          float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), bc1, bc2, float(grad_scale),
+          _lib.ptr(skip_flag), _s())
 
 
 # ------------------------------------------------------------------ transformer pieces

@@ -31,6 +31,7 @@ class FusedAdamW(Optimizer):
         super().__init__(params, defaults)
         self.grad_scale = 1.0
         self.loss_scale_inv = 1.0            # Trainer's GradScaler: gradients are unscaled inside the kernel
+        self.skip_flag = None                # 1-element device float: non-zero when the kernel runs = no update
         self._flat_plans = {}
 
     # ---- flat-buffer detection -----------------------------------------------------------
@@ -108,7 +109,8 @@ class FusedAdamW(Optimizer):
                 st0 = self.state[params[0]]
                 step = int(st0["step"].item()) + 1
                 ops.adamw_step(plan["flat_p"], plan["flat_g"], plan["m"], plan["v"], group["lr"], beta1, beta2,
-                               group["eps"], group["weight_decay"], step, self.grad_scale * self.loss_scale_inv)
+                               group["eps"], group["weight_decay"], step, self.grad_scale * self.loss_scale_inv,
+                               skip_flag=self.skip_flag)
                 new_step = torch.tensor(float(step))
                 for p in params:
                     self.state[p]["step"] = new_step
@@ -125,9 +127,17 @@ class FusedAdamW(Optimizer):
                     raise RuntimeError("FusedAdamW needs contiguous parameters and gradients")
                 ops.adamw_step(pd.view(-1), p.grad.view(-1), st["exp_avg"].view(-1), st["exp_avg_sq"].view(-1),
                                group["lr"], beta1, beta2, group["eps"], group["weight_decay"], step,
-                               self.grad_scale * self.loss_scale_inv)
+                               self.grad_scale * self.loss_scale_inv, skip_flag=self.skip_flag)
                 st["step"] = torch.tensor(float(step))
         return loss
+
+    def undo_step_count(self):
+        """The last ``step`` was skipped on the device (``skip_flag`` was set): take its count back so the redone
+        step uses the same bias corrections."""
+        for group in self.param_groups:
+            steps = {id(self.state[p]["step"]): self.state[p]["step"] for p in group["params"] if "step" in self.state.get(p, {})}
+            for t in steps.values():
+                t -= 1.0
 
 
 def build_optimizer(parameters):

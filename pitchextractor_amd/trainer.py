@@ -237,31 +237,65 @@ class Trainer(object):
                                 "falling back to the per-time-step kernels for the rest of this run")
         return bad
 
+    def _apply_update(self):
+        """optimizer.step() (through the GradScaler in fp16 mode).  The fused AdamW reads the model's status slot on
+        the device and leaves everything untouched when it is set."""
+        self._stepped = True
+        if self.scaler is None:
+            self.optimizer.step()
+            return
+        # scaler.step(optimizer); scaler.update()  (trainer.py:242-244)
+        found = bool(ops.nonfinite_flag(self.model.flat_gradients()).item())
+        if self.data_parallel is not None and self.data_parallel.active:
+            found = self.data_parallel.any_rank(found)
+        self._stepped = not found
+        if not found:
+            self.optimizer.loss_scale_inv = 1.0 / self.scaler.scale      # unscale inside the fused AdamW
+            try:
+                self.optimizer.step()
+            finally:
+                self.optimizer.loss_scale_inv = 1.0
+        self.scaler.update(found)
+
     def run(self, batch):
         self._runs = getattr(self, "_runs", 0) + 1
         if self._runs == GC_FREEZE_AFTER_STEPS + 1:
             _settle_gc()
         self.optimizer.zero_grad(set_to_none=True)
         x, f0, sil = self._inputs(batch)
+        slot_fn = getattr(self.model, "status_slot", None)
+        if slot_fn is None or not hasattr(self.optimizer, "skip_flag"):
+            # generic model / optimizer: the fault word is checked on the host before the update
+            out3 = self._forward_backward(x, f0, sil)
+            if self._lstm_fault(x.device):
+                self.optimizer.zero_grad(set_to_none=True)
+                out3 = self._forward_backward(x, f0, sil)
+            self._apply_update()
+            self.scheduler.step()
+            loss, loss_f0, loss_sil = out3.tolist()
+            return {"loss": loss, "f0": loss_f0, "sil": loss_sil}
+        # JDCNet + FusedAdamW: ONE host synchronisation per step.  The persistent-LSTM fault word travels in the flat
+        # gradient buffer (summed over ranks by the gradient all-reduce itself), the AdamW kernel is predicated on it
+        # on the device, and the host reads it together with the three loss scalars after everything is queued.
         out3 = self._forward_backward(x, f0, sil)
-        if self._lstm_fault(x.device):                     # before the update: redo the step on the safe kernels
+        self.optimizer.skip_flag = slot_fn()
+        self._apply_update()
+        loss, loss_f0, loss_sil, fault = torch.cat([out3, self.optimizer.skip_flag]).tolist()
+        if fault != 0.0:                                   # nothing was updated: redo the step on the safe kernels
+            ops.clear_persistent_lstm_error(x.device)
+            ops.USE_PERSISTENT_LSTM = False
+            self.logger.warning("persistent LSTM kernel: a group barrier timed out (workgroups not co-resident?); "
+                                "falling back to the per-time-step kernels for the rest of this run")
+            if self._stepped:
+                self.optimizer.undo_step_count()
             self.optimizer.zero_grad(set_to_none=True)
             out3 = self._forward_backward(x, f0, sil)
-        if self.scaler is None:
-            self.optimizer.step()
-        else:                                              # scaler.step(optimizer); scaler.update()  (trainer.py:242-244)
-            found = bool(ops.nonfinite_flag(self.model.flat_gradients()).item())
-            if self.data_parallel is not None and self.data_parallel.active:
-                found = self.data_parallel.any_rank(found)
-            if not found:
-                self.optimizer.loss_scale_inv = 1.0 / self.scaler.scale      # unscale inside the fused AdamW
-                try:
-                    self.optimizer.step()
-                finally:
-                    self.optimizer.loss_scale_inv = 1.0
-            self.scaler.update(found)
+            self.optimizer.skip_flag = slot_fn()
+            self._apply_update()
+            loss, loss_f0, loss_sil, fault = torch.cat([out3, self.optimizer.skip_flag]).tolist()
+            if fault != 0.0:
+                raise RuntimeError("LSTM fault word still set after falling back to the per-time-step kernels")
         self.scheduler.step()
-        loss, loss_f0, loss_sil = out3.tolist()            # one device->host copy for all three scalars
         return {"loss": loss, "f0": loss_f0, "sil": loss_sil}
 
     def _epoch(self, loader, tag, step_fn):
@@ -286,11 +320,17 @@ class Trainer(object):
         x, f0, sil = self._inputs(batch)
         with ops.matmul_bf16(self.use_amp, self.amp_dtype):
             f0_pred, sil_pred = self.model(x.transpose(-1, -2))
-        if self._lstm_fault(x.device, collective=False):
+        out3, _, _ = self._loss(f0_pred, sil_pred, f0, sil, False)
+        word = ops.persistent_lstm_error_word(x.device)        # this rank's word only: no collective in evaluation
+        if word is None:
+            loss, loss_f0, loss_sil = out3.tolist()
+            return {"loss": loss, "f0": loss_f0, "sil": loss_sil}
+        loss, loss_f0, loss_sil, fault = torch.cat([out3, word.float()]).tolist()     # one device->host copy
+        if fault != 0.0 and self._lstm_fault(x.device, collective=False):
             with ops.matmul_bf16(self.use_amp, self.amp_dtype):
                 f0_pred, sil_pred = self.model(x.transpose(-1, -2))
-        out3, _, _ = self._loss(f0_pred, sil_pred, f0, sil, False)
-        loss, loss_f0, loss_sil = out3.tolist()
+            out3, _, _ = self._loss(f0_pred, sil_pred, f0, sil, False)
+            loss, loss_f0, loss_sil = out3.tolist()
         return {"loss": loss, "f0": loss_f0, "sil": loss_sil}
 
     @torch.no_grad()

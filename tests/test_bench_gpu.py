@@ -67,3 +67,19 @@ def test_rccl_launch_at_world_size_one_keeps_stdout_clean(hip_device):
     ar = d["config"]["gradient_allreduce"]
     assert ar["backend"] == "nccl" and ar["payload"] == "bf16" and ar["rehearsal_world1"] is True
     assert d["dtype"] == "bf16" and d["n_gpus"] == 1
+
+
+def test_three_rank_launch_as_the_driver_launches_it(hip_device):
+    """The driver's multi-GPU command with an odd world size on one card over gloo (a one-GPU box admits six processes
+    on the card, and the test runner and the launcher count: three ranks; the eight-rank arithmetic -- shards, block
+    cuts, buckets, MAX-over-ranks -- runs on CPU in tests/test_distributed_cpu.py): one JSON line, whole-job aggregate."""
+    env = dict(os.environ, PE_FORCE_DEVICE="0", PE_DIST_BACKEND="gloo")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
+                          "--master-addr", "127.0.0.1", "--master-port", "29538", str(ROOT / "bench.py"), "--gpus", "3",
+                          "--batch", "8", "--steps", "2", "--warmup", "1", "--host-steps", "0"], cwd=str(ROOT), env=env,
+                         capture_output=True, text=True, timeout=1200)
+    d = _one_line(res)
+    assert CONTRACT <= set(d) and d["n_gpus"] == 3 and d["config"]["global_batch"] == 24
+    assert d["config"]["parallelism"] == "dp3" and "cpu_baseline" not in d and "kernel_families" not in d
+    assert d["config"]["gradient_allreduce"]["messages_per_step"] >= 5
+    assert abs(d["value"] - 24 * 192 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]

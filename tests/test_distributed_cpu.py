@@ -217,3 +217,59 @@ def test_shard_sampler_properties():
         assert max(map(len, val)) - min(map(len, val)) <= 1
 
     check()
+
+
+def _world8_worker(rank, world, port, out_dir):
+    """The 8-rank shape of the driver's scaling run, on CPU: JDCNet's backward-order block cuts over its real flat
+    gradient buffer (default BiLSTM: 28.9 M elements + the status slot), fp32 and bf16 buckets, the shard arithmetic
+    bench.py uses for rank 7, the epoch sampler, and the MAX-over-ranks timing reduction."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    r, w, local = pdist.init_from_env("gloo")
+    assert (r, w, local) == (rank, 8, rank)
+    from pitchextractor_amd.model import JDCNet
+    torch.manual_seed(1234)
+    net = JDCNet(num_class=1, sequence_model_config={"model_type": "bilstm", "num_layers": 1, "hidden_size": 32})
+    cuts = net._block_cuts()
+    n = net.flat_gradients().numel()
+    assert cuts is not None and n == net._status_off + 4
+    for payload in ("fp32", "bf16"):
+        g = net.flat_gradients()
+        g.copy_(torch.arange(n, dtype=torch.float32) % 251 * (1.0 if payload == "fp32" else 0.5) + rank)
+        net.status_slot().fill_(1.0 if rank == 5 else 0.0)            # one rank reports a fault
+        opt = _Opt()
+        dp = pdist.GradientAllReduce(g, opt, bucket_bytes=256 << 10, flat_param=net.flat_parameters.data, payload=payload)
+        assert opt.grad_scale == 1.0 / 8
+        # the order JDCNet._backward_impl issues: temporal + output heads (with the status slot), block 3, 2, 1, conv_block
+        dp.reduce_range(net._seq_offset(), n)
+        for k in (3, 2, 1):
+            dp.reduce_range(cuts[k], cuts[k + 1])
+        dp.reduce_range(0, cuts[1])
+        dp.finish()
+        base = torch.arange(n, dtype=torch.float32) % 251 * (1.0 if payload == "fp32" else 0.5)
+        expect = 8 * base + sum(range(8))
+        expect[net._status_off] = 1.0                                  # the fault count, seen by every rank
+        expect[net._status_off + 1:] = 8 * base[net._status_off + 1:] + sum(range(8))
+        if payload == "fp32":
+            assert torch.equal(g, expect)
+        else:                                                          # small integers / halves: exact in bf16 sums too
+            assert torch.allclose(g, expect, rtol=2.0 ** -6, atol=0)
+        assert g[net._status_off].item() == 1.0
+    lo, hi = pdist.shard_range(8 * 256, rank, world)
+    assert (lo, hi) == (256 * rank, 256 * rank + 256) and lo % 32 == 0
+    s = pdist.EpochShardSampler(1000, 8, rank, world, seed=3)
+    s.set_epoch(2)
+    assert len(s) == (1000 // 64) * 8
+    t = torch.tensor([float(rank)], dtype=torch.float64)              # bench.py: elapsed = MAX over ranks
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    assert t.item() == 7.0
+    np.save(os.path.join(out_dir, f"w8_{rank}.npy"), np.array(list(s)))
+    dist.destroy_process_group()
+
+
+def test_world_8_block_cuts_buckets_and_sharding(tmp_path):
+    mp.spawn(_world8_worker, args=(8, _free_port(), str(tmp_path)), nprocs=8, join=True)
+    shards = [np.load(tmp_path / f"w8_{r}.npy") for r in range(8)]
+    flat = np.concatenate(shards)
+    assert len(set(flat.tolist())) == len(flat) == 8 * 120
