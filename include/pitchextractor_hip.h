@@ -103,8 +103,6 @@ int pe_gemm_nt_x3(const float* A, long lda, const float* B, long ldb, float* C, 
 int pe_gemm_nt_h2(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
                   int K, const float* bias0, const float* bias1, int accumulate, const unsigned* amax_a,
                   const unsigned* amax_b, void* stream);
-/* Experiment switches for tools/ (kernel variants under A/B measurement); the product path never calls it. */
-int pe_tune_set(int key, int value);
 /* out[0] = IEEE bits of max |x| over a [rows][cols] matrix with leading dimension ld (cols, ld % 4 == 0, x 16-byte
  * aligned); zeroes out[0] first.  Exact and order-independent (integer max of the magnitudes' bit patterns). */
 int pe_absmax(const float* x, long rows, int cols, long ld, unsigned* out, void* stream);

@@ -55,27 +55,29 @@ static inline int pe_pick_splits(int tiles, long K, int min_k_per_split, int res
   return best;
 }
 
-// Ordered sum of `splits` slabs at float4 index i4 (element 4*i4 .. 4*i4+3): s = ((0 + w[0]) + w[1]) + ...,
-// the same order as a plain loop, with the loads issued eight at a time so the reduce kernels run at
-// memory speed instead of one dependent load latency per slab.
+// Ordered sum of `splits` slabs at float4 index i4 (element 4*i4 .. 4*i4+3), accumulated in DOUBLE in slab order
+// (every fp32 slab value is exact in double and so is their sum up to 2^29 terms' worth of exponent spread: the
+// result is the correctly rounded sum of the slabs for any realistic input, independent of how the reduction
+// dimension was cut -- the second level of the weight-gradient sums adds no error of its own).  Loads are issued
+// eight at a time so the reduce kernels run at memory speed instead of one dependent load latency per slab.
 __device__ __forceinline__ float4 pe_ordered_slab_sum4(const float* __restrict__ ws, long slab_stride, int splits,
                                                        long i4) {
   const float4* p = reinterpret_cast<const float4*>(ws) + i4;
   const long st4 = slab_stride >> 2;
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
   int z = 0;
   for (; z + 8 <= splits; z += 8) {
     float4 v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) v[u] = p[(long)(z + u) * st4];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    for (int u = 0; u < 8; ++u) { sx += (double)v[u].x; sy += (double)v[u].y; sz += (double)v[u].z; sw += (double)v[u].w; }
   }
   for (; z < splits; ++z) {
     const float4 v = p[(long)z * st4];
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    sx += (double)v.x; sy += (double)v.y; sz += (double)v.z; sw += (double)v.w;
   }
-  return s;
+  return make_float4((float)sx, (float)sy, (float)sz, (float)sw);
 }
 
 // Philox4x32-10 (dropout masks): 4 random words for counter `ctr`; element quad i of a dropout call uses

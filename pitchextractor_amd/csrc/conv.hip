@@ -9,8 +9,6 @@
 //   first layer (Cin = 1, model.py:24): 9 FMAs per output, HBM-bound on the 64-channel write.
 #include "gemm_engine.h"
 
-extern int g_pe_tune[16];
-
 namespace {
 using namespace pe;
 
@@ -1117,18 +1115,6 @@ static int conv3x3_fwd_wf_impl(const float* x, const void* wfrag, float* y, int 
   if (MODE == kSplit2 && (!amax_x || !amax_w)) return PE_E_ARG;
   hipStream_t st = pe_stream(stream);
   const int passes = conv_halo_passes(F, N);
-  if constexpr (MODE == kSplit2) {
-    const int v = g_pe_tune[0];
-    if (passes == 10 && v == 1)
-      return launch_conv_halo_wf<64, MODE, 10, 9, true>(x, wfrag, y, B, T, F, C, N, accumulate, stats, st, amax_x, amax_w);
-    if (passes == 7 && v >= 1) {
-      if (N % 192 == 0 && N % 128 != 0)
-        return launch_conv_halo_wf<192, MODE, 7, 6, false>(x, wfrag, y, B, T, F, C, N, accumulate, stats, st, amax_x, amax_w);
-      if (v == 1)
-        return launch_conv_halo_wf<128, MODE, 7, 6, true>(x, wfrag, y, B, T, F, C, N, accumulate, stats, st, amax_x, amax_w);
-      return launch_conv_halo_wf<128, MODE, 7, 6, false>(x, wfrag, y, B, T, F, C, N, accumulate, stats, st, amax_x, amax_w);
-    }
-  }
   if (passes == 10)
     return launch_conv_halo_wf<64, MODE, 10, 6, true>(x, wfrag, y, B, T, F, C, N, accumulate, stats, st, amax_x, amax_w);
   if (passes == 7) {

@@ -9,11 +9,6 @@
 #include <utility>
 #include "gemm_engine.h"
 
-#ifndef PE_F16_BUILD
-int g_pe_tune[16] = {0};          // experiment switches (tools/ only): pe_tune_set
-#else
-extern int g_pe_tune[16];
-#endif
 
 namespace {
 using namespace pe;
@@ -61,8 +56,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(RowLoader al, RowLoader bl
 // columns of one row instead of four rows of one column, and the epilogue writes 16-byte pieces (a quarter of the
 // store instructions, bias fetched once per column quad).  Bit-identical sums.  Needs N % 4 == 0 and a 16-byte
 // aligned C with ldc % 4 == 0 (checked by the host).
-template <class TL, int MODE, bool PF2 = false>
-__global__ __launch_bounds__(256, ((MODE == kSplit || MODE == kSplit2) && TL::BM == 128 && TL::BN == 128) ? (PF2 ? 2 : 3) : (PF2 ? 2 : 1))
+template <class TL, int MODE>
+__global__ __launch_bounds__(256, ((MODE == kSplit || MODE == kSplit2) && TL::BM == 128 && TL::BN == 128) ? 3 : 1)
 void gemm_nt_t_kernel(RowLoader al, RowLoader bl, StoreEpi ep, int K, int tiles_m, int tiles_n,
                       const unsigned* amax_a, const unsigned* amax_b) {
   using TT = Tile<TL::BN, TL::BM, TL::WAVES_N, TL::WAVES_M>;
@@ -76,7 +71,7 @@ void gemm_nt_t_kernel(RowLoader al, RowLoader bl, StoreEpi ep, int K, int tiles_
   zero_acc<TT>(acc);
   H2Scales hs{1.f, 1.f, 1.f};
   if constexpr (MODE == kSplit2) hs.load(amax_a, amax_b);
-  nt_mainloop_mode<TT, MODE, true, PF2>(bl, al, K, Bs, As, acc, hs.sb, hs.sa);
+  nt_mainloop_mode<TT, MODE, true>(bl, al, K, Bs, As, acc, hs.sb, hs.sa);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wn = wv / TT::WAVES_N, wm = wv % TT::WAVES_N;          // TT's "rows" are output columns
   const int r = lane & 31, h = lane >> 5;
@@ -299,10 +294,7 @@ int launch_nt(const RowLoader& al, const RowLoader& bl, const StoreEpi& ep, int 
   static const bool off = getenv("PE_GEMM_NT_SCALAR_EPILOGUE") != nullptr;     // A/B switch (tools/ab_gemm.py)
   const bool vec = !off && MODE != kNative && (N & 3) == 0 && (ep.ldc & 3) == 0 &&
                    (reinterpret_cast<uintptr_t>(ep.C) & 15) == 0;
-  if (vec && MODE == kSplit2 && g_pe_tune[1] == 1)
-    hipLaunchKernelGGL((gemm_nt_t_kernel<TL, MODE, MODE == kSplit2>), dim3(tm * tn), dim3(256), 0, st, al, bl, ep, K, tm,
-                       tn, amax_a, amax_b);
-  else if (vec)
+  if (vec)
     hipLaunchKernelGGL((gemm_nt_t_kernel<TL, MODE>), dim3(tm * tn), dim3(256), 0, st, al, bl, ep, K, tm, tn, amax_a,
                        amax_b);
   else
@@ -530,14 +522,6 @@ int launch_tn(const float* A, long lda, const float* B, long ldb, float* C, long
 }
 
 }  // namespace
-
-#ifndef PE_F16_BUILD
-extern "C" int pe_tune_set(int key, int value) {
-  if (key < 0 || key >= 16) return PE_E_ARG;
-  g_pe_tune[key] = value;
-  return PE_OK;
-}
-#endif
 
 static bool g_nt_pipeline = getenv("PE_GEMM_NT_PIPE") != nullptr && getenv("PE_GEMM_NT_PIPE")[0] == '1';
 

@@ -451,69 +451,6 @@ __device__ __forceinline__ void nt_mainloop_split(AL& al, BL& bl, int K, float* 
   }
 }
 
-// Same loop with the operand registers TWO k-tiles ahead (two register sets, the loop unrolled by two): with three
-// MFMAs per product block the MFMA phase of a k-tile (~0.6 us) no longer covers the latency of the loads issued at
-// its start, which the single-set loop above waits for at the next tile's stores.
-template <class TL, bool SW = false, int NT = 3, class AL, class BL>
-__device__ __forceinline__ void nt_mainloop_split_pf2(AL& al, BL& bl, int K, float* As_f, float* Bs_f,
-                                                      f32x16 (&acc)[TL::TM][TL::TN], float sa = 1.0f, float sb = 1.0f) {
-  constexpr int A_IMG = TL::BM * kBK, B_IMG = TL::BN * kBK;
-  __bf16* As = reinterpret_cast<__bf16*>(As_f);
-  __bf16* Bs = reinterpret_cast<__bf16*>(Bs_f);
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int wm = wv / TL::WAVES_N, wn = wv % TL::WAVES_N;
-  const int r = lane & 31, h = lane >> 5;
-  const int nk = (K + kBK - 1) / kBK;
-  float4 ra0[TL::A_LOADS], rb0[TL::B_LOADS], ra1[TL::A_LOADS], rb1[TL::B_LOADS];
-#pragma unroll
-  for (int i = 0; i < TL::A_LOADS; ++i) ra0[i] = al.load(i, 0);
-#pragma unroll
-  for (int i = 0; i < TL::B_LOADS; ++i) rb0[i] = bl.load(i, 0);
-  if (nk > 1) {
-#pragma unroll
-    for (int i = 0; i < TL::A_LOADS; ++i) ra1[i] = al.load(i, 1);
-#pragma unroll
-    for (int i = 0; i < TL::B_LOADS; ++i) rb1[i] = bl.load(i, 1);
-  }
-  const int srow = tid >> 3, piece = tid & 7;
-  auto tile = [&](float4 (&ra)[TL::A_LOADS], float4 (&rb)[TL::B_LOADS], int kt) {
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < TL::A_LOADS; ++i) halo_store<NT>(As, A_IMG, srow + 32 * i, piece, ra[i], sa);
-#pragma unroll
-    for (int i = 0; i < TL::B_LOADS; ++i) halo_store<NT>(Bs, B_IMG, srow + 32 * i, piece, rb[i], sb);
-    __syncthreads();
-    if (kt + 2 < nk) {
-#pragma unroll
-      for (int i = 0; i < TL::A_LOADS; ++i) ra[i] = al.load(i, kt + 2);
-#pragma unroll
-      for (int i = 0; i < TL::B_LOADS; ++i) rb[i] = bl.load(i, kt + 2);
-    }
-#pragma unroll
-    for (int kk = 0; kk < kBK / 16; ++kk) {
-      bf16x8 fa[TL::TM][NT], fb[TL::TN][NT];
-#pragma unroll
-      for (int i = 0; i < TL::TM; ++i)
-#pragma unroll
-        for (int c = 0; c < NT; ++c)
-          fa[i][c] = *reinterpret_cast<const bf16x8*>(As + c * A_IMG + swz_off(wm * TL::WM + i * 32 + r, kk * 2 + h));
-#pragma unroll
-      for (int j = 0; j < TL::TN; ++j)
-#pragma unroll
-        for (int c = 0; c < NT; ++c)
-          fb[j][c] = *reinterpret_cast<const bf16x8*>(Bs + c * B_IMG + swz_off(wn * TL::WN + j * 32 + r, kk * 2 + h));
-#pragma unroll
-      for (int i = 0; i < TL::TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TL::TN; ++j) acc[i][j] = mfma_terms<NT, SW>(fa[i], fb[j], acc[i][j]);
-    }
-  };
-  for (int kt = 0; kt < nk; kt += 2) {
-    tile(ra0, rb0, kt);
-    if (kt + 1 < nk) tile(ra1, rb1, kt + 1);
-  }
-}
-
 // compile-time loop: body(std::integral_constant<int, I>) for I = 0 .. N-1 (a plain `#pragma unroll` loop of a few
 // hundred instructions is only partly unrolled, and its indices then stop being constants)
 template <class F, int... Q>
@@ -527,12 +464,11 @@ template <int MODE> constexpr int nt_row_floats() {
   return MODE == kSplit ? kSplitRowFloats : MODE == kSplit2 ? 2 * kBK / 2 : kLdsStride;
 }
 
-template <class TL, int MODE, bool SW = false, bool PF2 = false, class AL, class BL>
+template <class TL, int MODE, bool SW = false, class AL, class BL>
 __device__ __forceinline__ void nt_mainloop_mode(AL& al, BL& bl, int K, float* As, float* Bs,
                                                  f32x16 (&acc)[TL::TM][TL::TN], float sa = 1.0f, float sb = 1.0f) {
   if constexpr (MODE == kBf16) nt_mainloop_bf16<TL>(al, bl, K, As, Bs, acc);
   else if constexpr (MODE == kSplit) nt_mainloop_split<TL, SW, 3>(al, bl, K, As, Bs, acc);
-  else if constexpr (MODE == kSplit2 && PF2) nt_mainloop_split_pf2<TL, SW, 2>(al, bl, K, As, Bs, acc, sa, sb);
   else if constexpr (MODE == kSplit2) nt_mainloop_split<TL, SW, 2>(al, bl, K, As, Bs, acc, sa, sb);
   else nt_mainloop<TL>(al, bl, K, As, Bs, acc);
 }

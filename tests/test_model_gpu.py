@@ -268,10 +268,13 @@ def test_full_size_training_step_matches_oracle_by_tiling(hip_device, oracle_b8,
     oracle at B = 8 is the oracle for B = 256 too.  This is where the split-K planner, the XCD remap, the
     9-tap weight-gradient slab reduction over 3.9 M pixels and the full persistent-LSTM grid run at their
     bench shapes.  Tolerances: logits 1e-4 of scale, loss 1e-5, per-parameter gradient norms 2e-3 (the golden
-    test's), every gradient ELEMENT within 2.5e-2 of its tensor's largest element against float64 -- the
-    weight gradients in front of a train-mode BatchNorm are sums with heavy cancellation: the reference's own
-    fp32 CPU path is off by up to 5.8e-3 there and this path by 1.1e-2 (native) / 1.4e-2 (x3) -- and, the
-    actual point of the test, within 1e-3 of the SAME path run at B = 8 (measured: identical to 3 digits)."""
+    test's), every gradient ELEMENT within 1.5e-2 of its tensor's largest element against float64 -- the
+    reference's own fp32 CPU path is off by up to 5.8e-3 there and this path by 1.07e-2 (h2) / 1.08e-2 (native) /
+    1.37e-2 (x3).  That deviation is NOT the weight-gradient kernels' accumulation: capping a slab at 2 048 pixels
+    instead of 7 680, summing the slabs in double, running the recurrences on the per-time-step kernels or on the
+    native fp32 MFMA all leave it unchanged to three digits (tools/fs_tune.py) -- it is fp32 rounding anywhere upstream
+    (forward activations, the 4 x 192-step recurrences) seen through train-mode BatchNorm's cancelling backward --
+    and, the actual point of the test, within 1e-3 of the SAME path run at B = 8 (measured: identical to 3 digits)."""
     monkeypatch.setattr(ops, "FP32_MATMUL", fp32_mode)
     state, x8, f0, sil, (ref_cls, ref_det, ref_loss, ref_g) = oracle_b8
     reps = 32
@@ -284,17 +287,19 @@ def test_full_size_training_step_matches_oracle_by_tiling(hip_device, oracle_b8,
         close(cls[8 * r:8 * r + 8], ref_cls.numpy(), 1e-4)
         close(det[8 * r:8 * r + 8], ref_det.numpy(), 1e-4)
     assert abs(loss - ref_loss) <= 1e-5 * abs(ref_loss) and abs(loss - loss8) <= 1e-6 * abs(ref_loss)
-    bad = []
+    bad, worst = [], (0.0, "")
     for n, got in g.items():
         ref = ref_g[n]
         got64, top = got.cpu().double(), ref.abs().max().item()
         rn = ref.norm().item()
+        worst = max(worst, ((got64 - ref).abs().max().item() / (top + 1e-30), n))
         if abs(got64.norm().item() - rn) > 2e-3 * rn + 1e-9:
             bad.append((n, "norm", got64.norm().item(), rn))
-        if (got64 - ref).abs().max().item() > 2.5e-2 * top + 1e-9:
+        if (got64 - ref).abs().max().item() > 1.5e-2 * top + 1e-9:
             bad.append((n, "elem vs float64", (got64 - ref).abs().max().item(), top))
         if (got - g8[n]).abs().max().item() > 1e-3 * top + 1e-9:
             bad.append((n, "elem vs B=8", (got - g8[n]).abs().max().item(), top))
+    print(f"{fp32_mode}: worst gradient element error vs float64 / tensor max = {worst[0]:.2e} ({worst[1]})")
     assert not bad, bad
 
 
