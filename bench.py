@@ -65,20 +65,38 @@ def host_cores():
     return max(1, min(n, 32))
 
 
+PMC_SUMMARY = "profiles/pmc_r03_summary.json"
+
+
 def pmc_traffic(conv_key="pe_conv3x3_fwd"):
     """(HBM-side bytes per launch, MFMA-busy share) of the roofline kernel family from the committed rocprofv3 --pmc
-    passes of this same command (profiles/pmc_r02_summary.json, built by tools/prof_step.sh + tools/pmc_build.py:
-    FETCH_SIZE / WRITE_SIZE / SQ counters in separate passes, FETCH doubled per the gfx950 correction).  Launch-weighted
-    over the family's tile variants; (None, None) when the profile holds no entry for this mode."""
-    prefix = {"pe_conv3x3_fwd_x3": "conv3x3_halo_wf_kernel<", "pe_conv3x3_fwd_wf_x3": "conv3x3_halo_wf_kernel<"}.get(conv_key)
+    passes of this same command (PMC_SUMMARY, built by tools/prof_step.sh + tools/pmc_build.py: FETCH_SIZE /
+    WRITE_SIZE / SQ counters in separate passes, FETCH doubled per the gfx950 correction).  Launch-weighted over the
+    family's tile variants; (None, None) when the profile holds no entry for this mode.  These two numbers are read from
+    the committed profile, NOT measured in this run: the line carries `traffic_source` next to them."""
+    import re
+    mode = {"pe_conv3x3_fwd_x3": 2, "pe_conv3x3_fwd_wf_x3": 2, "pe_conv3x3_fwd_h2": 3, "pe_conv3x3_fwd_wf_h2": 3,
+            "pe_conv3x3_fwd_bf16": 1, "pe_conv3x3_fwd_wf_bf16": 1}.get(conv_key)
     try:
-        d = json.loads((ROOT / "profiles" / "pmc_r02_summary.json").read_text())["kernels"]
-        rows = [v for k, v in d.items() if prefix and k.startswith(prefix) and ", 2, " in k and "hbm_bytes_per_launch" in v]
+        d = json.loads((ROOT / PMC_SUMMARY).read_text())["kernels"]
+        rows = [v for k, v in d.items() if mode is not None and re.match(r"conv3x3_halo_wf_kernel<\d+, %d, " % mode, k)
+                and "hbm_bytes_per_launch" in v and v.get("calls")]
         n = sum(v["calls"] for v in rows)
         return (sum(v["hbm_bytes_per_launch"] * v["calls"] for v in rows) / n,
                 sum(v["mfma_busy"] * v["calls"] for v in rows) / n)
     except Exception:
         return None, None
+
+
+def pmc_source():
+    """`<file>@<commit that last touched it>` for the profile the traffic numbers come from."""
+    import subprocess
+    try:
+        rev = subprocess.run(["git", "log", "-1", "--format=%h", "--", PMC_SUMMARY], cwd=str(ROOT), capture_output=True,
+                             text=True, timeout=10).stdout.strip()
+    except Exception:
+        rev = ""
+    return PMC_SUMMARY + ("@" + rev if rev else "")
 
 
 def cpu_baseline(n_steps=10, batch=4, n_warm=2):
@@ -382,7 +400,16 @@ def main():
                                                  "conv3x3_halo_kernel (halo-staged implicit GEMM; " + which + ")")),
                     "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak,
                     "peak_note": note, "traffic": pmc_traffic(conv_key)[0], "mfma_busy_pmc": pmc_traffic(conv_key)[1],
+                    "traffic_source": pmc_source() + " (rocprofv3 --pmc passes of this command, committed; not "
+                                                     "re-measured in this run)",
                     "avg_launch_ms": conv["avg_ms"], "launches_per_step": conv["calls"] / args.steps}
+            # the whole step against the same ceiling: SURVEY 8(d)'s 369.6 (BiLSTM) / 344.4 (Transformer) MFLOP per frame
+            step_flop = (369.6e6 if args.head == "bilstm" else 344.4e6) * args.batch * FRAMES
+            roof["whole_step"] = {"achieved": step_flop / (ms * 1e-3) / 1e12, "unit": "TFLOP/s",
+                                  "frac": step_flop / (ms * 1e-3) / 1e12 / peak,
+                                  "flop_per_step": step_flop,
+                                  "note": "all algorithmic FLOPs of the step (fwd + dgrad + wgrad, every family) over the "
+                                          "timed step, same peak as above"}
             if overlapped and dgrad:
                 roof["dgrad_overlapped"] = {"avg_launch_ms": dgrad["avg_ms"], "launches_per_step": dgrad["calls"] / args.steps,
                                             "achieved": dgrad["work"] / (dgrad["total_ms"] * 1e-3) / 1e12,

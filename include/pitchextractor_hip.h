@@ -106,6 +106,10 @@ int pe_gemm_nt_h2(const float* A, long lda, const float* B, long ldb, float* C, 
 /* out[0] = IEEE bits of max |x| over a [rows][cols] matrix with leading dimension ld (cols, ld % 4 == 0, x 16-byte
  * aligned); zeroes out[0] first.  Exact and order-independent (integer max of the magnitudes' bit patterns). */
 int pe_absmax(const float* x, long rows, int cols, long ld, unsigned* out, void* stream);
+/* out[s] = IEEE bits of max |base[seg_off[s] .. + seg_len[s])| for s < nseg, one launch (seg_off / seg_len: device
+ * arrays; every parameter of a model that lives in one flat buffer). */
+int pe_absmax_segments(const float* base, const long* seg_off, const long* seg_len, int nseg, unsigned* out,
+                       void* stream);
 /* pe_gemm_nt_wf_*: the same product with B given as pe_wfrag_pack(B, ldb, N, K, terms) (see the convolution
  * section): the weight operand comes from L2 in MFMA fragment order, only A is staged through LDS. */
 int pe_gemm_nt_wf_x3(const float* A, long lda, const void* wfrag, float* C, long ldc, int M, int N, int K,

@@ -44,6 +44,7 @@ PROTOTYPES = {
     "pe_gemm_nt_x3": (_i, [_p, _l, _p, _l, _p, _l, _i, _i, _i, _p, _p, _i, _p]),
     "pe_gemm_nt_h2": (_i, [_p, _l, _p, _l, _p, _l, _i, _i, _i, _p, _p, _i, _p, _p, _p]),
     "pe_absmax": (_i, [_p, _l, _i, _l, _p, _p]),
+    "pe_absmax_segments": (_i, [_p, _p, _p, _i, _p, _p]),
     "pe_gemm_nt_wf_x3": (_i, [_p, _l, _p, _p, _l, _i, _i, _i, _p, _p, _i, _p]),
     "pe_gemm_nt_wf_bf16": (_i, [_p, _l, _p, _p, _l, _i, _i, _i, _p, _p, _i, _p]),
     "pe_gemm_nt_wf_ablate": (_i, [_i, _p, _l, _p, _p, _l, _i, _i, _i, _p]),

@@ -577,6 +577,28 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
   if (threadIdx.x == 0) atomicMax(out, max(max(red[0], red[1]), max(red[2], red[3])));
 }
 
+// absmax of many segments of one buffer in a single launch (the model's parameters inside the flat buffer): block
+// (x, y) folds chunk x of segment y and max-merges into out[y]
+__global__ __launch_bounds__(256) void absmax_segments_kernel(const float* __restrict__ base,
+                                                              const long* __restrict__ seg_off,
+                                                              const long* __restrict__ seg_len,
+                                                              unsigned* __restrict__ out) {
+  const float* x = base + seg_off[blockIdx.y];
+  const long n = seg_len[blockIdx.y];
+  unsigned m = 0u;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+  __shared__ unsigned red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned w = max(max(red[0], red[1]), max(red[2], red[3]));
+    if (w) atomicMax(out + blockIdx.y, w);
+  }
+}
+
 }  // namespace
 
 extern "C" size_t pe_bn_workspace_bytes(int C) { return (size_t)kMaxPartials * 2 * C * sizeof(double); }
@@ -763,6 +785,16 @@ extern "C" int pe_absmax(const float* x, long rows, int cols, long ld, unsigned*
   const long n4 = rows * (cols / 4);
   const int grid = (int)(n4 / 2048 < 1 ? 1 : n4 / 2048 > 2048 ? 2048 : n4 / 2048);     // >= 8 float4 per thread
   hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, st, x, rows, cols / 4, ld, out);
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+
+extern "C" int pe_absmax_segments(const float* base, const long* seg_off, const long* seg_len, int nseg, unsigned* out,
+                                  void* stream) {
+  if (!base || !seg_off || !seg_len || !out || nseg <= 0 || nseg > 65535) return PE_E_ARG;
+  hipStream_t st = pe_stream(stream);
+  PE_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)nseg * sizeof(unsigned), st));
+  hipLaunchKernelGGL(absmax_segments_kernel, dim3(16, nseg), dim3(256), 0, st, base, seg_off, seg_len, out);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }

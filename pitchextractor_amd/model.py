@@ -202,27 +202,32 @@ def _flat2(t):
     return t.view(-1, t.shape[-1])
 
 
-def _res_forward(blk: _ResBlock, x, pool, train, need_grad, slope, x_stats=None):
+def _no_amax(_param):
+    return None
+
+
+def _res_forward(blk: _ResBlock, x, pool, train, need_grad, slope, x_stats=None, wa=_no_amax):
     """x [B,T,F,Cin] -> [B,T,F/pool,Cout]; returns (out, saved, BatchNorm partials of out or None)."""
     s = _Ctx()
     s.x = x
     s.bn_pre = _bn(blk.pre_conv[0], x, train, x_stats)
     s.am_p = ops.amax_word()            # "h2" products: one absmax word per operand tensor, left by its producer
     s.p = ops.bn_act_pool_fwd(x, s.bn_pre, pool=pool, slope=slope, amax_out=s.am_p)
-    out = ops.gemm_nt(_flat2(s.p), blk.conv1by1.weight.view(blk.cout, blk.cin), amax_a=s.am_p)
+    out = ops.gemm_nt(_flat2(s.p), blk.conv1by1.weight.view(blk.cout, blk.cin), amax_a=s.am_p,
+                      amax_b=wa(blk.conv1by1.weight))
     out = out.view(*s.p.shape[:3], blk.cout)
-    wf0, s.wd0 = ops.conv3x3_repack(blk.conv[0].weight, True, need_grad)
+    wf0, s.wd0 = ops.conv3x3_repack(blk.conv[0].weight, True, need_grad, amax=wa(blk.conv[0].weight))
     s.c, c_stats = ops.conv3x3_fwd(s.p, wf0, bn_stats=train, amax=s.am_p)
     s.bn_mid = _bn(blk.conv[1], s.c, train, c_stats)
     s.am_a = ops.amax_word()
     s.a = ops.bn_act_pool_fwd(s.c, s.bn_mid, pool=1, slope=slope, amax_out=s.am_a)
-    wf3, s.wd3 = ops.conv3x3_repack(blk.conv[3].weight, True, need_grad)
+    wf3, s.wd3 = ops.conv3x3_repack(blk.conv[3].weight, True, need_grad, amax=wa(blk.conv[3].weight))
     _, out_stats = ops.conv3x3_fwd(s.a, wf3, out=out, accumulate=True, bn_stats=train,   # conv(x) + conv1by1(x), model.py:171-172
                                    amax=s.am_a)
     return out, s, out_stats
 
 
-def _res_backward(blk: _ResBlock, s, d_out, pool, slope, grads, side, am_do=None):
+def _res_backward(blk: _ResBlock, s, d_out, pool, slope, grads, side, am_do=None, wa=_no_amax):
     """d_out: grad of the block output (am_do: its absmax word if the producer left one).  Returns (grad wrt the block
     input (dense, overwritten), its absmax word).  The three weight gradients go through `side` (_SideWork)."""
     if am_do is None:
@@ -241,7 +246,7 @@ def _res_backward(blk: _ResBlock, s, d_out, pool, slope, grads, side, am_do=None
     with ops.timer_tag("dgrad"):
         d_p = ops.conv3x3_fwd(d_c, s.wd0, amax=am_dc)
     w1t = ops.transpose2d(blk.conv1by1.weight.view(blk.cout, blk.cin))
-    ops.gemm_nt(_flat2(d_out), w1t, out=_flat2(d_p), accumulate=True, amax_a=am_do)
+    ops.gemm_nt(_flat2(d_out), w1t, out=_flat2(d_p), accumulate=True, amax_a=am_do, amax_b=wa(blk.conv1by1.weight))
     am_dx = ops.amax_word()
     return ops.bn_act_pool_bwd(s.x, d_p, s.bn_pre, grads[blk.pre_conv[0].weight], grads[blk.pre_conv[0].bias],
                                pool=pool, slope=slope, amax_out=am_dx), am_dx
@@ -281,7 +286,7 @@ def _dropout_bwd(dy2d, p, mask, out2d=None):
     return out
 
 
-def _lstm_forward(models, xs, train, need_grad, drop: _DropoutCfg):
+def _lstm_forward(models, xs, train, need_grad, drop: _DropoutCfg, wa=_no_amax):
     """models: list of SequenceModel (identical shapes); xs: list of [B,T,in].  One launch per time step
     advances every (model, direction) cell of a layer together."""
     m0 = models[0].model
@@ -303,7 +308,8 @@ def _lstm_forward(models, xs, train, need_grad, drop: _DropoutCfg):
         for mi, sm in enumerate(models):
             for d in range(ND):
                 w_ih, w_hh, b_ih, b_hh = sm.model.cell(layer, d)
-                g = ops.gemm_nt(_flat2(cur[mi]), w_ih, bias0=b_ih, bias1=b_hh, amax_a=lay.am_x[mi]).view(B, T, 4 * H)
+                g = ops.gemm_nt(_flat2(cur[mi]), w_ih, bias0=b_ih, bias1=b_hh, amax_a=lay.am_x[mi],
+                                amax_b=wa(w_ih)).view(B, T, 4 * H)
                 cb = torch.empty((B, T, H), dtype=torch.float32, device=g.device)
                 whh.append(w_hh); gts.append(g); cbs.append(cb); rev.append(d)
                 ysl.append(ys[mi][:, :, d * H:(d + 1) * H])
@@ -385,7 +391,7 @@ OVERLAP_TF_WGRAD = os.environ.get("PE_OVERLAP_TF_WGRAD", "1") != "0"
 LSTM_WGRAD_JOIN_EARLY = os.environ.get("PE_LSTM_WGRAD_JOIN", "early") == "early"
 
 
-def _lstm_backward(models, saved, dys, grads, side):
+def _lstm_backward(models, saved, dys, grads, side, wa=_no_amax):
     """dys: list of [B,T,ND*H] grads of the top layer outputs.  Returns grads of the inputs.  Weight / bias gradients
     go through `side` (_SideWork) and are NOT joined here."""
     m0 = models[0].model
@@ -420,7 +426,7 @@ def _lstm_backward(models, saved, dys, grads, side):
             for d in range(ND):
                 w_ih = sm.model.cell(layer, d)[0]
                 ops.gemm_nt(_flat2(lay.gates[mi * ND + d]), ops.transpose2d(w_ih), out=_flat2(dx), accumulate=(d > 0),
-                            amax_a=am_dg[mi * ND + d])
+                            amax_a=am_dg[mi * ND + d], amax_b=wa(w_ih))
             dxs.append(dx)
 
         # ... the weight / bias gradients need nothing downstream: on the (low-priority) side stream they fill the
@@ -708,6 +714,7 @@ class JDCNet(nn.Module):
         self._grad_flat = None
         self._param_offsets = {id(p): off for p, off in zip(params, offsets)}
         self._param_list = params
+        self._wseg = self._wamax = None
 
     def _apply(self, fn, recurse=True):
         out = super()._apply(fn, recurse)
@@ -752,6 +759,25 @@ class JDCNet(nn.Module):
             self._grad_flat = torch.zeros_like(self._flat, requires_grad=False)
         return self._grad_flat
 
+    def _refresh_weight_amax(self):
+        """"h2" products: the absmax word of every parameter, one launch per forward over the flat buffer."""
+        if not ops.h2_active() or self._flat is None or not self._flat.is_cuda:
+            self._wamax = None
+            return
+        if getattr(self, "_wseg", None) is None or self._wseg[0].device != self._flat.device:
+            offs = torch.tensor([self._param_offsets[id(p)] for p in self._param_list], dtype=torch.int64)
+            lens = torch.tensor([p.numel() for p in self._param_list], dtype=torch.int64)
+            self._wseg = (offs.to(self._flat.device), lens.to(self._flat.device))
+            self._windex = {id(p): i for i, p in enumerate(self._param_list)}
+        self._wamax = ops.absmax_segments(self._flat.detach(), self._wseg[0], self._wseg[1])
+
+    def weight_amax(self, param):
+        """1-element view of the absmax word of ``param`` (None outside "h2" mode)."""
+        if getattr(self, "_wamax", None) is None:
+            return None
+        i = self._windex[id(param)]
+        return self._wamax[i:i + 1]
+
     def status_slot(self) -> torch.Tensor:
         """1-element view of the flat gradient buffer behind the last parameter: 0 after a clean backward, non-zero
         when a persistent-LSTM hand-off timed out in this step (summed over ranks by the gradient all-reduce).  The
@@ -788,6 +814,7 @@ class JDCNet(nn.Module):
     def _forward_impl(self, x, need_grad):
         train = self.training
         slope = self.leaky_relu_slope
+        self._refresh_weight_amax()
         s = _Ctx()
         x_btf = x[:, 0].float()
         B, T, F = x_btf.shape
@@ -797,11 +824,12 @@ class JDCNet(nn.Module):
         s.bn0 = _bn(cbk[1], s.y0, train, y0_stats)
         s.am_a0 = ops.amax_word()
         s.a0 = ops.bn_act_pool_fwd(s.y0, s.bn0, pool=1, slope=slope, amax_out=s.am_a0)
-        wf, s.wd_cb = ops.conv3x3_repack(cbk[3].weight, True, need_grad)
+        wf, s.wd_cb = ops.conv3x3_repack(cbk[3].weight, True, need_grad, amax=self.weight_amax(cbk[3].weight))
         s.cb, st_cb = ops.conv3x3_fwd(s.a0, wf, bn_stats=train, amax=s.am_a0)        # convblock_out
-        s.rb1, s.r1, st1 = _res_forward(self.res_block1, s.cb, 2, train, need_grad, slope, st_cb)
-        s.rb2, s.r2, st2 = _res_forward(self.res_block2, s.rb1, 2, train, need_grad, slope, st1)
-        s.rb3, s.r3, st3 = _res_forward(self.res_block3, s.rb2, 2, train, need_grad, slope, st2)
+        wa = self.weight_amax
+        s.rb1, s.r1, st1 = _res_forward(self.res_block1, s.cb, 2, train, need_grad, slope, st_cb, wa)
+        s.rb2, s.r2, st2 = _res_forward(self.res_block2, s.rb1, 2, train, need_grad, slope, st1, wa)
+        s.rb3, s.r3, st3 = _res_forward(self.res_block3, s.rb2, 2, train, need_grad, slope, st2, wa)
 
         # pool_block -> channels [384, 640) of the detector concat (model.py:36-41,90,108)
         Fp = s.rb3.shape[2] // 4
@@ -819,7 +847,8 @@ class JDCNet(nn.Module):
         ops.maxpool_fwd(s.rb1, 20, out=s.concat, coff=64)
         ops.maxpool_fwd(s.rb2, 10, out=s.concat, coff=192)
         wdet = self.detector_conv[0].weight.view(256, 640)
-        s.dconv = ops.gemm_nt(s.concat.view(-1, 640), wdet).view(B, T, 2, 256)
+        s.dconv = ops.gemm_nt(s.concat.view(-1, 640), wdet, amax_b=self.weight_amax(self.detector_conv[0].weight))
+        s.dconv = s.dconv.view(B, T, 2, 256)
         s.bnd = _bn(self.detector_conv[1], s.dconv, train)
         dact = ops.bn_act_pool_fwd(s.dconv, s.bnd, pool=1, slope=slope)
         ddrop, s.mask_det = _dropout(self.dropout_cfg, _flat2(dact), p_blk)
@@ -827,7 +856,7 @@ class JDCNet(nn.Module):
 
         models = [self.sequence_classifier, self.sequence_detector]
         if models[0].model_type == "bilstm":
-            (yc, yd), s.lstm = _lstm_forward(models, [seq_c, seq_d], train, need_grad, self.dropout_cfg)
+            (yc, yd), s.lstm = _lstm_forward(models, [seq_c, seq_d], train, need_grad, self.dropout_cfg, wa)
         else:
             yc, s.tf_c = _tf_forward(models[0], seq_c, train, need_grad, self.dropout_cfg)
             yd, s.tf_d = _tf_forward(models[1], seq_d, train, need_grad, self.dropout_cfg)
@@ -867,7 +896,8 @@ class JDCNet(nn.Module):
         models = [self.sequence_classifier, self.sequence_detector]
         side = _SideWork(dev)               # weight-gradient kernels of the whole backward; joined once, at the end
         if models[0].model_type == "bilstm":
-            dseq_c, dseq_d = _lstm_backward(models, s.lstm, [dyc.view(B, T, D), dyd.view(B, T, D)], g, side)
+            dseq_c, dseq_d = _lstm_backward(models, s.lstm, [dyc.view(B, T, D), dyd.view(B, T, D)], g, side,
+                                            self.weight_amax)
             if LSTM_WGRAD_JOIN_EARLY:
                 side.join()
         else:
@@ -889,7 +919,8 @@ class JDCNet(nn.Module):
         wdet = self.detector_conv[0].weight
         side.run(lambda: ops.gemm_tn(_flat2(d_dconv), s.concat.view(-1, 640), out=g[wdet].view(256, 640)), d_dconv,
                  on=OVERLAP_CONV_WGRAD)
-        d_concat = ops.gemm_nt(_flat2(d_dconv), ops.transpose2d(wdet.view(256, 640))).view(B, T, 2, 640)
+        d_concat = ops.gemm_nt(_flat2(d_dconv), ops.transpose2d(wdet.view(256, 640)), amax_b=self.weight_amax(wdet))
+        d_concat = d_concat.view(B, T, 2, 640)
         # classifier branch joins at the pool_block output (channels 384..639 of the concat)
         ops.seq_to_nhwc(dseq_c, d_concat, 256, coff=384, accumulate=True)
         d_pool = torch.empty((B, T, 2, 256), dtype=torch.float32, device=dev)
@@ -907,13 +938,14 @@ class JDCNet(nn.Module):
 
         # each block-input gradient leaves its absmax word behind; the detector tap's max-pool gradient, added in place
         # afterwards, merges the values it rewrote into the same word
-        d_rb2, am2 = _res_backward(self.res_block3, s.r3, d_rb3, 2, slope, g, side, am3)
+        wa = self.weight_amax
+        d_rb2, am2 = _res_backward(self.res_block3, s.r3, d_rb3, 2, slope, g, side, am3, wa)
         block_done(3)                       # res_block3 + pool_block + detector_conv
         ops.maxpool_bwd_add(s.rb2, d_concat, d_rb2, 10, coff=192, amax_out=am2)
-        d_rb1, am1 = _res_backward(self.res_block2, s.r2, d_rb2, 2, slope, g, side, am2)
+        d_rb1, am1 = _res_backward(self.res_block2, s.r2, d_rb2, 2, slope, g, side, am2, wa)
         block_done(2)
         ops.maxpool_bwd_add(s.rb1, d_concat, d_rb1, 20, coff=64, amax_out=am1)
-        d_cb, am_dcb = _res_backward(self.res_block1, s.r1, d_rb1, 2, slope, g, side, am1)
+        d_cb, am_dcb = _res_backward(self.res_block1, s.r1, d_rb1, 2, slope, g, side, am1, wa)
         block_done(1)
         ops.maxpool_bwd_add(s.cb, d_concat, d_cb, 40, coff=0, amax_out=am_dcb)
 

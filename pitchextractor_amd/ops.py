@@ -144,6 +144,19 @@ def _unit_amax(device):
     return _UNIT_AMAX[key]
 
 
+def absmax_segments(flat, seg_off, seg_len, out=None):
+    """out[s] = absmax word of flat[seg_off[s] : seg_off[s] + seg_len[s]] (int64 device tensors), one launch."""
+    _dense(flat, "flat")
+    n = seg_off.numel()
+    _chk(seg_off.is_cuda and seg_len.is_cuda and seg_off.dtype == seg_len.dtype == torch.int64 and seg_len.numel() == n,
+         "absmax_segments: int64 device offset / length arrays")
+    if out is None:
+        out = torch.empty((n,), dtype=torch.int32, device=flat.device)
+    _chk(out.is_cuda and out.dtype == torch.int32 and out.numel() == n, "absmax_segments: out")
+    _call("pe_absmax_segments", flat.data_ptr(), seg_off.data_ptr(), seg_len.data_ptr(), n, out.data_ptr(), _s())
+    return out
+
+
 def h2_active() -> bool:
     """True when fp32 products run as two scaled fp16 terms, i.e. when GEMM / conv operands need an absmax word."""
     return (not MATMUL_BF16) and FP32_MATMUL == "h2"
@@ -368,8 +381,9 @@ def _mode_terms():
     return 3 if sfx == "_x3" else 2 if sfx == "_h2" else 1 if sfx in ("_bf16", "_f16") else 0
 
 
-def conv3x3_repack(w, want_fwd=True, want_dgrad=True):
-    """OIHW (Cout,Cin,3,3) -> (w_fwd [Cout, 9*Cin], w_dgrad [Cin, 9*Cout]) as ``PackedWeight``s."""
+def conv3x3_repack(w, want_fwd=True, want_dgrad=True, amax=None):
+    """OIHW (Cout,Cin,3,3) -> (w_fwd [Cout, 9*Cin], w_dgrad [Cin, 9*Cout]) as ``PackedWeight``s.  ``amax``: the
+    weight's absmax word when the caller has it ("h2" mode)."""
     w = _dense(w, "w")
     _chk(w.dim() == 4 and w.shape[2:] == (3, 3), "conv3x3_repack: OIHW 3x3")
     co, ci = w.shape[0], w.shape[1]
@@ -377,7 +391,10 @@ def conv3x3_repack(w, want_fwd=True, want_dgrad=True):
     wd = torch.empty((ci, 9 * co), dtype=torch.float32, device=w.device) if want_dgrad else None
     _call("pe_conv3x3_repack", w.data_ptr(), _lib.ptr(wf), _lib.ptr(wd), co, ci, _s())
     terms = _mode_terms() if CONV_WFRAG else 0
-    amax = absmax(w.view(co, ci * 9)) if _mode_terms() == 2 else None   # forward and data-gradient forms share it
+    if _mode_terms() != 2:
+        amax = None
+    elif amax is None:
+        amax = absmax(w.view(co, ci * 9))                               # forward and data-gradient forms share it
     out = []
     for t in (wf, wd):
         if t is None:

@@ -38,7 +38,7 @@ def test_single_gpu_line_has_the_contract_fields(hip_device):
     assert mel["bound"] == "hbm" and mel["peak"] == 8000.0 and 0 < mel["frac"] < 1
     cpu = d["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and "sample" in cpu
-    assert d["from_host"]["ms_per_step"] > 0 and d["kernel_families"]["rows"] and d["fp32_native_mfma"]["ms_per_step"] > 0
+    assert d["from_host"]["ms_per_step"] > 0 and d["kernel_families"]["rows"] and d["fp32_native_mfma"]["ms_per_step"] > 0 and roof["whole_step"]["frac"] > 0 and "traffic_source" in roof
 
 
 def test_two_rank_launch_over_gloo(hip_device):

@@ -2,7 +2,7 @@
 set -o pipefail
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_r02
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_r03
 rm -rf $OUT; mkdir -p $OUT
 ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-native-ref --family-steps 0 --host-steps 0"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/trace.log 2>&1 || echo trace-rc=$?
