@@ -262,11 +262,13 @@ int pe_bn_act_pool_bwd(const float* x, const float* dy, const float* scale, cons
                        const float* mean, const float* invstd, float slope, float* dx, float* dgamma,
                        float* dbeta, long rows, int Fin, int C, int pool, long lddy, int coff,
                        void* workspace, size_t workspace_bytes, unsigned* amax_out, void* stream);
-/* detector-branch MaxPool2d((1,40|20|10)) (model.py:45-49,103-105) into a channel slice */
+/* detector-branch MaxPool2d((1,40|20|10)) (model.py:45-49,103-105) into a channel slice.  argmax_out (optional,
+ * [rows * (Fin / pool)][C] bytes): the window position of each maximum (the first one, as torch's backward routes it);
+ * pe_maxpool_bwd_add given that array as `argmax` scatters dy without reading x (x may then be NULL). */
 int pe_maxpool_fwd(const float* x, float* y, long rows, int Fin, int C, int pool, long ldy, int coff,
-                   void* stream);
-int pe_maxpool_bwd_add(const float* x, const float* dy, float* dx, long rows, int Fin, int C, int pool,
-                       long lddy, int coff, unsigned* amax_out, void* stream);
+                   unsigned char* argmax_out, void* stream);
+int pe_maxpool_bwd_add(const float* x, const unsigned char* argmax, const float* dy, float* dx, long rows, int Fin,
+                       int C, int pool, long lddy, int coff, unsigned* amax_out, void* stream);
 /* nn.Dropout (model.py:40,56; LSTM inter-layer): Philox4x32-10 keyed by (seed, offset + quad index);
  * mask bytes (1 = kept) can be exported (mask_out) or replayed (mask_in). */
 int pe_dropout_fwd(const float* x, long ldx, float* y, long ldy, const unsigned char* mask_in,

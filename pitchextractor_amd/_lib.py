@@ -83,8 +83,8 @@ PROTOTYPES = {
     "pe_bn_eval_affine": (_i, [_p, _p, _p, _p, _f, _i, _p, _p, _p]),
     "pe_bn_act_pool_fwd": (_i, [_p, _p, _p, _f, _p, _l, _i, _i, _i, _l, _i, _p, _p]),
     "pe_bn_act_pool_bwd": (_i, [_p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _l, _i, _i, _i, _l, _i, _p, _z, _p, _p]),
-    "pe_maxpool_fwd": (_i, [_p, _p, _l, _i, _i, _i, _l, _i, _p]),
-    "pe_maxpool_bwd_add": (_i, [_p, _p, _p, _l, _i, _i, _i, _l, _i, _p, _p]),
+    "pe_maxpool_fwd": (_i, [_p, _p, _l, _i, _i, _i, _l, _i, _p, _p]),
+    "pe_maxpool_bwd_add": (_i, [_p, _p, _p, _p, _l, _i, _i, _i, _l, _i, _p, _p]),
     "pe_dropout_fwd": (_i, [_p, _l, _p, _l, _p, _p, _l, _i, _f, _u64, _u64, _p]),
     "pe_nhwc_to_seq": (_i, [_p, _l, _i, _p, _l, _i, _p]),
     "pe_seq_to_nhwc": (_i, [_p, _p, _l, _i, _l, _i, _i, _p]),

@@ -378,7 +378,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_win_kernel(const BnBwdArgs a
 // ---------------------------------------------------------------- plain MaxPool(1,k) (detector taps)
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                           long n_out_pix, int Fin, int C, int pool, long ldy,
-                                                          int coff) {
+                                                          int coff, unsigned char* __restrict__ arg) {
+  // arg (optional, [n_out_pix][C] bytes): the window position of each maximum (first one wins, as torch's
+  // max_pool2d backward routes it), so that the backward pass does not have to read x again
   const int quads = C >> 2, Fout = Fin / pool;
   const long total = n_out_pix * quads;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -387,6 +389,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
     const int fo = (int)(op % Fout);
     const float* xp = x + ((row * Fin + (long)fo * pool) * C + q * 4);
     float4 m = *reinterpret_cast<const float4*>(xp);
+    int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     int j = 1;
     for (; j + 4 <= pool; j += 4) {                               // four window rows in flight
       float4 v[4];
@@ -394,14 +397,23 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
       for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(xp + (long)(j + u) * C);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        m.x = fmaxf(m.x, v[u].x); m.y = fmaxf(m.y, v[u].y); m.z = fmaxf(m.z, v[u].z); m.w = fmaxf(m.w, v[u].w);
+        if (v[u].x > m.x) { m.x = v[u].x; a0 = j + u; }
+        if (v[u].y > m.y) { m.y = v[u].y; a1 = j + u; }
+        if (v[u].z > m.z) { m.z = v[u].z; a2 = j + u; }
+        if (v[u].w > m.w) { m.w = v[u].w; a3 = j + u; }
       }
     }
     for (; j < pool; ++j) {
       const float4 v = *reinterpret_cast<const float4*>(xp + (long)j * C);
-      m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+      if (v.x > m.x) { m.x = v.x; a0 = j; }
+      if (v.y > m.y) { m.y = v.y; a1 = j; }
+      if (v.z > m.z) { m.z = v.z; a2 = j; }
+      if (v.w > m.w) { m.w = v.w; a3 = j; }
     }
     *reinterpret_cast<float4*>(y + op * ldy + coff + q * 4) = m;
+    if (arg != nullptr)
+      *reinterpret_cast<uchar4*>(arg + op * C + q * 4) = make_uchar4((unsigned char)a0, (unsigned char)a1,
+                                                                     (unsigned char)a2, (unsigned char)a3);
   }
 }
 
@@ -409,8 +421,10 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
 __global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const float* __restrict__ x,
                                                               const float* __restrict__ dy, float* __restrict__ dx,
                                                               long n_out_pix, int Fin, int C, int pool, long lddy,
-                                                              int coff, unsigned* __restrict__ amax) {
-  // one thread per (window, channel quad): float4 loads, four window rows in flight, first maximum wins
+                                                              int coff, unsigned* __restrict__ amax,
+                                                              const unsigned char* __restrict__ arg) {
+  // one thread per (window, channel quad): float4 loads, four window rows in flight, first maximum wins; with `arg`
+  // (the positions maxpool_fwd_kernel recorded) x is not read at all
   const int Fout = Fin / pool, quads = C >> 2;
   const long total = n_out_pix * quads;
   float am = 0.f;
@@ -419,9 +433,13 @@ __global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const float* __res
     const int c = (int)(i - op * quads) * 4;
     const long row = op / Fout;
     const int fo = (int)(op - row * Fout);
+    int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    if (arg != nullptr) {
+      const uchar4 a = *reinterpret_cast<const uchar4*>(arg + op * C + c);
+      a0 = a.x; a1 = a.y; a2 = a.z; a3 = a.w;
+    } else {
     const float* xp = x + (row * Fin + (long)fo * pool) * C + c;
     float4 best = *reinterpret_cast<const float4*>(xp);
-    int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     int jn = 1;
     for (; jn + 4 <= pool; jn += 4) {
       float4 v[4];
@@ -441,6 +459,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const float* __res
       if (v.y > best.y) { best.y = v.y; a1 = jn; }
       if (v.z > best.z) { best.z = v.z; a2 = jn; }
       if (v.w > best.w) { best.w = v.w; a3 = jn; }
+    }
     }
     const float4 g = *reinterpret_cast<const float4*>(dy + op * lddy + coff + c);
     float* dp = dx + (row * Fin + (long)fo * pool) * C + c;
@@ -717,23 +736,23 @@ extern "C" int pe_bn_act_pool_bwd(const float* x, const float* dy, const float* 
 }
 
 extern "C" int pe_maxpool_fwd(const float* x, float* y, long rows, int Fin, int C, int pool, long ldy, int coff,
-                              void* stream) {
+                              unsigned char* argmax_out, void* stream) {
   if (!x || !y || rows <= 0 || Fin <= 0 || pool <= 0) return PE_E_ARG;
-  if ((C & 3) || (ldy & 3) || (coff & 3)) return PE_E_UNSUPPORTED;
+  if ((C & 3) || (ldy & 3) || (coff & 3) || (argmax_out && pool > 255)) return PE_E_UNSUPPORTED;
   const long n_out = rows * (Fin / pool);
   hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(n_out * (C / 4))), dim3(256), 0, pe_stream(stream), x, y, n_out,
-                     Fin, C, pool, ldy, coff);
+                     Fin, C, pool, ldy, coff, argmax_out);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }
 
-extern "C" int pe_maxpool_bwd_add(const float* x, const float* dy, float* dx, long rows, int Fin, int C, int pool,
-                                  long lddy, int coff, unsigned* amax_out, void* stream) {
-  if (!x || !dy || !dx || rows <= 0 || Fin <= 0 || pool <= 0 || C <= 0) return PE_E_ARG;
+extern "C" int pe_maxpool_bwd_add(const float* x, const unsigned char* argmax, const float* dy, float* dx, long rows,
+                                  int Fin, int C, int pool, long lddy, int coff, unsigned* amax_out, void* stream) {
+  if ((!x && !argmax) || !dy || !dx || rows <= 0 || Fin <= 0 || pool <= 0 || C <= 0) return PE_E_ARG;
   if ((C & 3) || (lddy & 3) || (coff & 3)) return PE_E_UNSUPPORTED;
   const long n_out = rows * (Fin / pool);
   hipLaunchKernelGGL(maxpool_bwd_add_kernel, dim3(ew_grid(n_out * (C / 4))), dim3(256), 0, pe_stream(stream), x, dy,
-                     dx, n_out, Fin, C, pool, lddy, coff, amax_out);
+                     dx, n_out, Fin, C, pool, lddy, coff, amax_out, argmax);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }

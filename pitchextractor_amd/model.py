@@ -843,9 +843,10 @@ class JDCNet(nn.Module):
         _, s.mask_pool = _dropout(self.dropout_cfg, _flat2(pooled), p_blk, out2d=cslice)
         seq_c = ops.nhwc_to_seq(s.concat, 256, coff=384)
 
-        ops.maxpool_fwd(s.cb, 40, out=s.concat, coff=0)
-        ops.maxpool_fwd(s.rb1, 20, out=s.concat, coff=64)
-        ops.maxpool_fwd(s.rb2, 10, out=s.concat, coff=192)
+        # (the positions of the maxima are kept: 25 MB of bytes save the backward pass three 1 GB reads)
+        _, s.arg_cb = ops.maxpool_fwd(s.cb, 40, out=s.concat, coff=0, want_argmax=True)
+        _, s.arg_rb1 = ops.maxpool_fwd(s.rb1, 20, out=s.concat, coff=64, want_argmax=True)
+        _, s.arg_rb2 = ops.maxpool_fwd(s.rb2, 10, out=s.concat, coff=192, want_argmax=True)
         wdet = self.detector_conv[0].weight.view(256, 640)
         s.dconv = ops.gemm_nt(s.concat.view(-1, 640), wdet, amax_b=self.weight_amax(self.detector_conv[0].weight))
         s.dconv = s.dconv.view(B, T, 2, 256)
@@ -941,13 +942,13 @@ class JDCNet(nn.Module):
         wa = self.weight_amax
         d_rb2, am2 = _res_backward(self.res_block3, s.r3, d_rb3, 2, slope, g, side, am3, wa)
         block_done(3)                       # res_block3 + pool_block + detector_conv
-        ops.maxpool_bwd_add(s.rb2, d_concat, d_rb2, 10, coff=192, amax_out=am2)
+        ops.maxpool_bwd_add(s.rb2, d_concat, d_rb2, 10, coff=192, amax_out=am2, argmax=s.arg_rb2)
         d_rb1, am1 = _res_backward(self.res_block2, s.r2, d_rb2, 2, slope, g, side, am2, wa)
         block_done(2)
-        ops.maxpool_bwd_add(s.rb1, d_concat, d_rb1, 20, coff=64, amax_out=am1)
+        ops.maxpool_bwd_add(s.rb1, d_concat, d_rb1, 20, coff=64, amax_out=am1, argmax=s.arg_rb1)
         d_cb, am_dcb = _res_backward(self.res_block1, s.r1, d_rb1, 2, slope, g, side, am1, wa)
         block_done(1)
-        ops.maxpool_bwd_add(s.cb, d_concat, d_cb, 40, coff=0, amax_out=am_dcb)
+        ops.maxpool_bwd_add(s.cb, d_concat, d_cb, 40, coff=0, amax_out=am_dcb, argmax=s.arg_cb)
 
         cbk = self.conv_block
         side.run(lambda: ops.conv3x3_wgrad(s.a0, d_cb, g[cbk[3].weight], amax_x=s.am_a0, amax_dy=am_dcb), d_cb, am_dcb,

@@ -581,24 +581,32 @@ def bn_act_pool_bwd(x, dy, st: BnState, dgamma, dbeta, pool=1, slope=0.01, coff=
     return dx
 
 
-def maxpool_fwd(x, pool, out=None, coff=0):
+def maxpool_fwd(x, pool, out=None, coff=0, want_argmax=False):
+    """MaxPool2d((1, pool)) into a channel slice.  ``want_argmax``: also return the uint8 window positions of the
+    maxima ([B, T, F // pool, C]) for ``maxpool_bwd_add(argmax=...)``: returns (out, argmax)."""
     x = _dense(x, "x")
     B, T, F, Cc = x.shape
     Fo = F // pool
     if out is None:
         out = torch.empty((B, T, Fo, Cc), dtype=torch.float32, device=x.device)
     ld = _slice_target(out, B, T, Fo, Cc, coff)
-    _call("pe_maxpool_fwd", x.data_ptr(), out.data_ptr(), B * T, F, Cc, pool, ld, coff, _s())
-    return out
+    arg = torch.empty((B, T, Fo, Cc), dtype=torch.uint8, device=x.device) if want_argmax else None
+    _call("pe_maxpool_fwd", x.data_ptr(), out.data_ptr(), B * T, F, Cc, pool, ld, coff, _lib.ptr(arg), _s())
+    return (out, arg) if want_argmax else out
 
 
-def maxpool_bwd_add(x, dy, dx, pool, coff=0, amax_out=None):
-    x = _dense(x, "x")
+def maxpool_bwd_add(x, dy, dx, pool, coff=0, amax_out=None, argmax=None):
+    """dx[first maximum of each window] += dy.  With ``argmax`` (from ``maxpool_fwd``) x is only used for its shape."""
     B, T, F, Cc = x.shape
+    if argmax is None:
+        x = _dense(x, "x")
+    else:
+        _chk(argmax.is_cuda and argmax.dtype == torch.uint8 and argmax.is_contiguous()
+             and argmax.shape == (B, T, F // pool, Cc), "maxpool_bwd_add: argmax shape")
     ld = _slice_target(dy, B, T, F // pool, Cc, coff)
     _chk(_dense(dx, "dx").shape == x.shape, "dx shape")
-    _call("pe_maxpool_bwd_add", x.data_ptr(), dy.data_ptr(), dx.data_ptr(), B * T, F, Cc, pool, ld, coff,
-          _lib.ptr(amax_out), _s())
+    _call("pe_maxpool_bwd_add", x.data_ptr() if argmax is None else 0, _lib.ptr(argmax), dy.data_ptr(), dx.data_ptr(),
+          B * T, F, Cc, pool, ld, coff, _lib.ptr(amax_out), _s())
     return dx
 
 

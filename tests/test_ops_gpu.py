@@ -405,6 +405,13 @@ def test_maxpool_taps(hip_device, C, Fq, pool, coff):
     dx = base.clone()
     ops.maxpool_bwd_add(xd, dwide, dx, pool, coff=coff)
     close(nchw(dx - base), x.grad, 1e-6)
+    # the same gradient from the recorded positions of the maxima, without reading x
+    wide2 = torch.zeros(B, T, 2, 640, device=hip_device)
+    _, arg = ops.maxpool_fwd(xd, pool, out=wide2, coff=coff, want_argmax=True)
+    assert torch.equal(wide2, wide) and arg.dtype == torch.uint8 and int(arg.max()) < pool
+    dx2 = base.clone()
+    ops.maxpool_bwd_add(xd, dwide, dx2, pool, coff=coff, argmax=arg)
+    assert torch.equal(dx2, dx)
 
 
 @pytest.mark.parametrize("pool", [1, 2, 4])
