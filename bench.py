@@ -194,6 +194,9 @@ def main():
                     help="fp32 products on v_mfma_f32_32x32x2_f32 (native), as an exact three-term bf16 split (x3: six "
                          "bf16 MFMAs per block) or as two scaled fp16 terms (h2: three fp16 MFMAs per block); "
                          "default: PE_FP32_MATMUL or the library default (h2)")
+    ap.add_argument("--act-storage", choices=["fp32", "bf16"], default=None,
+                    help="--precision bf16 only: HBM format of the conv stack's activations and their gradients "
+                         "(default bf16 = what the reference's autocast keeps in memory; fp32 = operands rounded only)")
     ap.add_argument("--no-native-ref", action="store_true",
                     help="skip the 7 extra steps that time the native fp32 MFMA form for the fp32_native_mfma field")
     ap.add_argument("--family-timing", action="store_true",
@@ -245,7 +248,7 @@ def main():
     log = logging.getLogger("bench")
     tr = Trainer(model=net, criterion=crit, optimizer=opt, scheduler=sched, device=str(dev),
                  loss_config={"lambda_f0": 0.1}, logger=log, mel_transform=MelSpectrogram(**DEFAULT_MEL_PARAMS),
-                 data_parallel=dp, use_mixed_precision=bf16)
+                 data_parallel=dp, use_mixed_precision=bf16, activation_storage=args.act_storage if bf16 else None)
 
     # this rank's shard of the global minibatch: 32 distinct synthetic utterances tiled to the batch
     lo, _ = pdist.shard_range(args.batch * world, rank, world)
@@ -268,6 +271,7 @@ def main():
             print(f"[bench] warmup {i}: {time.perf_counter() - t_w:.3f} s loss {last['loss']:.4f}", file=sys.stderr,
                   flush=True)
     barrier()
+    torch.cuda.reset_peak_memory_stats(dev)
     x3 = ops.FP32_MATMUL in ("x3", "h2")        # fp32 results from split 16-bit terms on the bf16 / fp16 MFMA pipe
     h2 = ops.FP32_MATMUL == "h2"
     fp32_mode = ops.FP32_MATMUL
@@ -281,6 +285,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     timer, ops.TIMER = ops.TIMER, None
+    peak_mem = int(torch.cuda.max_memory_allocated(dev))
     if rank == 0:
         print(f"[bench] timed {args.steps} steps: {elapsed / args.steps * 1e3:.1f} ms/step", file=sys.stderr,
               flush=True)
@@ -432,12 +437,15 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
             "config": {"workload": (("BASELINE config[2]: batch" if args.head == "transformer" else "BASELINE config[3] per-GPU shape: batch") if bf16 else "BASELINE config[1]: batch") + "=256/GPU, 24 kHz 2 s synthetic glides "
-                                   f"({real_frames} real frames zero-padded to 192), JDCNet+{'BiLSTM(4x384)' if args.head == 'bilstm' else 'Transformer(4 layers, 8 heads, ff 1536)'}, " + ("mixed precision (bf16 conv/linear operands, fp32 accumulate), " if bf16 else f"fp32 (products: {ops.FP32_MATMUL}), ") +
+                                   f"({real_frames} real frames zero-padded to 192), JDCNet+{'BiLSTM(4x384)' if args.head == 'bilstm' else 'Transformer(4 layers, 8 heads, ff 1536)'}, " + ("mixed precision (bf16 conv/linear operands, fp32 accumulate, " + ("bf16" if tr.act16 else "fp32") + " activation storage), " if bf16 else f"fp32 (products: {ops.FP32_MATMUL}), ") +
                                    "raw audio resident in HBM -> mel -> fwd -> loss -> bwd -> AdamW",
                        "global_batch": args.batch * world, "frames_per_utterance": FRAMES,
                        "real_frames_per_utterance": real_frames, "parallelism": f"dp{world}"},
             "loss": last["loss"], "roofline": roof, "roofline_mel": roof_mel,
+            "peak_memory_bytes": peak_mem,              # torch.cuda.max_memory_allocated over the timed steps, rank 0
         }
+        if bf16:
+            line["config"]["activation_storage"] = "bf16" if tr.act16 else "fp32"
         if dp is not None:
             line["config"]["gradient_allreduce"] = {
                 "backend": dist.get_backend(), "payload": dp.payload, "bucket_bytes": dp.bucket_elems * (2 if dp.payload == "bf16" else 4),

@@ -377,6 +377,49 @@ int pe_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_av
 /* GradScaler support (reference trainer.py:241-244): *flag = 1 if any of x[0..n) is inf or nan, else 0. */
 int pe_nonfinite_flag(const float* x, long n, int* flag, void* stream);
 
+/* ---- bf16 ACTIVATION STORAGE for mixed precision (`*_a16`) ------------------------------------------------------
+ * The reference's autocast keeps conv / linear outputs and what backward saves of them in 16 bits (trainer.py:226-235,
+ * README.md:36).  These entry points are the fp32-tensor functions of the same name with the conv stack's activation
+ * and activation-gradient tensors (x, y, dy, dx, the GEMM operand A and result C) stored as bf16 in HBM: half the bytes
+ * of every BatchNorm / pooling / staging pass and of the saved-for-backward footprint.  Arithmetic, BatchNorm
+ * statistics, weights, weight gradients and biases stay fp32; a store rounds to nearest even.  Statistics a kernel
+ * leaves behind (bn_partials) are those of the ROUNDED values, i.e. of the tensor BatchNorm then reads.  Layouts,
+ * strides (in elements) and argument meaning are unchanged; activation pointers need 8-byte alignment. */
+int pe_conv3x3_c1_fwd_a16(const float* x, long sb, long st, long sf, const float* w_oihw, void* y, int B, int T, int F,
+                          double* bn_partials, void* stream);
+int pe_conv3x3_c1_wgrad_a16(const float* x, long sb, long st, long sf, const void* dy, float* dw_oihw, int B, int T,
+                            int F, float* workspace, size_t workspace_bytes, void* stream);
+int pe_conv3x3_fwd_bf16_a16(const void* x, const float* w_packed, void* y, int B, int T, int F, int C, int N,
+                            int accumulate, void* stream);
+int pe_conv3x3_fwd_wf_bf16_a16(const void* x, const void* wfrag, void* y, int B, int T, int F, int C, int N,
+                               int accumulate, double* bn_partials, void* stream);
+int pe_conv3x3_wgrad_bf16_a16(const void* x, const void* dy, float* dw_oihw, int B, int T, int F, int Cin, int Cout,
+                              float* workspace, size_t workspace_bytes, void* stream);
+int pe_gemm_nt_bf16_a16(const void* A, long lda, const float* B, long ldb, void* C, long ldc, int M, int N, int K,
+                        const float* bias0, const float* bias1, int accumulate, void* stream);
+int pe_gemm_tn_bf16_a16(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,
+                        int accumulate, float* workspace, size_t workspace_bytes, void* stream);
+int pe_bn_train_stats_a16(const void* x, long n_pix, int C, const float* gamma, const float* beta, float eps,
+                          float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
+                          float* scale, float* shift, void* workspace, size_t workspace_bytes, void* stream);
+int pe_bn_act_pool_fwd_a16(const void* x, const float* scale, const float* shift, float slope, void* y, long rows,
+                           int Fin, int C, int pool, long ldy, int coff, void* stream);
+int pe_bn_act_pool_bwd_a16(const void* x, const void* dy, const float* scale, const float* shift, const float* mean,
+                           const float* invstd, float slope, void* dx, float* dgamma, float* dbeta, long rows, int Fin,
+                           int C, int pool, long lddy, int coff, void* workspace, size_t workspace_bytes,
+                           void* stream);          /* pool in {1, 2, 4} */
+int pe_maxpool_fwd_a16(const void* x, void* y, long rows, int Fin, int C, int pool, long ldy, int coff,
+                       unsigned char* argmax_out, void* stream);
+int pe_maxpool_bwd_add_a16(const void* x, const unsigned char* argmax, const void* dy, void* dx, long rows, int Fin,
+                           int C, int pool, long lddy, int coff, void* stream);
+int pe_dropout_fwd_a16(const void* x, long ldx, void* y, long ldy, const unsigned char* mask_in,
+                       unsigned char* mask_out, long rows, int cols, float p, unsigned long long seed,
+                       unsigned long long offset, void* stream);
+int pe_nhwc_to_seq_a16(const void* x, long ldx, int coff, float* seq, long rows, int C, void* stream);   /* bf16 -> fp32 */
+int pe_seq_to_nhwc_a16(const float* seq, void* x, long ldx, int coff, long rows, int C, int accumulate,
+                       void* stream);                                                                    /* fp32 -> bf16 */
+int pe_copy2d_a16(const void* src, long lds, void* dst, long ldd, long rows, int cols, int accumulate, void* stream);
+
 /* ---- Transformer temporal head (model.py:178-193,229-241,253-255) ---------------------------
  * pe_bgemm: batched 64x64-tiled fp32 MFMA GEMM over `batch` matrices; matrix b of operand X lives
  *   at X + (b / inner) * x_outer + (b % inner) * x_inner (e.g. batch item / head inside the packed

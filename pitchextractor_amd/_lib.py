@@ -141,6 +141,22 @@ PROTOTYPES = {
     "pe_lstm_bwd_persistent_f16": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _pp, _pp, _p, _p]),
     "pe_lstm_whh_grad_f16": (_i, [_p, _p, _l, _p, _i, _i, _i, _i, _p, _z, _p]),
     "pe_wfrag_pack_f16": (_i, [_p, _l, _i, _i, _p, _p]),
+    "pe_conv3x3_c1_fwd_a16": (_i, [_p, _l, _l, _l, _p, _p, _i, _i, _i, _p, _p]),
+    "pe_conv3x3_c1_wgrad_a16": (_i, [_p, _l, _l, _l, _p, _p, _i, _i, _i, _p, _z, _p]),
+    "pe_conv3x3_fwd_bf16_a16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "pe_conv3x3_fwd_wf_bf16_a16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "pe_conv3x3_wgrad_bf16_a16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "pe_gemm_nt_bf16_a16": (_i, [_p, _l, _p, _l, _p, _l, _i, _i, _i, _p, _p, _i, _p]),
+    "pe_gemm_tn_bf16_a16": (_i, [_p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _p, _z, _p]),
+    "pe_bn_train_stats_a16": (_i, [_p, _l, _i, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "pe_bn_act_pool_fwd_a16": (_i, [_p, _p, _p, _f, _p, _l, _i, _i, _i, _l, _i, _p]),
+    "pe_bn_act_pool_bwd_a16": (_i, [_p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _l, _i, _i, _i, _l, _i, _p, _z, _p]),
+    "pe_maxpool_fwd_a16": (_i, [_p, _p, _l, _i, _i, _i, _l, _i, _p, _p]),
+    "pe_maxpool_bwd_add_a16": (_i, [_p, _p, _p, _p, _l, _i, _i, _i, _l, _i, _p]),
+    "pe_dropout_fwd_a16": (_i, [_p, _l, _p, _l, _p, _p, _l, _i, _f, _u64, _u64, _p]),
+    "pe_nhwc_to_seq_a16": (_i, [_p, _l, _i, _p, _l, _i, _p]),
+    "pe_seq_to_nhwc_a16": (_i, [_p, _p, _l, _i, _l, _i, _i, _p]),
+    "pe_copy2d_a16": (_i, [_p, _l, _p, _l, _l, _i, _i, _p]),
     "pe_nonfinite_flag": (_i, [_p, _l, _p, _p]),
     "pe_adamw_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _d, _d, _f, _p, _p]),
 }

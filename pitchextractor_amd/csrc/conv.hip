@@ -7,6 +7,7 @@
 //   weight gradient:          dW[n][tap][c] = sum_p dY[p][n] * X[p + tap][c]         (TN engine,
 //       pixels split across workgroups, per-split slabs reduced in a fixed order -> deterministic);
 //   first layer (Cin = 1, model.py:24): 9 FMAs per output, HBM-bound on the 64-channel write.
+#include <type_traits>
 #include "gemm_engine.h"
 
 namespace {
@@ -38,21 +39,30 @@ __global__ void transpose2d_kernel(const float* __restrict__ in, float* __restri
 }
 
 // ---------------------------------------------------------------- forward / dgrad
-struct ConvEpi {
-  float* Y;
+template <class TO>
+struct ConvEpiT {
+  TO* Y;
   int rows, N, accumulate;
   double* stats;          // optional [tiles_m][2][N]: per-tile column sums / sums of squares of the final outputs
   __device__ __forceinline__ void operator()(int row, int col, float v) const {
     if (row < rows && col < N) {
-      float* d = Y + (long)row * N + col;
-      if (accumulate) v += *d;
-      *d = v;
+      TO* d = Y + (long)row * N + col;
+      if (accumulate) v += ld1(d);
+      st1(d, v);
     }
   }
 };
+typedef ConvEpiT<float> ConvEpi;
 
-template <class TL, int MODE>
-__global__ __launch_bounds__(256) void conv3x3_kernel(ConvLoader<TL::A_LOADS> al, RowLoader bl, ConvEpi ep,
+// the value a TO tensor holds after storing v (bf16: round to nearest even), so that BatchNorm statistics taken in
+// the epilogue describe the stored tensor
+template <class TO> __device__ __forceinline__ float stored_value(float v) {
+  if constexpr (std::is_same<TO, float>::value) return v;
+  else return __uint_as_float(pack_bf16_rne(v, 0.f) << 16);
+}
+
+template <class TL, int MODE, class TA = float>
+__global__ __launch_bounds__(256) void conv3x3_kernel(ConvLoader<TL::A_LOADS, TA> al, RowLoader bl, ConvEpiT<TA> ep,
                                                       int K, int tiles_m, int tiles_n, const unsigned* amax_x,
                                                       const unsigned* amax_w) {
   __shared__ __attribute__((aligned(16))) float As[TL::BM * nt_row_floats<MODE>()];
@@ -69,16 +79,16 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvLoader<TL::A_LOADS> al
   for_each_acc<TL>(acc, [&](int r, int c, float v) { ep(m0 + r, n0 + c, MODE == kSplit2 ? v * hs.inv : v); });
 }
 
-template <class TL, int MODE>
-int launch_conv(const float* x, const float* wp, float* y, int B, int T, int F, int C, int N, int accumulate,
+template <class TL, int MODE, class TA = float>
+int launch_conv(const TA* x, const float* wp, TA* y, int B, int T, int F, int C, int N, int accumulate,
                 hipStream_t st, const unsigned* amax_x = nullptr, const unsigned* amax_w = nullptr) {
   const int rows = B * T * F, K = 9 * C;
-  ConvLoader<TL::A_LOADS> al;
+  ConvLoader<TL::A_LOADS, TA> al;
   al.p = x; al.T = T; al.F = F; al.C = C; al.rows = rows;
   RowLoader bl{wp, (long)K, N, K, 0};
-  ConvEpi ep{y, rows, N, accumulate, nullptr};
+  ConvEpiT<TA> ep{y, rows, N, accumulate, nullptr};
   const int tm = pe_cdiv(rows, TL::BM), tn = pe_cdiv(N, TL::BN);
-  hipLaunchKernelGGL((conv3x3_kernel<TL, MODE>), dim3(tm * tn), dim3(256), 0, st, al, bl, ep, K, tm, tn, amax_x,
+  hipLaunchKernelGGL((conv3x3_kernel<TL, MODE, TA>), dim3(tm * tn), dim3(256), 0, st, al, bl, ep, K, tm, tn, amax_x,
                      amax_w);
   PE_LAUNCH_CHECK();
   return PE_OK;
@@ -99,194 +109,9 @@ int launch_conv(const float* x, const float* wp, float* y, int B, int T, int F, 
 // operand for the exact three-term split, 1 for mixed precision.
 // PASSES = staged window rows / 32: 7 (F <= 47) for the wide tiles, 10 (F <= 95) for the 64-channel layers.
 
-template <int BN, int MODE, int PASSES>
-__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const float* __restrict__ x,
-                                                              const float* __restrict__ wp, ConvEpi ep, int T, int F,
-                                                              int C, int N, int P, int tiles_m, int tiles_n) {
-  constexpr int NT = MODE == kSplit ? 3 : 1;
-  constexpr int TM = 2, TN = BN / 64, WN = BN / 2;
-  constexpr int ZR = PASSES * 32;                                  // an all-zero row behind the window
-  constexpr int AIMG = (ZR + 4) * 32, BIMG = BN * 32;              // bf16 elements per image
-  constexpr int BL = BN / 32;                                      // weight float4 per thread per stage
-  __shared__ __attribute__((aligned(16))) __bf16 As[NT * AIMG];
-  __shared__ __attribute__((aligned(16))) __bf16 Bs[NT * BIMG];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int wm = wv >> 1, wn = wv & 1, r = lane & 31, h = lane >> 5;
-  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int p0 = (tile / tiles_n) * 128, n0 = (tile % tiles_n) * BN;
-  const int WR = 128 + 2 * F + 2;                                  // window rows actually used
-  const int srow = tid >> 3, piece = tid & 7;                      // staging assignment: 8 threads per row
-  const int K = 9 * C, nchunks = C / 32;
-
-  // tap validity of this lane's two output pixels: bit tap of vbits[i]
-  unsigned vbits[TM];
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int p = p0 + wm * 64 + i * 32 + r;
-    unsigned b = 0;
-    if (p < P) {
-      const int f = p % F, t = (p / F) % T;
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int tt = t + tap / 3 - 1, ff = f + tap % 3 - 1;
-        if (tt >= 0 && tt < T && ff >= 0 && ff < F) b |= 1u << tap;
-      }
-    }
-    vbits[i] = b;
-  }
-
-  float4 ra[PASSES], rb[BL];
-  auto fetch_a = [&](int cc) {
-#pragma unroll
-    for (int ps = 0; ps < PASSES; ++ps) {
-      const int wr = ps * 32 + srow;
-      const long q = (long)p0 - F - 1 + wr;
-      ra[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (wr < WR && q >= 0 && q < P) ra[ps] = *reinterpret_cast<const float4*>(x + q * C + cc * 32 + piece * 4);
-    }
-  };
-  // weight rows of this thread: the 64-bit row offsets are formed once, a stage adds a wave-uniform k offset
-  const float* wrow[BL];
-#pragma unroll
-  for (int i = 0; i < BL; ++i) {
-    const int n = n0 + i * 32 + srow;
-    wrow[i] = wp + (long)(n < N ? n : 0) * K + piece * 4;
-  }
-  auto fetch_b = [&](int stage) {                                  // stage = cc * 9 + tap
-    const int cc = stage / 9, tap = stage - cc * 9;
-    const int k0 = tap * C + cc * 32;
-#pragma unroll
-    for (int i = 0; i < BL; ++i)
-      rb[i] = n0 + i * 32 + srow < N ? *reinterpret_cast<const float4*>(wrow[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
-
-  if (tid < 8) {
-#pragma unroll
-    for (int c = 0; c < NT; ++c) *reinterpret_cast<uint2*>(As + c * AIMG + ZR * 32 + tid * 4) = make_uint2(0u, 0u);
-  }
-  fetch_a(0);
-  fetch_b(0);
-  const int nstages = nchunks * 9;
-  for (int cc = 0; cc < nchunks; ++cc) {
-#pragma unroll 1
-    for (int tap = 0; tap < 9; ++tap) {
-      const int stage = cc * 9 + tap;
-      __syncthreads();
-      if (tap == 0) {
-#pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps) halo_store<NT>(As, AIMG, ps * 32 + srow, piece, ra[ps]);
-      }
-#pragma unroll
-      for (int i = 0; i < BL; ++i) halo_store<NT>(Bs, BIMG, i * 32 + srow, piece, rb[i]);
-      __syncthreads();
-      if (stage + 1 < nstages) fetch_b(stage + 1);
-      if (tap == 0 && cc + 1 < nchunks) fetch_a(cc + 1);
-      const int shift = (tap / 3) * F + tap % 3;                   // (F + 1) + (dt * F + df)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        bf16x8 fa[TM][NT], fb[TN][NT];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          // a neighbour across an image border reads the zero row instead: one select on the address in place
-          // of masking every fragment register (VALU beside the MFMAs costs matrix-pipe issue time)
-          const int row = (vbits[i] >> tap) & 1u ? wm * 64 + i * 32 + r + shift : ZR;
-#pragma unroll
-          for (int c = 0; c < NT; ++c)
-            fa[i][c] = *reinterpret_cast<const bf16x8*>(As + c * AIMG + swz_off(row, kk * 2 + h));
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int row = wn * WN + j * 32 + r;
-#pragma unroll
-          for (int c = 0; c < NT; ++c)
-            fb[j][c] = *reinterpret_cast<const bf16x8*>(Bs + c * BIMG + swz_off(row, kk * 2 + h));
-        }
-        if constexpr (NT == 3) {
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = mfma_split(fa[i], fb[j], acc[i][j]);
-        } else {
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(fa[i][0], fb[j][0], acc[i][j]);
-        }
-      }
-    }
-  }
-  // ---- epilogue.  With ep.stats the BatchNorm statistics of the layer that consumes this output (model.py:25,37,
-  // 150,159) are a by-product: per-column sum and sum of squares of the FINAL values (after the residual add) over
-  // this tile's 128 pixels, in double, written as one partial per (pixel tile, column) -- the separate 1 GB
-  // statistics pass over the activation disappears (pe_bn_finalize_stats sums the partials in a fixed order).
-  double s1[TN], s2[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) s1[j] = s2[j] = 0.0;
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        const int row = p0 + wm * 64 + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * h, col = n0 + wn * WN + j * 32 + r;
-        if (row < ep.rows && col < ep.N) {
-          float* d = ep.Y + (long)row * ep.N + col;
-          float v = acc[i][j][g];
-          if (ep.accumulate) v += *d;
-          *d = v;
-          s1[j] += (double)v;
-          s2[j] += (double)v * (double)v;
-        }
-      }
-  if (ep.stats) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      s1[j] += __shfl_xor(s1[j], 32, 64);                          // the two lane halves hold different rows
-      s2[j] += __shfl_xor(s2[j], 32, 64);
-    }
-    __syncthreads();                                               // the activation window is dead: reuse its space
-    double* red = reinterpret_cast<double*>(As);                   // [2 (wm)][BN][2]
-    if (h == 0) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        red[(wm * BN + wn * WN + j * 32 + r) * 2] = s1[j];
-        red[(wm * BN + wn * WN + j * 32 + r) * 2 + 1] = s2[j];
-      }
-    }
-    __syncthreads();
-    const long tile_m = tile / tiles_n;
-    for (int c = tid; c < BN; c += 256) {
-      if (n0 + c < ep.N) {
-        ep.stats[(tile_m * 2) * ep.N + n0 + c] = red[c * 2] + red[(BN + c) * 2];
-        ep.stats[(tile_m * 2 + 1) * ep.N + n0 + c] = red[c * 2 + 1] + red[(BN + c) * 2 + 1];
-      }
-    }
-  }
-}
-
-template <int BN, int MODE, int PASSES>
-int launch_conv_halo(const float* x, const float* wp, float* y, int B, int T, int F, int C, int N, int accumulate,
-                     hipStream_t st) {
-  const int P = B * T * F;
-  ConvEpi ep{y, P, N, accumulate, nullptr};
-  const int tm = pe_cdiv(P, 128), tn = pe_cdiv(N, BN);
-  hipLaunchKernelGGL((conv3x3_halo_kernel<BN, MODE, PASSES>), dim3(tm * tn), dim3(256), 0, st, x, wp, ep, T, F, C, N, P, tm,
-                     tn);
-  PE_LAUNCH_CHECK();
-  return PE_OK;
-}
-
 // ---------------------------------------------------------------- weights as MFMA fragments straight from L2
-// The kernel above stages a 32-k weight slab per tap through LDS: every workgroup repeats the split of the
-// same few hundred KB of weights, and each of the nine stages of a channel chunk costs two workgroup
+// Staging a 32-k weight slab per tap through LDS as well (the first form of this kernel) made every workgroup repeat
+// the split of the same few hundred KB of weights, and each of the nine stages of a channel chunk cost two workgroup
 // barriers although the activation window does not change.  Here the weights are packed ONCE per call
 // (wfrag_pack_kernel) into the B-operand fragment order of v_mfma_f32_32x32x16_bf16 -- for every
 // (16-k block, 32-row block, term) the 64 lanes' 16-byte pieces are contiguous (1 KB) -- and a wave loads
@@ -327,9 +152,9 @@ __global__ void wfrag_pack_kernel(const float* __restrict__ w, long ld, int N, i
   }
 }
 
-template <int BN, int MODE, int PASSES, int D, bool FA2>
-__global__ __launch_bounds__(256, 2) void conv3x3_halo_wf_kernel(const float* __restrict__ x,
-                                                                 const uint4* __restrict__ wf, ConvEpi ep, int T,
+template <int BN, int MODE, int PASSES, int D, bool FA2, class TA = float>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_wf_kernel(const TA* __restrict__ x,
+                                                                 const uint4* __restrict__ wf, ConvEpiT<TA> ep, int T,
                                                                  int F, int C, int N, int P, int tiles_m,
                                                                  int tiles_n, const unsigned* amax_x,
                                                                  const unsigned* amax_w) {
@@ -366,14 +191,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_wf_kernel(const float* __
     vbits[i] = b;
   }
 
-  float4 ra[PASSES];
+  typedef typename RawQuad<TA>::type Raw;      // the staged window keeps its storage form until the LDS stores
+  Raw ra[PASSES];
   auto fetch_a = [&](int cc) {
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
       const int wr = ps * 32 + srow;
       const long q = (long)p0 - F - 1 + wr;
-      ra[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (wr < WR && q >= 0 && q < P) ra[ps] = *reinterpret_cast<const float4*>(x + q * C + cc * 32 + piece * 4);
+      ra[ps] = zero_raw<Raw>();
+      if (wr < WR && q >= 0 && q < P) ra[ps] = ldraw(x + q * C + cc * 32 + piece * 4);
     }
   };
 
@@ -467,10 +293,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_wf_kernel(const float* __
       for (int g = 0; g < 16; ++g) {
         const int row = p0 + wm * 64 + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * h, col = n0 + wn * WN + j * 32 + r;
         if (row < ep.rows && col < ep.N) {
-          float* d = ep.Y + (long)row * ep.N + col;
+          TA* d = ep.Y + (long)row * ep.N + col;
           float v = MODE == kSplit2 ? acc[i][j][g] * hs.inv : acc[i][j][g];
-          if (ep.accumulate) v += *d;
-          *d = v;
+          if (ep.accumulate) v += ld1(d);
+          st1(d, v);
+          v = stored_value<TA>(v);
           s1[j] += (double)v;
           s2[j] += (double)v * (double)v;
         }
@@ -501,14 +328,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_wf_kernel(const float* __
   }
 }
 
-template <int BN, int MODE, int PASSES, int D, bool FA2>
-int launch_conv_halo_wf(const float* x, const void* wf, float* y, int B, int T, int F, int C, int N, int accumulate,
+template <int BN, int MODE, int PASSES, int D, bool FA2, class TA = float>
+int launch_conv_halo_wf(const TA* x, const void* wf, TA* y, int B, int T, int F, int C, int N, int accumulate,
                         double* stats, hipStream_t st, const unsigned* amax_x = nullptr,
                         const unsigned* amax_w = nullptr) {
   const int P = B * T * F;
-  ConvEpi ep{y, P, N, accumulate, stats};
+  ConvEpiT<TA> ep{y, P, N, accumulate, stats};
   const int tm = pe_cdiv(P, 128), tn = pe_cdiv(N, BN);
-  hipLaunchKernelGGL((conv3x3_halo_wf_kernel<BN, MODE, PASSES, D, FA2>), dim3(tm * tn), dim3(256), 0, st, x,
+  hipLaunchKernelGGL((conv3x3_halo_wf_kernel<BN, MODE, PASSES, D, FA2, TA>), dim3(tm * tn), dim3(256), 0, st, x,
                      reinterpret_cast<const uint4*>(wf), ep, T, F, C, N, P, tm, tn, amax_x, amax_w);
   PE_LAUNCH_CHECK();
   return PE_OK;
@@ -676,9 +503,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_kernel(const float* __r
 // of one channel) come from ds_read_b64_tr_b16, and the border mask becomes a 16-bit AND mask per pixel:
 // Mk16[d][w][k] covers source row k + d of window w for column shift df = d - 1, so the 8 masks of a
 // fragment are one aligned 16-byte read.
-template <int NT>   // 3 = exact three-term split, 2 = two scaled fp16 terms, 1 = operands rounded to bf16 (mixed precision)
-__global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(const float* __restrict__ dy,
-                                                                   const float* __restrict__ x,
+template <int NT, class TA = float>   // NT: 3 = exact three-term split, 2 = two scaled fp16 terms, 1 = operands rounded to bf16
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(const TA* __restrict__ dy,
+                                                                   const TA* __restrict__ x,
                                                                    float* __restrict__ ws, int T, int F, int Cin,
                                                                    int Cout, int P, int k_per_split, int tiles_n,
                                                                    const unsigned* amax_dy, const unsigned* amax_x) {
@@ -707,26 +534,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(const float* 
     for (int q = 0; q < 16; ++q) acc[tp][q] = 0.f;
 
   const int c4 = (tid & 15) * 4;
-  float4 ry[2], rx[7];
+  typedef typename RawQuad<TA>::type Raw;
+  Raw ry[2], rx[7];
   auto fetch = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int k = k0 + (tid >> 4) + 16 * i;
-      ry[i] = k < ke ? *reinterpret_cast<const float4*>(dy + (long)k * Cout + m0 + c4)
-                     : make_float4(0.f, 0.f, 0.f, 0.f);
+      ry[i] = k < ke ? ldraw(dy + (long)k * Cout + m0 + c4) : zero_raw<Raw>();
     }
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
       const int wr = (tid >> 4) + 16 * i;
-      rx[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      rx[i] = zero_raw<Raw>();
       if (wr < 102) {
         const int w = wr / 34, row = wr - w * 34;
         const long q = (long)k0 + (long)(w - 1) * F + row - 1;
-        if (q >= 0 && q < P) rx[i] = *reinterpret_cast<const float4*>(x + q * Cin + n0 + c4);
+        if (q >= 0 && q < P) rx[i] = ldraw(x + q * Cin + n0 + c4);
       }
     }
   };
-  auto store3 = [&](__bf16* img, int img_elems, int off, const float4& v, float scale) {
+  auto store3 = [&](__bf16* img, int img_elems, int off, const Raw& raw, float scale) {
+    if constexpr (NT == 1 && !std::is_same<TA, float>::value) {
+      *reinterpret_cast<Raw*>(img + off) = raw;              // bf16 tensor, one rounded term: the bits as they are
+      return;
+    }
+    const float4 v = widen(raw);
     if constexpr (NT == 3) {
       const Split3 sp = split3(v);
       *reinterpret_cast<uint2*>(img + off) = sp.hi;
@@ -853,9 +685,9 @@ int launch_wgrad(const float* x, const float* dy, float* dw, float* ws, int B, i
 // 4 output channels each (one float4 store; 16 threads write one 256-B pixel row).
 // STATS: also reduce the BatchNorm batch statistics of the output (double sum / sum of squares per channel over this
 // workgroup's pixels -> one [2][64] row of bn_partials per workgroup), saving the 1 GB statistics pass over y
-template <bool STATS>
+template <bool STATS, class TA = float>
 __global__ __launch_bounds__(256) void conv3x3_c1_fwd_kernel(const float* __restrict__ x, long sb, long st_, long sf,
-                                                             const float* __restrict__ w, float* __restrict__ y,
+                                                             const float* __restrict__ w, TA* __restrict__ y,
                                                              double* __restrict__ bn_partials, int B, int T, int F) {
   __shared__ double sred[STATS ? 2 * 16 * 64 : 1];
   double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
@@ -892,12 +724,12 @@ __global__ __launch_bounds__(256) void conv3x3_c1_fwd_kernel(const float* __rest
         for (int k = 0; k < 9; ++k) s = fmaf(in[k / 3][px + k % 3], wr[c][k], s);
         op[c] = s;
         if constexpr (STATS) {
-          const double dv = (double)s;
+          const double dv = (double)stored_value<TA>(s);
           s1[c] += dv;
           s2[c] += dv * dv;
         }
       }
-      *reinterpret_cast<float4*>(y + ((long)bt * F + f0 + px) * 64 + q * 4) = o;
+      st4(y + ((long)bt * F + f0 + px) * 64 + q * 4, o);
     }
   }
   if constexpr (STATS) {                          // fold the 16 pixel groups of the workgroup (fixed order)
@@ -919,8 +751,9 @@ __global__ __launch_bounds__(256) void conv3x3_c1_fwd_kernel(const float* __rest
 }
 
 // dW[co][tap] = sum_p dY[p][co] * x[p + tap]; partials per workgroup, then an ordered reduce.
+template <class TA = float>
 __global__ __launch_bounds__(256) void conv3x3_c1_wgrad_kernel(const float* __restrict__ x, long sb, long st_,
-                                                               long sf, const float* __restrict__ dy,
+                                                               long sf, const TA* __restrict__ dy,
                                                                float* __restrict__ partial, int B, int T, int F) {
   // 16 threads per pixel, 4 output channels each (one float4 of dY per thread); 16 pixels per block pass;
   // the nine taps of a pixel are read once per 16-thread group (same address: one broadcast load).
@@ -946,7 +779,7 @@ __global__ __launch_bounds__(256) void conv3x3_c1_wgrad_kernel(const float* __re
       }
 #pragma unroll
     for (int px = 0; px < 4; ++px) {
-      const float4 g = *reinterpret_cast<const float4*>(dy + ((long)bt * F + f0 + px) * 64 + q * 4);
+      const float4 g = ld4(dy + ((long)bt * F + f0 + px) * 64 + q * 4);
 #pragma unroll
       for (int k = 0; k < 9; ++k) {
         const float xv = in[k / 3][px + k % 3];
@@ -1006,28 +839,19 @@ extern "C" int pe_transpose2d(const float* in, float* out, int rows, int cols, v
 }
 #endif
 
-template <int MODE>
-static int conv3x3_fwd_impl(const float* x, const float* w_packed, float* y, int B, int T, int F, int C, int N,
+template <int MODE, class TA = float>
+static int conv3x3_fwd_impl(const TA* x, const float* w_packed, TA* y, int B, int T, int F, int C, int N,
                             int accumulate, void* stream, const unsigned* amax_x = nullptr,
                             const unsigned* amax_w = nullptr) {
   if (!x || !w_packed || !y || B <= 0 || T <= 0 || F <= 0 || C <= 0 || N <= 0) return PE_E_ARG;
   if ((C % 32) != 0 || (long)B * T * F * (C > N ? C : N) >= (1L << 31)) return PE_E_UNSUPPORTED;
   if (MODE == kSplit2 && (!amax_x || !amax_w)) return PE_E_ARG;
   hipStream_t st = pe_stream(stream);
-  if constexpr (MODE != kNative && MODE != kSplit2) {
-    const int passes = conv_halo_passes(F, N);
-    if (passes == 10) return launch_conv_halo<64, MODE, 10>(x, w_packed, y, B, T, F, C, N, accumulate, st);
-    if (passes == 7) {
-      if (N % 192 == 0 && N % 128 != 0)
-        return launch_conv_halo<192, MODE, 7>(x, w_packed, y, B, T, F, C, N, accumulate, st);
-      return launch_conv_halo<128, MODE, 7>(x, w_packed, y, B, T, F, C, N, accumulate, st);
-    }
-  }
   if (N <= 64)
-    return launch_conv<Tile<256, 64, 4, 1>, MODE>(x, w_packed, y, B, T, F, C, N, accumulate, st, amax_x, amax_w);
+    return launch_conv<Tile<256, 64, 4, 1>, MODE, TA>(x, w_packed, y, B, T, F, C, N, accumulate, st, amax_x, amax_w);
   if (N % 192 == 0 && N % 128 != 0)
-    return launch_conv<Tile<128, 192, 2, 2>, MODE>(x, w_packed, y, B, T, F, C, N, accumulate, st, amax_x, amax_w);
-  return launch_conv<Tile<128, 128, 2, 2>, MODE>(x, w_packed, y, B, T, F, C, N, accumulate, st, amax_x, amax_w);
+    return launch_conv<Tile<128, 192, 2, 2>, MODE, TA>(x, w_packed, y, B, T, F, C, N, accumulate, st, amax_x, amax_w);
+  return launch_conv<Tile<128, 128, 2, 2>, MODE, TA>(x, w_packed, y, B, T, F, C, N, accumulate, st, amax_x, amax_w);
 }
 
 #ifndef PE_F16_BUILD
@@ -1106,8 +930,8 @@ extern "C" int pe_wfrag_pack_f16(const float* w, long ld, int N, int K, void* ou
   return PE_OK;
 }
 #endif
-template <int MODE>
-static int conv3x3_fwd_wf_impl(const float* x, const void* wfrag, float* y, int B, int T, int F, int C, int N,
+template <int MODE, class TA = float>
+static int conv3x3_fwd_wf_impl(const TA* x, const void* wfrag, TA* y, int B, int T, int F, int C, int N,
                                int accumulate, double* stats, void* stream, const unsigned* amax_x = nullptr,
                                const unsigned* amax_w = nullptr) {
   if (!x || !wfrag || !y || B <= 0 || T <= 0 || F <= 0 || C <= 0 || N <= 0) return PE_E_ARG;
@@ -1116,11 +940,14 @@ static int conv3x3_fwd_wf_impl(const float* x, const void* wfrag, float* y, int 
   hipStream_t st = pe_stream(stream);
   const int passes = conv_halo_passes(F, N);
   if (passes == 10)
-    return launch_conv_halo_wf<64, MODE, 10, 6, true>(x, wfrag, y, B, T, F, C, N, accumulate, stats, st, amax_x, amax_w);
+    return launch_conv_halo_wf<64, MODE, 10, 6, true, TA>(x, wfrag, y, B, T, F, C, N, accumulate, stats, st, amax_x,
+                                                          amax_w);
   if (passes == 7) {
     if (N % 192 == 0 && N % 128 != 0)
-      return launch_conv_halo_wf<192, MODE, 7, 3, false>(x, wfrag, y, B, T, F, C, N, accumulate, stats, st, amax_x, amax_w);
-    return launch_conv_halo_wf<128, MODE, 7, 3, true>(x, wfrag, y, B, T, F, C, N, accumulate, stats, st, amax_x, amax_w);
+      return launch_conv_halo_wf<192, MODE, 7, 3, false, TA>(x, wfrag, y, B, T, F, C, N, accumulate, stats, st, amax_x,
+                                                             amax_w);
+    return launch_conv_halo_wf<128, MODE, 7, 3, true, TA>(x, wfrag, y, B, T, F, C, N, accumulate, stats, st, amax_x,
+                                                          amax_w);
   }
   return PE_E_UNSUPPORTED;
 }
@@ -1152,8 +979,8 @@ extern "C" size_t pe_conv3x3_wgrad_workspace_bytes(int B, int T, int F, int Cin,
 }
 #endif
 
-template <int MODE>
-static int conv3x3_wgrad_impl(const float* x, const float* dy, float* dw_oihw, int B, int T, int F, int Cin,
+template <int MODE, class TA = float>
+static int conv3x3_wgrad_impl(const TA* x, const TA* dy, float* dw_oihw, int B, int T, int F, int Cin,
                               int Cout, float* workspace, size_t workspace_bytes, void* stream,
                               const unsigned* amax_x = nullptr, const unsigned* amax_dy = nullptr) {
   if (!x || !dy || !dw_oihw || B <= 0 || T <= 0 || F <= 0 || Cin <= 0 || Cout <= 0) return PE_E_ARG;
@@ -1166,15 +993,15 @@ static int conv3x3_wgrad_impl(const float* x, const float* dy, float* dw_oihw, i
   if (wgrad9_ok(Cout, Cin)) {
     const int P = B * T * F, tn = Cin / 64;
     if (MODE == kSplit)
-      hipLaunchKernelGGL(conv3x3_wgrad9_x3_kernel<3>, dim3((Cout / 64) * tn * splits), dim3(256), 0, st, dy, x,
+      hipLaunchKernelGGL((conv3x3_wgrad9_x3_kernel<3, TA>), dim3((Cout / 64) * tn * splits), dim3(256), 0, st, dy, x,
                          workspace, T, F, Cin, Cout, P, kps, tn, nullptr, nullptr);
     else if (MODE == kSplit2)
-      hipLaunchKernelGGL(conv3x3_wgrad9_x3_kernel<2>, dim3((Cout / 64) * tn * splits), dim3(256), 0, st, dy, x,
+      hipLaunchKernelGGL((conv3x3_wgrad9_x3_kernel<2, TA>), dim3((Cout / 64) * tn * splits), dim3(256), 0, st, dy, x,
                          workspace, T, F, Cin, Cout, P, kps, tn, amax_dy, amax_x);
     else if (MODE == kBf16)
-      hipLaunchKernelGGL(conv3x3_wgrad9_x3_kernel<1>, dim3((Cout / 64) * tn * splits), dim3(256), 0, st, dy, x,
+      hipLaunchKernelGGL((conv3x3_wgrad9_x3_kernel<1, TA>), dim3((Cout / 64) * tn * splits), dim3(256), 0, st, dy, x,
                          workspace, T, F, Cin, Cout, P, kps, tn, nullptr, nullptr);
-    else
+    else if constexpr (std::is_same<TA, float>::value)
       hipLaunchKernelGGL(conv3x3_wgrad9_kernel<0>, dim3((Cout / 64) * tn * splits), dim3(256), 0, st, dy, x,
                          workspace, T, F, Cin, Cout, P, kps, tn);
     PE_LAUNCH_CHECK();
@@ -1184,11 +1011,14 @@ static int conv3x3_wgrad_impl(const float* x, const float* dy, float* dw_oihw, i
     PE_LAUNCH_CHECK();
     return PE_OK;
   }
-  // channel counts that are not multiples of 64: per-tap kernels on the native fp32 MFMA in every mode
-  if (bm == 64 && bn == 64) return launch_wgrad<64, 64>(x, dy, dw_oihw, workspace, B, T, F, Cin, Cout, splits, kps, st);
-  if (bm == 64) return launch_wgrad<64, 128>(x, dy, dw_oihw, workspace, B, T, F, Cin, Cout, splits, kps, st);
-  if (bn == 64) return launch_wgrad<128, 64>(x, dy, dw_oihw, workspace, B, T, F, Cin, Cout, splits, kps, st);
-  return launch_wgrad<128, 128>(x, dy, dw_oihw, workspace, B, T, F, Cin, Cout, splits, kps, st);
+  // channel counts that are not multiples of 64: per-tap kernels on the native fp32 MFMA in every mode (fp32 tensors)
+  if constexpr (std::is_same<TA, float>::value) {
+    if (bm == 64 && bn == 64) return launch_wgrad<64, 64>(x, dy, dw_oihw, workspace, B, T, F, Cin, Cout, splits, kps, st);
+    if (bm == 64) return launch_wgrad<64, 128>(x, dy, dw_oihw, workspace, B, T, F, Cin, Cout, splits, kps, st);
+    if (bn == 64) return launch_wgrad<128, 64>(x, dy, dw_oihw, workspace, B, T, F, Cin, Cout, splits, kps, st);
+    return launch_wgrad<128, 128>(x, dy, dw_oihw, workspace, B, T, F, Cin, Cout, splits, kps, st);
+  }
+  return PE_E_UNSUPPORTED;
 }
 
 #ifndef PE_F16_BUILD
@@ -1202,6 +1032,27 @@ extern "C" int PE_HALF(pe_conv3x3_wgrad)(const float* x, const float* dy, float*
                                      int Cout, float* workspace, size_t workspace_bytes, void* stream) {
   return conv3x3_wgrad_impl<kBf16>(x, dy, dw_oihw, B, T, F, Cin, Cout, workspace, workspace_bytes, stream);
 }
+
+#ifndef PE_F16_BUILD
+// ---- mixed precision with bf16 ACTIVATION STORAGE (x, y, dy are bf16 tensors in HBM; weights / gradients fp32)
+extern "C" int pe_conv3x3_fwd_bf16_a16(const void* x, const float* w_packed, void* y, int B, int T, int F, int C, int N,
+                                       int accumulate, void* stream) {
+  return conv3x3_fwd_impl<kBf16, act16_t>(static_cast<const act16_t*>(x), w_packed, static_cast<act16_t*>(y), B, T, F,
+                                          C, N, accumulate, stream);
+}
+
+extern "C" int pe_conv3x3_fwd_wf_bf16_a16(const void* x, const void* wfrag, void* y, int B, int T, int F, int C, int N,
+                                          int accumulate, double* bn_partials, void* stream) {
+  return conv3x3_fwd_wf_impl<kBf16, act16_t>(static_cast<const act16_t*>(x), wfrag, static_cast<act16_t*>(y), B, T, F,
+                                             C, N, accumulate, bn_partials, stream);
+}
+
+extern "C" int pe_conv3x3_wgrad_bf16_a16(const void* x, const void* dy, float* dw_oihw, int B, int T, int F, int Cin,
+                                         int Cout, float* workspace, size_t workspace_bytes, void* stream) {
+  return conv3x3_wgrad_impl<kBf16, act16_t>(static_cast<const act16_t*>(x), static_cast<const act16_t*>(dy), dw_oihw,
+                                            B, T, F, Cin, Cout, workspace, workspace_bytes, stream);
+}
+#endif
 
 #ifndef PE_F16_BUILD
 extern "C" int pe_conv3x3_wgrad_x3(const float* x, const float* dy, float* dw_oihw, int B, int T, int F, int Cin,
@@ -1224,32 +1075,55 @@ static int c1_grid(int B, int T, int F) {
 // rows of the [rows][2][64] double partials pe_conv3x3_c1_fwd writes when bn_partials is given
 extern "C" int pe_conv3x3_c1_stat_parts(int B, int T, int F) { return (B > 0 && T > 0 && F > 0) ? c1_grid(B, T, F) : 0; }
 
-extern "C" int pe_conv3x3_c1_fwd(const float* x, long sb, long st, long sf, const float* w_oihw, float* y, int B,
-                                 int T, int F, double* bn_partials, void* stream) {
+template <class TA>
+static int conv3x3_c1_fwd_impl(const float* x, long sb, long st, long sf, const float* w_oihw, TA* y, int B, int T,
+                               int F, double* bn_partials, void* stream) {
   if (!x || !w_oihw || !y || B <= 0 || T <= 0 || F <= 0) return PE_E_ARG;
   if ((F & 3) || (long)B * T * F >= (1L << 31) - 64L * 8192) return PE_E_UNSUPPORTED;   // runs of 4, 32-bit indices
   const int grid = c1_grid(B, T, F);
   if (bn_partials)
-    hipLaunchKernelGGL(conv3x3_c1_fwd_kernel<true>, dim3(grid), dim3(256), 0, pe_stream(stream), x, sb, st, sf, w_oihw,
-                       y, bn_partials, B, T, F);
+    hipLaunchKernelGGL((conv3x3_c1_fwd_kernel<true, TA>), dim3(grid), dim3(256), 0, pe_stream(stream), x, sb, st, sf,
+                       w_oihw, y, bn_partials, B, T, F);
   else
-    hipLaunchKernelGGL(conv3x3_c1_fwd_kernel<false>, dim3(grid), dim3(256), 0, pe_stream(stream), x, sb, st, sf,
+    hipLaunchKernelGGL((conv3x3_c1_fwd_kernel<false, TA>), dim3(grid), dim3(256), 0, pe_stream(stream), x, sb, st, sf,
                        w_oihw, y, nullptr, B, T, F);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }
 
-extern "C" int pe_conv3x3_c1_wgrad(const float* x, long sb, long st, long sf, const float* dy, float* dw_oihw,
-                                   int B, int T, int F, float* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int pe_conv3x3_c1_fwd(const float* x, long sb, long st, long sf, const float* w_oihw, float* y, int B,
+                                 int T, int F, double* bn_partials, void* stream) {
+  return conv3x3_c1_fwd_impl<float>(x, sb, st, sf, w_oihw, y, B, T, F, bn_partials, stream);
+}
+
+extern "C" int pe_conv3x3_c1_fwd_a16(const float* x, long sb, long st, long sf, const float* w_oihw, void* y, int B,
+                                     int T, int F, double* bn_partials, void* stream) {
+  return conv3x3_c1_fwd_impl<act16_t>(x, sb, st, sf, w_oihw, static_cast<act16_t*>(y), B, T, F, bn_partials, stream);
+}
+
+template <class TA>
+static int conv3x3_c1_wgrad_impl(const float* x, long sb, long st, long sf, const TA* dy, float* dw_oihw, int B, int T,
+                                 int F, float* workspace, size_t workspace_bytes, void* stream) {
   if (!x || !dy || !dw_oihw || B <= 0 || T <= 0 || F <= 0) return PE_E_ARG;
   if ((F & 3) || (long)B * T * F >= (1L << 31) - 65536) return PE_E_UNSUPPORTED;   // runs of 4, 32-bit pixel index
   if (!workspace || workspace_bytes < (size_t)kC1WgradBlocks * 576 * sizeof(float)) return PE_E_WORKSPACE;
-  hipLaunchKernelGGL(conv3x3_c1_wgrad_kernel, dim3(kC1WgradBlocks), dim3(256), 0, pe_stream(stream), x, sb, st, sf,
+  hipLaunchKernelGGL(conv3x3_c1_wgrad_kernel<TA>, dim3(kC1WgradBlocks), dim3(256), 0, pe_stream(stream), x, sb, st, sf,
                      dy, workspace, B, T, F);
   PE_LAUNCH_CHECK();
   hipLaunchKernelGGL(c1_wgrad_reduce_kernel, dim3(144), dim3(256), 0, pe_stream(stream), workspace, dw_oihw,
                      kC1WgradBlocks);
   PE_LAUNCH_CHECK();
   return PE_OK;
+}
+
+extern "C" int pe_conv3x3_c1_wgrad(const float* x, long sb, long st, long sf, const float* dy, float* dw_oihw,
+                                   int B, int T, int F, float* workspace, size_t workspace_bytes, void* stream) {
+  return conv3x3_c1_wgrad_impl<float>(x, sb, st, sf, dy, dw_oihw, B, T, F, workspace, workspace_bytes, stream);
+}
+
+extern "C" int pe_conv3x3_c1_wgrad_a16(const float* x, long sb, long st, long sf, const void* dy, float* dw_oihw,
+                                       int B, int T, int F, float* workspace, size_t workspace_bytes, void* stream) {
+  return conv3x3_c1_wgrad_impl<act16_t>(x, sb, st, sf, static_cast<const act16_t*>(dy), dw_oihw, B, T, F, workspace,
+                                        workspace_bytes, stream);
 }
 #endif

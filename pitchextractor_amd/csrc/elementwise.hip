@@ -3,9 +3,11 @@
 // BN -> LeakyReLU(0.01) -> MaxPool2d((1, k)) blocks (model.py:36-41,148-153) forward and backward,
 // the detector-branch max-pools (model.py:45-49), dropout (model.py:40,56) and the
 // (B,256,T,2) -> (B,T,512) re-layout of model.py:93,112.  Everything moves float4 (4 channels).
-#include "common.h"
+#include <type_traits>
+#include "act16.h"
 
 namespace {
+using namespace pe;
 
 constexpr int kMaxPartials = 1024;
 
@@ -44,11 +46,12 @@ __device__ __forceinline__ void column_reduce2(F&& f, long n_pix, int C, double*
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 
 // ---------------------------------------------------------------- BN statistics
-__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, long n_pix, int C,
+template <class TA>
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const TA* __restrict__ x, long n_pix, int C,
                                                                double* __restrict__ partial) {
   column_reduce2(
       [&](long p, int c, float4& a, float4& b) {
-        a = *reinterpret_cast<const float4*>(x + p * C + c);
+        a = ld4(x + p * C + c);
         b = make_float4(a.x * a.x, a.y * a.y, a.z * a.z, a.w * a.w);
       },
       n_pix, C, partial);
@@ -129,10 +132,11 @@ __device__ __forceinline__ void amax_commit(float m, unsigned* __restrict__ amax
 
 // ---------------------------------------------------------------- BN -> LReLU -> MaxPool(1,k) forward
 // x: [rows][Fin][C]; y: pixel (row, fo) at y[(row*Fout + fo)*ldy + coff + c]
-__global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const float* __restrict__ x,
+template <class TA>
+__global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const TA* __restrict__ x,
                                                               const float* __restrict__ scale,
                                                               const float* __restrict__ shift, float slope,
-                                                              float* __restrict__ y, long n_out_pix, int Fin, int C,
+                                                              TA* __restrict__ y, long n_out_pix, int Fin, int C,
                                                               int pool, long ldy, int coff,
                                                               unsigned* __restrict__ amax) {
   const int quads = C >> 2;
@@ -146,10 +150,10 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const float* __res
     const int fo = (int)(op % Fout);
     const float4 sc = *reinterpret_cast<const float4*>(scale + q * 4);
     const float4 sh = *reinterpret_cast<const float4*>(shift + q * 4);
-    const float* xp = x + ((row * Fin + (long)fo * pool) * C + q * 4);
+    const TA* xp = x + ((row * Fin + (long)fo * pool) * C + q * 4);
     float4 m;
     for (int j = 0; j < pool; ++j) {
-      const float4 v = *reinterpret_cast<const float4*>(xp + (long)j * C);
+      const float4 v = ld4(xp + (long)j * C);
       float4 a;
       a.x = lrelu(fmaf(v.x, sc.x, sh.x), slope);
       a.y = lrelu(fmaf(v.y, sc.y, sh.y), slope);
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const float* __res
       if (j == 0) m = a;
       else { m.x = fmaxf(m.x, a.x); m.y = fmaxf(m.y, a.y); m.z = fmaxf(m.z, a.z); m.w = fmaxf(m.w, a.w); }
     }
-    *reinterpret_cast<float4*>(y + op * ldy + coff + q * 4) = m;
+    st4(y + op * ldy + coff + q * 4, m);
     am = amax4(am, m);
   }
   amax_commit(am, amax);
@@ -180,9 +184,10 @@ __device__ __forceinline__ float dz_one(const float* __restrict__ xwin, long cst
   return z > 0.f ? dyv : dyv * slope;
 }
 
-struct BnBwdArgs {
-  const float* x;       // [rows][Fin][C]
-  const float* dy;      // pixel (row, fo) at dy[(row*Fout + fo)*lddy + coff + c]
+template <class TA>
+struct BnBwdArgsT {
+  const TA* x;          // [rows][Fin][C]
+  const TA* dy;         // pixel (row, fo) at dy[(row*Fout + fo)*lddy + coff + c]
   const float* scale;
   const float* shift;
   const float* mean;
@@ -193,6 +198,7 @@ struct BnBwdArgs {
   long lddy;
   int coff;
 };
+typedef BnBwdArgsT<float> BnBwdArgs;
 
 __device__ __forceinline__ float4 dz_quad(const BnBwdArgs& a, long p, int c) {
   const int Fout = a.Fin / a.pool;
@@ -286,22 +292,22 @@ struct BnWindow {
   int n;         // pixels in it
 };
 
-template <int POOL>
-__device__ __forceinline__ void bn_window(const BnBwdArgs& a, long item, int nwin, int c, BnWindow<POOL>& w) {
+template <int POOL, class TA>
+__device__ __forceinline__ void bn_window(const BnBwdArgsT<TA>& a, long item, int nwin, int c, BnWindow<POOL>& w) {
   const int Fout = a.Fin / POOL;
   const long row = item / nwin;
   const int wi = (int)(item - row * nwin);
   const bool real = wi < Fout;
   w.n = real ? POOL : a.Fin - Fout * POOL;
   w.p0 = row * a.Fin + (long)wi * POOL;
-  const float* xp = a.x + w.p0 * a.C + c;
+  const TA* xp = a.x + w.p0 * a.C + c;
 #pragma unroll
   for (int j = 0; j < POOL; ++j) {
-    w.v[j] = j < w.n ? *reinterpret_cast<const float4*>(xp + (long)j * a.C) : make_float4(0.f, 0.f, 0.f, 0.f);
+    w.v[j] = j < w.n ? ld4(xp + (long)j * a.C) : make_float4(0.f, 0.f, 0.f, 0.f);
     w.dz[j] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   if (!real) return;
-  const float4 dyv = *reinterpret_cast<const float4*>(a.dy + (row * Fout + wi) * a.lddy + a.coff + c);
+  const float4 dyv = ld4(a.dy + (row * Fout + wi) * a.lddy + a.coff + c);
   const float4 sc = *reinterpret_cast<const float4*>(a.scale + c);
   const float4 sh = *reinterpret_cast<const float4*>(a.shift + c);
   const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
@@ -321,13 +327,13 @@ __device__ __forceinline__ void bn_window(const BnBwdArgs& a, long item, int nwi
   }
 }
 
-template <int POOL>
-__global__ __launch_bounds__(256) void bn_bwd_partial_win_kernel(const BnBwdArgs a, long n_items, int nwin,
+template <int POOL, class TA>
+__global__ __launch_bounds__(256) void bn_bwd_partial_win_kernel(const BnBwdArgsT<TA> a, long n_items, int nwin,
                                                                  double* __restrict__ partial) {
   column_reduce2(
       [&](long item, int c, float4& s, float4& t) {
         BnWindow<POOL> w;
-        bn_window<POOL>(a, item, nwin, c, w);
+        bn_window<POOL, TA>(a, item, nwin, c, w);
         const float4 mu = *reinterpret_cast<const float4*>(a.mean + c);
         const float4 is = *reinterpret_cast<const float4*>(a.invstd + c);
         s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -342,10 +348,10 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_win_kernel(const BnBwdArgs
       n_items, a.C, partial);
 }
 
-template <int POOL>
-__global__ __launch_bounds__(256) void bn_bwd_apply_win_kernel(const BnBwdArgs a, long n_items, int nwin,
+template <int POOL, class TA>
+__global__ __launch_bounds__(256) void bn_bwd_apply_win_kernel(const BnBwdArgsT<TA> a, long n_items, int nwin,
                                                                const float* __restrict__ c1,
-                                                               const float* __restrict__ c2, float* __restrict__ dx,
+                                                               const float* __restrict__ c2, TA* __restrict__ dx,
                                                                unsigned* __restrict__ amax) {
   const int quads = a.C >> 2;
   const long total = n_items * quads;
@@ -354,7 +360,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_win_kernel(const BnBwdArgs a
     const long item = i / quads;
     const int c = (int)(i - item * quads) * 4;
     BnWindow<POOL> w;
-    bn_window<POOL>(a, item, nwin, c, w);
+    bn_window<POOL, TA>(a, item, nwin, c, w);
     const float4 mu = *reinterpret_cast<const float4*>(a.mean + c);
     const float4 is = *reinterpret_cast<const float4*>(a.invstd + c);
     const float4 sc = *reinterpret_cast<const float4*>(a.scale + c);
@@ -368,7 +374,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_win_kernel(const BnBwdArgs a
       o.y = sc.y * (w.dz[j].y - k1.y - (w.v[j].y - mu.y) * is.y * k2.y);
       o.z = sc.z * (w.dz[j].z - k1.z - (w.v[j].z - mu.z) * is.z * k2.z);
       o.w = sc.w * (w.dz[j].w - k1.w - (w.v[j].w - mu.w) * is.w * k2.w);
-      *reinterpret_cast<float4*>(dx + (w.p0 + j) * a.C + c) = o;
+      st4(dx + (w.p0 + j) * a.C + c, o);
       am = amax4(am, o);
     }
   }
@@ -376,7 +382,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_win_kernel(const BnBwdArgs a
 }
 
 // ---------------------------------------------------------------- plain MaxPool(1,k) (detector taps)
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+template <class TA>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const TA* __restrict__ x, TA* __restrict__ y,
                                                           long n_out_pix, int Fin, int C, int pool, long ldy,
                                                           int coff, unsigned char* __restrict__ arg) {
   // arg (optional, [n_out_pix][C] bytes): the window position of each maximum (first one wins, as torch's
@@ -387,14 +394,14 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
     const int q = (int)(i % quads);
     const long op = i / quads, row = op / Fout;
     const int fo = (int)(op % Fout);
-    const float* xp = x + ((row * Fin + (long)fo * pool) * C + q * 4);
-    float4 m = *reinterpret_cast<const float4*>(xp);
+    const TA* xp = x + ((row * Fin + (long)fo * pool) * C + q * 4);
+    float4 m = ld4(xp);
     int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     int j = 1;
     for (; j + 4 <= pool; j += 4) {                               // four window rows in flight
       float4 v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(xp + (long)(j + u) * C);
+      for (int u = 0; u < 4; ++u) v[u] = ld4(xp + (long)(j + u) * C);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (v[u].x > m.x) { m.x = v[u].x; a0 = j + u; }
@@ -404,13 +411,13 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
       }
     }
     for (; j < pool; ++j) {
-      const float4 v = *reinterpret_cast<const float4*>(xp + (long)j * C);
+      const float4 v = ld4(xp + (long)j * C);
       if (v.x > m.x) { m.x = v.x; a0 = j; }
       if (v.y > m.y) { m.y = v.y; a1 = j; }
       if (v.z > m.z) { m.z = v.z; a2 = j; }
       if (v.w > m.w) { m.w = v.w; a3 = j; }
     }
-    *reinterpret_cast<float4*>(y + op * ldy + coff + q * 4) = m;
+    st4(y + op * ldy + coff + q * 4, m);
     if (arg != nullptr)
       *reinterpret_cast<uchar4*>(arg + op * C + q * 4) = make_uchar4((unsigned char)a0, (unsigned char)a1,
                                                                      (unsigned char)a2, (unsigned char)a3);
@@ -418,8 +425,9 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
 }
 
 // dx[first argmax of each window] += dy   (one thread owns a whole window: no atomics)
-__global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const float* __restrict__ x,
-                                                              const float* __restrict__ dy, float* __restrict__ dx,
+template <class TA>
+__global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const TA* __restrict__ x,
+                                                              const TA* __restrict__ dy, TA* __restrict__ dx,
                                                               long n_out_pix, int Fin, int C, int pool, long lddy,
                                                               int coff, unsigned* __restrict__ amax,
                                                               const unsigned char* __restrict__ arg) {
@@ -438,13 +446,13 @@ __global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const float* __res
       const uchar4 a = *reinterpret_cast<const uchar4*>(arg + op * C + c);
       a0 = a.x; a1 = a.y; a2 = a.z; a3 = a.w;
     } else {
-    const float* xp = x + (row * Fin + (long)fo * pool) * C + c;
-    float4 best = *reinterpret_cast<const float4*>(xp);
+    const TA* xp = x + (row * Fin + (long)fo * pool) * C + c;
+    float4 best = ld4(xp);
     int jn = 1;
     for (; jn + 4 <= pool; jn += 4) {
       float4 v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(xp + (long)(jn + u) * C);
+      for (int u = 0; u < 4; ++u) v[u] = ld4(xp + (long)(jn + u) * C);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (v[u].x > best.x) { best.x = v[u].x; a0 = jn + u; }
@@ -454,21 +462,21 @@ __global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const float* __res
       }
     }
     for (; jn < pool; ++jn) {
-      const float4 v = *reinterpret_cast<const float4*>(xp + (long)jn * C);
+      const float4 v = ld4(xp + (long)jn * C);
       if (v.x > best.x) { best.x = v.x; a0 = jn; }
       if (v.y > best.y) { best.y = v.y; a1 = jn; }
       if (v.z > best.z) { best.z = v.z; a2 = jn; }
       if (v.w > best.w) { best.w = v.w; a3 = jn; }
     }
     }
-    const float4 g = *reinterpret_cast<const float4*>(dy + op * lddy + coff + c);
-    float* dp = dx + (row * Fin + (long)fo * pool) * C + c;
-    const float4 nv = make_float4(dp[(long)a0 * C] + g.x, dp[(long)a1 * C + 1] + g.y, dp[(long)a2 * C + 2] + g.z,
-                                  dp[(long)a3 * C + 3] + g.w);
-    dp[(long)a0 * C] = nv.x;
-    dp[(long)a1 * C + 1] = nv.y;
-    dp[(long)a2 * C + 2] = nv.z;
-    dp[(long)a3 * C + 3] = nv.w;
+    const float4 g = ld4(dy + op * lddy + coff + c);
+    TA* dp = dx + (row * Fin + (long)fo * pool) * C + c;
+    const float4 nv = make_float4(ld1(dp + (long)a0 * C) + g.x, ld1(dp + (long)a1 * C + 1) + g.y,
+                                  ld1(dp + (long)a2 * C + 2) + g.z, ld1(dp + (long)a3 * C + 3) + g.w);
+    st1(dp + (long)a0 * C, nv.x);
+    st1(dp + (long)a1 * C + 1, nv.y);
+    st1(dp + (long)a2 * C + 2, nv.z);
+    st1(dp + (long)a3 * C + 3, nv.w);
     am = amax4(am, nv);          // merged into dx's word: an upper bound of max |dx| (elements that shrank keep their old share)
   }
   amax_commit(am, amax);
@@ -477,8 +485,9 @@ __global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const float* __res
 // ---------------------------------------------------------------- dropout (Philox4x32-10)
 // rows x cols, x row stride ldx, y row stride ldy; mask is dense [rows*cols] bytes (1 = kept).
 // mask_in != NULL replays a given mask (parity tests); otherwise keep = (u >= p).
-__global__ __launch_bounds__(256) void dropout_fwd_kernel(const float* __restrict__ x, long ldx,
-                                                          float* __restrict__ y, long ldy,
+template <class TA>
+__global__ __launch_bounds__(256) void dropout_fwd_kernel(const TA* __restrict__ x, long ldx,
+                                                          TA* __restrict__ y, long ldy,
                                                           const uint8_t* __restrict__ mask_in,
                                                           uint8_t* __restrict__ mask_out, long rows, int cols,
                                                           float p, float scale, uint64_t seed, uint64_t offset) {
@@ -497,57 +506,60 @@ __global__ __launch_bounds__(256) void dropout_fwd_kernel(const float* __restric
 #pragma unroll
       for (int k = 0; k < 4; ++k) keep[k] = ((float)(rnd[k] >> 8) * (1.0f / 16777216.0f)) >= p ? 1 : 0;
     }
-    const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
+    const float4 v = ld4(x + r * ldx + c);
     float4 o;
     o.x = keep[0] ? v.x * scale : 0.f;
     o.y = keep[1] ? v.y * scale : 0.f;
     o.z = keep[2] ? v.z * scale : 0.f;
     o.w = keep[3] ? v.w * scale : 0.f;
-    *reinterpret_cast<float4*>(y + r * ldy + c) = o;
+    st4(y + r * ldy + c, o);
     if (mask_out) *reinterpret_cast<uchar4*>(mask_out + r * cols + c) = make_uchar4(keep[0], keep[1], keep[2], keep[3]);
   }
 }
 
 // ---------------------------------------------------------------- (B,256,T,2) <-> (B,T,512) re-layout
 // channels-last pixel pair (row, w in {0,1}) at x[(row*2 + w)*ldx + coff + c]  <->  seq[row][c*2 + w]
-__global__ __launch_bounds__(256) void nhwc_to_seq_kernel(const float* __restrict__ x, long ldx, int coff,
+template <class TA>
+__global__ __launch_bounds__(256) void nhwc_to_seq_kernel(const TA* __restrict__ x, long ldx, int coff,
                                                           float* __restrict__ seq, long rows, int C) {
   const long total = rows * C;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int c = (int)(i % C);
     const long r = i / C;
-    const float a = x[(r * 2 + 0) * ldx + coff + c];
-    const float b = x[(r * 2 + 1) * ldx + coff + c];
+    const float a = ld1(x + (r * 2 + 0) * ldx + coff + c);
+    const float b = ld1(x + (r * 2 + 1) * ldx + coff + c);
     *reinterpret_cast<float2*>(seq + r * 2 * C + 2 * c) = make_float2(a, b);
   }
 }
 
-__global__ __launch_bounds__(256) void seq_to_nhwc_kernel(const float* __restrict__ seq, float* __restrict__ x,
+template <class TA>
+__global__ __launch_bounds__(256) void seq_to_nhwc_kernel(const float* __restrict__ seq, TA* __restrict__ x,
                                                           long ldx, int coff, long rows, int C, int accumulate) {
   const long total = rows * C;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int c = (int)(i % C);
     const long r = i / C;
     const float2 v = *reinterpret_cast<const float2*>(seq + r * 2 * C + 2 * c);
-    float* d0 = x + (r * 2 + 0) * ldx + coff + c;
-    float* d1 = x + (r * 2 + 1) * ldx + coff + c;
-    if (accumulate) { *d0 += v.x; *d1 += v.y; }
-    else { *d0 = v.x; *d1 = v.y; }
+    TA* d0 = x + (r * 2 + 0) * ldx + coff + c;
+    TA* d1 = x + (r * 2 + 1) * ldx + coff + c;
+    if (accumulate) { st1(d0, ld1(d0) + v.x); st1(d1, ld1(d1) + v.y); }
+    else { st1(d0, v.x); st1(d1, v.y); }
   }
 }
 
 // strided 2-D copy / add: dst[r*ldd + c] (+)= src[r*lds + c]
-__global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ src, long lds, float* __restrict__ dst,
+template <class TA>
+__global__ __launch_bounds__(256) void copy2d_kernel(const TA* __restrict__ src, long lds, TA* __restrict__ dst,
                                                      long ldd, long rows, int cols, int accumulate) {
   const int quads = cols >> 2;
   const long total = rows * quads;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int c = (int)(i % quads) * 4;
     const long r = i / quads;
-    float4 v = *reinterpret_cast<const float4*>(src + r * lds + c);
-    float4* d = reinterpret_cast<float4*>(dst + r * ldd + c);
-    if (accumulate) { const float4 o = *d; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-    *d = v;
+    float4 v = ld4(src + r * lds + c);
+    TA* d = dst + r * ldd + c;
+    if (accumulate) { const float4 o = ld4(d); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+    st4(d, v);
   }
 }
 
@@ -622,22 +634,39 @@ __global__ __launch_bounds__(256) void absmax_segments_kernel(const float* __res
 
 extern "C" size_t pe_bn_workspace_bytes(int C) { return (size_t)kMaxPartials * 2 * C * sizeof(double); }
 
-extern "C" int pe_bn_train_stats(const float* x, long n_pix, int C, const float* gamma, const float* beta, float eps,
-                                 float momentum, float* running_mean, float* running_var, float* mean,
-                                 float* invstd, float* scale, float* shift, void* workspace, size_t workspace_bytes,
-                                 void* stream) {
+template <class TA>
+static int bn_train_stats_impl(const TA* x, long n_pix, int C, const float* gamma, const float* beta, float eps,
+                               float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
+                               float* scale, float* shift, void* workspace, size_t workspace_bytes, void* stream) {
   if (!x || !gamma || !beta || !mean || !invstd || !scale || !shift || n_pix <= 0) return PE_E_ARG;
   if (!bn_channels_ok(C)) return PE_E_UNSUPPORTED;
   if (!workspace || workspace_bytes < pe_bn_workspace_bytes(C)) return PE_E_WORKSPACE;
   hipStream_t st = pe_stream(stream);
   const int grid = reduce_grid(n_pix, C);
   double* partial = reinterpret_cast<double*>(workspace);
-  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(grid), dim3(256), reduce_lds(C), st, x, n_pix, C, partial);
+  hipLaunchKernelGGL(bn_stats_partial_kernel<TA>, dim3(grid), dim3(256), reduce_lds(C), st, x, n_pix, C, partial);
   PE_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(pe_cdiv(C, 4)), dim3(256), 0, st, partial, grid, n_pix, C, gamma,
                      beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
   PE_LAUNCH_CHECK();
   return PE_OK;
+}
+
+extern "C" int pe_bn_train_stats(const float* x, long n_pix, int C, const float* gamma, const float* beta, float eps,
+                                 float momentum, float* running_mean, float* running_var, float* mean,
+                                 float* invstd, float* scale, float* shift, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+  return bn_train_stats_impl<float>(x, n_pix, C, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
+                                    scale, shift, workspace, workspace_bytes, stream);
+}
+
+extern "C" int pe_bn_train_stats_a16(const void* x, long n_pix, int C, const float* gamma, const float* beta, float eps,
+                                     float momentum, float* running_mean, float* running_var, float* mean,
+                                     float* invstd, float* scale, float* shift, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  return bn_train_stats_impl<act16_t>(static_cast<const act16_t*>(x), n_pix, C, gamma, beta, eps, momentum,
+                                      running_mean, running_var, mean, invstd, scale, shift, workspace,
+                                      workspace_bytes, stream);
 }
 
 // BatchNorm training statistics from partials a producer kernel left behind ([nparts][2][C] doubles: column sums
@@ -678,14 +707,73 @@ extern "C" int pe_bn_eval_affine(const float* gamma, const float* beta, const fl
   return PE_OK;
 }
 
-extern "C" int pe_bn_act_pool_fwd(const float* x, const float* scale, const float* shift, float slope, float* y,
-                                  long rows, int Fin, int C, int pool, long ldy, int coff, unsigned* amax_out,
-                                  void* stream) {
+template <class TA>
+static int bn_act_pool_fwd_impl(const TA* x, const float* scale, const float* shift, float slope, TA* y, long rows,
+                                int Fin, int C, int pool, long ldy, int coff, unsigned* amax_out, void* stream) {
   if (!x || !scale || !shift || !y || rows <= 0 || Fin <= 0 || pool <= 0) return PE_E_ARG;
   if (!bn_channels_ok(C) || (ldy & 3) || (coff & 3)) return PE_E_UNSUPPORTED;
   const long n_out = rows * (Fin / pool);
-  hipLaunchKernelGGL(bn_act_pool_fwd_kernel, dim3(ew_grid(n_out * (C / 4))), dim3(256), 0, pe_stream(stream), x, scale,
-                     shift, slope, y, n_out, Fin, C, pool, ldy, coff, amax_out);
+  hipLaunchKernelGGL(bn_act_pool_fwd_kernel<TA>, dim3(ew_grid(n_out * (C / 4))), dim3(256), 0, pe_stream(stream), x,
+                     scale, shift, slope, y, n_out, Fin, C, pool, ldy, coff, amax_out);
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+
+extern "C" int pe_bn_act_pool_fwd(const float* x, const float* scale, const float* shift, float slope, float* y,
+                                  long rows, int Fin, int C, int pool, long ldy, int coff, unsigned* amax_out,
+                                  void* stream) {
+  return bn_act_pool_fwd_impl<float>(x, scale, shift, slope, y, rows, Fin, C, pool, ldy, coff, amax_out, stream);
+}
+
+extern "C" int pe_bn_act_pool_fwd_a16(const void* x, const float* scale, const float* shift, float slope, void* y,
+                                      long rows, int Fin, int C, int pool, long ldy, int coff, void* stream) {
+  return bn_act_pool_fwd_impl<act16_t>(static_cast<const act16_t*>(x), scale, shift, slope, static_cast<act16_t*>(y),
+                                       rows, Fin, C, pool, ldy, coff, nullptr, stream);
+}
+
+template <class TA>
+static int bn_act_pool_bwd_impl(const TA* x, const TA* dy, const float* scale, const float* shift, const float* mean,
+                                const float* invstd, float slope, TA* dx, float* dgamma, float* dbeta, long rows,
+                                int Fin, int C, int pool, long lddy, int coff, void* workspace, size_t workspace_bytes,
+                                unsigned* amax_out, void* stream) {
+  if (!x || !dy || !scale || !shift || !mean || !invstd || !dx || !dgamma || !dbeta || rows <= 0) return PE_E_ARG;
+  if (!bn_channels_ok(C) || (lddy & 3) || (coff & 3) || pool <= 0) return PE_E_UNSUPPORTED;
+  const size_t need = pe_bn_workspace_bytes(C) + 2 * (size_t)C * sizeof(float);
+  if (!workspace || workspace_bytes < need) return PE_E_WORKSPACE;
+  hipStream_t st = pe_stream(stream);
+  BnBwdArgsT<TA> a{x, dy, scale, shift, mean, invstd, slope, rows * Fin, Fin, C, pool, lddy, coff};
+  double* partial = reinterpret_cast<double*>(workspace);
+  float* c1 = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + pe_bn_workspace_bytes(C));
+  float* c2 = c1 + C;
+  const int nwin = Fin / pool + (Fin % pool ? 1 : 0);
+  const long n_items = rows * nwin;
+  const bool win = pool == 1 || pool == 2 || pool == 4;
+  if (!win && !std::is_same<TA, float>::value) return PE_E_UNSUPPORTED;      // other pool widths: fp32 tensors only
+  const int grid = reduce_grid(win ? n_items : a.n_in_pix, C);
+  if (pool == 1)
+    hipLaunchKernelGGL((bn_bwd_partial_win_kernel<1, TA>), dim3(grid), dim3(256), reduce_lds(C), st, a, n_items, nwin, partial);
+  else if (pool == 2)
+    hipLaunchKernelGGL((bn_bwd_partial_win_kernel<2, TA>), dim3(grid), dim3(256), reduce_lds(C), st, a, n_items, nwin, partial);
+  else if (pool == 4)
+    hipLaunchKernelGGL((bn_bwd_partial_win_kernel<4, TA>), dim3(grid), dim3(256), reduce_lds(C), st, a, n_items, nwin, partial);
+  else if constexpr (std::is_same<TA, float>::value)
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(grid), dim3(256), reduce_lds(C), st, a, partial);
+  PE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pe_cdiv(C, 4)), dim3(256), 0, st, partial, grid, a.n_in_pix, C,
+                     dgamma, dbeta, c1, c2);
+  PE_LAUNCH_CHECK();
+  const int agrid = ew_grid((win ? n_items : a.n_in_pix) * (C / 4));
+  if (pool == 1)
+    hipLaunchKernelGGL((bn_bwd_apply_win_kernel<1, TA>), dim3(agrid), dim3(256), 0, st, a, n_items, nwin, c1, c2, dx,
+                       amax_out);
+  else if (pool == 2)
+    hipLaunchKernelGGL((bn_bwd_apply_win_kernel<2, TA>), dim3(agrid), dim3(256), 0, st, a, n_items, nwin, c1, c2, dx,
+                       amax_out);
+  else if (pool == 4)
+    hipLaunchKernelGGL((bn_bwd_apply_win_kernel<4, TA>), dim3(agrid), dim3(256), 0, st, a, n_items, nwin, c1, c2, dx,
+                       amax_out);
+  else if constexpr (std::is_same<TA, float>::value)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(agrid), dim3(256), 0, st, a, c1, c2, dx, amax_out);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }
@@ -694,65 +782,73 @@ extern "C" int pe_bn_act_pool_bwd(const float* x, const float* dy, const float* 
                                   const float* mean, const float* invstd, float slope, float* dx, float* dgamma,
                                   float* dbeta, long rows, int Fin, int C, int pool, long lddy, int coff,
                                   void* workspace, size_t workspace_bytes, unsigned* amax_out, void* stream) {
-  if (!x || !dy || !scale || !shift || !mean || !invstd || !dx || !dgamma || !dbeta || rows <= 0) return PE_E_ARG;
-  if (!bn_channels_ok(C) || (lddy & 3) || (coff & 3) || pool <= 0) return PE_E_UNSUPPORTED;
-  const size_t need = pe_bn_workspace_bytes(C) + 2 * (size_t)C * sizeof(float);
-  if (!workspace || workspace_bytes < need) return PE_E_WORKSPACE;
-  hipStream_t st = pe_stream(stream);
-  BnBwdArgs a{x, dy, scale, shift, mean, invstd, slope, rows * Fin, Fin, C, pool, lddy, coff};
-  double* partial = reinterpret_cast<double*>(workspace);
-  float* c1 = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + pe_bn_workspace_bytes(C));
-  float* c2 = c1 + C;
-  const int nwin = Fin / pool + (Fin % pool ? 1 : 0);
-  const long n_items = rows * nwin;
-  const bool win = pool == 1 || pool == 2 || pool == 4;
-  const int grid = reduce_grid(win ? n_items : a.n_in_pix, C);
-  if (pool == 1)
-    hipLaunchKernelGGL(bn_bwd_partial_win_kernel<1>, dim3(grid), dim3(256), reduce_lds(C), st, a, n_items, nwin, partial);
-  else if (pool == 2)
-    hipLaunchKernelGGL(bn_bwd_partial_win_kernel<2>, dim3(grid), dim3(256), reduce_lds(C), st, a, n_items, nwin, partial);
-  else if (pool == 4)
-    hipLaunchKernelGGL(bn_bwd_partial_win_kernel<4>, dim3(grid), dim3(256), reduce_lds(C), st, a, n_items, nwin, partial);
-  else
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(grid), dim3(256), reduce_lds(C), st, a, partial);
-  PE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pe_cdiv(C, 4)), dim3(256), 0, st, partial, grid, a.n_in_pix, C,
-                     dgamma, dbeta, c1, c2);
-  PE_LAUNCH_CHECK();
-  const int agrid = ew_grid((win ? n_items : a.n_in_pix) * (C / 4));
-  if (pool == 1)
-    hipLaunchKernelGGL(bn_bwd_apply_win_kernel<1>, dim3(agrid), dim3(256), 0, st, a, n_items, nwin, c1, c2, dx,
-                       amax_out);
-  else if (pool == 2)
-    hipLaunchKernelGGL(bn_bwd_apply_win_kernel<2>, dim3(agrid), dim3(256), 0, st, a, n_items, nwin, c1, c2, dx,
-                       amax_out);
-  else if (pool == 4)
-    hipLaunchKernelGGL(bn_bwd_apply_win_kernel<4>, dim3(agrid), dim3(256), 0, st, a, n_items, nwin, c1, c2, dx,
-                       amax_out);
-  else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(agrid), dim3(256), 0, st, a, c1, c2, dx, amax_out);
+  return bn_act_pool_bwd_impl<float>(x, dy, scale, shift, mean, invstd, slope, dx, dgamma, dbeta, rows, Fin, C, pool,
+                                     lddy, coff, workspace, workspace_bytes, amax_out, stream);
+}
+
+extern "C" int pe_bn_act_pool_bwd_a16(const void* x, const void* dy, const float* scale, const float* shift,
+                                      const float* mean, const float* invstd, float slope, void* dx, float* dgamma,
+                                      float* dbeta, long rows, int Fin, int C, int pool, long lddy, int coff,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+  return bn_act_pool_bwd_impl<act16_t>(static_cast<const act16_t*>(x), static_cast<const act16_t*>(dy), scale, shift,
+                                       mean, invstd, slope, static_cast<act16_t*>(dx), dgamma, dbeta, rows, Fin, C,
+                                       pool, lddy, coff, workspace, workspace_bytes, nullptr, stream);
+}
+
+template <class TA>
+static int maxpool_fwd_impl(const TA* x, TA* y, long rows, int Fin, int C, int pool, long ldy, int coff,
+                            unsigned char* argmax_out, void* stream) {
+  if (!x || !y || rows <= 0 || Fin <= 0 || pool <= 0) return PE_E_ARG;
+  if ((C & 3) || (ldy & 3) || (coff & 3) || (argmax_out && pool > 255)) return PE_E_UNSUPPORTED;
+  const long n_out = rows * (Fin / pool);
+  hipLaunchKernelGGL(maxpool_fwd_kernel<TA>, dim3(ew_grid(n_out * (C / 4))), dim3(256), 0, pe_stream(stream), x, y,
+                     n_out, Fin, C, pool, ldy, coff, argmax_out);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }
 
 extern "C" int pe_maxpool_fwd(const float* x, float* y, long rows, int Fin, int C, int pool, long ldy, int coff,
                               unsigned char* argmax_out, void* stream) {
-  if (!x || !y || rows <= 0 || Fin <= 0 || pool <= 0) return PE_E_ARG;
-  if ((C & 3) || (ldy & 3) || (coff & 3) || (argmax_out && pool > 255)) return PE_E_UNSUPPORTED;
+  return maxpool_fwd_impl<float>(x, y, rows, Fin, C, pool, ldy, coff, argmax_out, stream);
+}
+
+extern "C" int pe_maxpool_fwd_a16(const void* x, void* y, long rows, int Fin, int C, int pool, long ldy, int coff,
+                                  unsigned char* argmax_out, void* stream) {
+  return maxpool_fwd_impl<act16_t>(static_cast<const act16_t*>(x), static_cast<act16_t*>(y), rows, Fin, C, pool, ldy,
+                                   coff, argmax_out, stream);
+}
+
+template <class TA>
+static int maxpool_bwd_add_impl(const TA* x, const unsigned char* argmax, const TA* dy, TA* dx, long rows, int Fin,
+                                int C, int pool, long lddy, int coff, unsigned* amax_out, void* stream) {
+  if ((!x && !argmax) || !dy || !dx || rows <= 0 || Fin <= 0 || pool <= 0 || C <= 0) return PE_E_ARG;
+  if ((C & 3) || (lddy & 3) || (coff & 3)) return PE_E_UNSUPPORTED;
   const long n_out = rows * (Fin / pool);
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(n_out * (C / 4))), dim3(256), 0, pe_stream(stream), x, y, n_out,
-                     Fin, C, pool, ldy, coff, argmax_out);
+  hipLaunchKernelGGL(maxpool_bwd_add_kernel<TA>, dim3(ew_grid(n_out * (C / 4))), dim3(256), 0, pe_stream(stream), x,
+                     dy, dx, n_out, Fin, C, pool, lddy, coff, amax_out, argmax);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }
 
 extern "C" int pe_maxpool_bwd_add(const float* x, const unsigned char* argmax, const float* dy, float* dx, long rows,
                                   int Fin, int C, int pool, long lddy, int coff, unsigned* amax_out, void* stream) {
-  if ((!x && !argmax) || !dy || !dx || rows <= 0 || Fin <= 0 || pool <= 0 || C <= 0) return PE_E_ARG;
-  if ((C & 3) || (lddy & 3) || (coff & 3)) return PE_E_UNSUPPORTED;
-  const long n_out = rows * (Fin / pool);
-  hipLaunchKernelGGL(maxpool_bwd_add_kernel, dim3(ew_grid(n_out * (C / 4))), dim3(256), 0, pe_stream(stream), x, dy,
-                     dx, n_out, Fin, C, pool, lddy, coff, amax_out, argmax);
+  return maxpool_bwd_add_impl<float>(x, argmax, dy, dx, rows, Fin, C, pool, lddy, coff, amax_out, stream);
+}
+
+extern "C" int pe_maxpool_bwd_add_a16(const void* x, const unsigned char* argmax, const void* dy, void* dx, long rows,
+                                      int Fin, int C, int pool, long lddy, int coff, void* stream) {
+  return maxpool_bwd_add_impl<act16_t>(static_cast<const act16_t*>(x), argmax, static_cast<const act16_t*>(dy),
+                                       static_cast<act16_t*>(dx), rows, Fin, C, pool, lddy, coff, nullptr, stream);
+}
+
+template <class TA>
+static int dropout_fwd_impl(const TA* x, long ldx, TA* y, long ldy, const unsigned char* mask_in,
+                            unsigned char* mask_out, long rows, int cols, float p, unsigned long long seed,
+                            unsigned long long offset, void* stream) {
+  if (!x || !y || rows <= 0 || cols <= 0 || p < 0.f || p >= 1.f) return PE_E_ARG;
+  if ((cols & 3) || (ldx & 3) || (ldy & 3)) return PE_E_UNSUPPORTED;
+  hipLaunchKernelGGL(dropout_fwd_kernel<TA>, dim3(ew_grid(rows * (cols / 4))), dim3(256), 0, pe_stream(stream), x, ldx,
+                     y, ldy, mask_in, mask_out, rows, cols, p, 1.0f / (1.0f - p), (uint64_t)seed, (uint64_t)offset);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }
@@ -760,18 +856,28 @@ extern "C" int pe_maxpool_bwd_add(const float* x, const unsigned char* argmax, c
 extern "C" int pe_dropout_fwd(const float* x, long ldx, float* y, long ldy, const unsigned char* mask_in,
                               unsigned char* mask_out, long rows, int cols, float p, unsigned long long seed,
                               unsigned long long offset, void* stream) {
-  if (!x || !y || rows <= 0 || cols <= 0 || p < 0.f || p >= 1.f) return PE_E_ARG;
-  if ((cols & 3) || (ldx & 3) || (ldy & 3)) return PE_E_UNSUPPORTED;
-  hipLaunchKernelGGL(dropout_fwd_kernel, dim3(ew_grid(rows * (cols / 4))), dim3(256), 0, pe_stream(stream), x, ldx, y,
-                     ldy, mask_in, mask_out, rows, cols, p, 1.0f / (1.0f - p), (uint64_t)seed, (uint64_t)offset);
-  PE_LAUNCH_CHECK();
-  return PE_OK;
+  return dropout_fwd_impl<float>(x, ldx, y, ldy, mask_in, mask_out, rows, cols, p, seed, offset, stream);
+}
+
+extern "C" int pe_dropout_fwd_a16(const void* x, long ldx, void* y, long ldy, const unsigned char* mask_in,
+                                  unsigned char* mask_out, long rows, int cols, float p, unsigned long long seed,
+                                  unsigned long long offset, void* stream) {
+  return dropout_fwd_impl<act16_t>(static_cast<const act16_t*>(x), ldx, static_cast<act16_t*>(y), ldy, mask_in,
+                                   mask_out, rows, cols, p, seed, offset, stream);
 }
 
 extern "C" int pe_nhwc_to_seq(const float* x, long ldx, int coff, float* seq, long rows, int C, void* stream) {
   if (!x || !seq || rows <= 0 || C <= 0) return PE_E_ARG;
-  hipLaunchKernelGGL(nhwc_to_seq_kernel, dim3(ew_grid(rows * C)), dim3(256), 0, pe_stream(stream), x, ldx, coff, seq,
-                     rows, C);
+  hipLaunchKernelGGL(nhwc_to_seq_kernel<float>, dim3(ew_grid(rows * C)), dim3(256), 0, pe_stream(stream), x, ldx, coff,
+                     seq, rows, C);
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+
+extern "C" int pe_nhwc_to_seq_a16(const void* x, long ldx, int coff, float* seq, long rows, int C, void* stream) {
+  if (!x || !seq || rows <= 0 || C <= 0) return PE_E_ARG;
+  hipLaunchKernelGGL(nhwc_to_seq_kernel<act16_t>, dim3(ew_grid(rows * C)), dim3(256), 0, pe_stream(stream),
+                     static_cast<const act16_t*>(x), ldx, coff, seq, rows, C);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }
@@ -779,20 +885,40 @@ extern "C" int pe_nhwc_to_seq(const float* x, long ldx, int coff, float* seq, lo
 extern "C" int pe_seq_to_nhwc(const float* seq, float* x, long ldx, int coff, long rows, int C, int accumulate,
                               void* stream) {
   if (!x || !seq || rows <= 0 || C <= 0) return PE_E_ARG;
-  hipLaunchKernelGGL(seq_to_nhwc_kernel, dim3(ew_grid(rows * C)), dim3(256), 0, pe_stream(stream), seq, x, ldx, coff,
-                     rows, C, accumulate);
+  hipLaunchKernelGGL(seq_to_nhwc_kernel<float>, dim3(ew_grid(rows * C)), dim3(256), 0, pe_stream(stream), seq, x, ldx,
+                     coff, rows, C, accumulate);
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+
+extern "C" int pe_seq_to_nhwc_a16(const float* seq, void* x, long ldx, int coff, long rows, int C, int accumulate,
+                                  void* stream) {
+  if (!x || !seq || rows <= 0 || C <= 0) return PE_E_ARG;
+  hipLaunchKernelGGL(seq_to_nhwc_kernel<act16_t>, dim3(ew_grid(rows * C)), dim3(256), 0, pe_stream(stream), seq,
+                     static_cast<act16_t*>(x), ldx, coff, rows, C, accumulate);
+  PE_LAUNCH_CHECK();
+  return PE_OK;
+}
+
+template <class TA>
+static int copy2d_impl(const TA* src, long lds, TA* dst, long ldd, long rows, int cols, int accumulate, void* stream) {
+  if (!src || !dst || rows <= 0 || cols <= 0) return PE_E_ARG;
+  if ((cols & 3) || (lds & 3) || (ldd & 3)) return PE_E_UNSUPPORTED;
+  hipLaunchKernelGGL(copy2d_kernel<TA>, dim3(ew_grid(rows * (cols / 4))), dim3(256), 0, pe_stream(stream), src, lds, dst,
+                     ldd, rows, cols, accumulate);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }
 
 extern "C" int pe_copy2d(const float* src, long lds, float* dst, long ldd, long rows, int cols, int accumulate,
                          void* stream) {
-  if (!src || !dst || rows <= 0 || cols <= 0) return PE_E_ARG;
-  if ((cols & 3) || (lds & 3) || (ldd & 3)) return PE_E_UNSUPPORTED;
-  hipLaunchKernelGGL(copy2d_kernel, dim3(ew_grid(rows * (cols / 4))), dim3(256), 0, pe_stream(stream), src, lds, dst,
-                     ldd, rows, cols, accumulate);
-  PE_LAUNCH_CHECK();
-  return PE_OK;
+  return copy2d_impl<float>(src, lds, dst, ldd, rows, cols, accumulate, stream);
+}
+
+extern "C" int pe_copy2d_a16(const void* src, long lds, void* dst, long ldd, long rows, int cols, int accumulate,
+                             void* stream) {
+  return copy2d_impl<act16_t>(static_cast<const act16_t*>(src), lds, static_cast<act16_t*>(dst), ldd, rows, cols,
+                              accumulate, stream);
 }
 
 extern "C" int pe_absmax(const float* x, long rows, int cols, long ld, unsigned* out, void* stream) {

@@ -6,6 +6,7 @@
 //   pe_gemm_tn:  C[M][N] = sum_k A[k][m] . B[k][n]  (k = rows), split over k across workgroups
 //                -> weight gradients (dW = dY^T X), deterministic slab + ordered reduce.
 #include <stdlib.h>
+#include <type_traits>
 #include <utility>
 #include "gemm_engine.h"
 
@@ -16,8 +17,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-struct StoreEpi {
-  float* C;
+template <class TO>
+struct StoreEpiT {
+  TO* C;
   long ldc;
   const float* bias0;
   const float* bias1;
@@ -26,15 +28,16 @@ struct StoreEpi {
     if (row < M && col < N) {
       if (bias0) v += bias0[col];
       if (bias1) v += bias1[col];
-      float* dst = C + (long)row * ldc + col;
-      if (accumulate) v += *dst;
-      *dst = v;
+      TO* dst = C + (long)row * ldc + col;
+      if (accumulate) v += ld1(dst);
+      st1(dst, v);
     }
   }
 };
+typedef StoreEpiT<float> StoreEpi;
 
-template <class TL, int MODE>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(RowLoader al, RowLoader bl, StoreEpi ep, int K,
+template <class TL, int MODE, class TA = float>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(RowLoaderT<TA> al, RowLoader bl, StoreEpiT<TA> ep, int K,
                                                       int tiles_m, int tiles_n, const unsigned* amax_a,
                                                       const unsigned* amax_b) {
   __shared__ __attribute__((aligned(16))) float As[TL::BM * nt_row_floats<MODE>()];
@@ -56,9 +59,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(RowLoader al, RowLoader bl
 // columns of one row instead of four rows of one column, and the epilogue writes 16-byte pieces (a quarter of the
 // store instructions, bias fetched once per column quad).  Bit-identical sums.  Needs N % 4 == 0 and a 16-byte
 // aligned C with ldc % 4 == 0 (checked by the host).
-template <class TL, int MODE>
+template <class TL, int MODE, class TA = float>
 __global__ __launch_bounds__(256, ((MODE == kSplit || MODE == kSplit2) && TL::BM == 128 && TL::BN == 128) ? 3 : 1)
-void gemm_nt_t_kernel(RowLoader al, RowLoader bl, StoreEpi ep, int K, int tiles_m, int tiles_n,
+void gemm_nt_t_kernel(RowLoaderT<TA> al, RowLoader bl, StoreEpiT<TA> ep, int K, int tiles_m, int tiles_n,
                       const unsigned* amax_a, const unsigned* amax_b) {
   using TT = Tile<TL::BN, TL::BM, TL::WAVES_N, TL::WAVES_M>;
   __shared__ __attribute__((aligned(16))) float As[TL::BM * nt_row_floats<MODE>()];
@@ -88,13 +91,13 @@ void gemm_nt_t_kernel(RowLoader al, RowLoader bl, StoreEpi ep, int K, int tiles_
       for (int j = 0; j < TT::TN; ++j) {
         const int row = m0 + wm * TT::WN + j * 32 + r;
         if (row >= ep.M) continue;
-        float4* dst = reinterpret_cast<float4*>(ep.C + (long)row * ep.ldc + col);
+        TA* dst = ep.C + (long)row * ep.ldc + col;
         float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
         if constexpr (MODE == kSplit2) { v.x *= hs.inv; v.y *= hs.inv; v.z *= hs.inv; v.w *= hs.inv; }
         if (ep.bias0) { v.x += b0.x; v.y += b0.y; v.z += b0.z; v.w += b0.w; }
         if (ep.bias1) { v.x += b1.x; v.y += b1.y; v.z += b1.z; v.w += b1.w; }
-        if (ep.accumulate) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-        *dst = v;
+        if (ep.accumulate) { const float4 o = ld4(dst); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        st4(dst, v);
       }
     }
 }
@@ -287,18 +290,18 @@ int launch_nt_pipe(const RowLoader& al, const RowLoader& bl, const StoreEpi& ep,
   return PE_OK;
 }
 
-template <class TL, int MODE>
-int launch_nt(const RowLoader& al, const RowLoader& bl, const StoreEpi& ep, int M, int N, int K,
+template <class TL, int MODE, class TA = float>
+int launch_nt(const RowLoaderT<TA>& al, const RowLoader& bl, const StoreEpiT<TA>& ep, int M, int N, int K,
               hipStream_t st, const unsigned* amax_a = nullptr, const unsigned* amax_b = nullptr) {
   const int tm = pe_cdiv(M, TL::BM), tn = pe_cdiv(N, TL::BN);
   static const bool off = getenv("PE_GEMM_NT_SCALAR_EPILOGUE") != nullptr;     // A/B switch (tools/ab_gemm.py)
   const bool vec = !off && MODE != kNative && (N & 3) == 0 && (ep.ldc & 3) == 0 &&
-                   (reinterpret_cast<uintptr_t>(ep.C) & 15) == 0;
+                   (reinterpret_cast<uintptr_t>(ep.C) & (4 * sizeof(TA) - 1)) == 0;
   if (vec)
-    hipLaunchKernelGGL((gemm_nt_t_kernel<TL, MODE>), dim3(tm * tn), dim3(256), 0, st, al, bl, ep, K, tm, tn, amax_a,
-                       amax_b);
+    hipLaunchKernelGGL((gemm_nt_t_kernel<TL, MODE, TA>), dim3(tm * tn), dim3(256), 0, st, al, bl, ep, K, tm, tn,
+                       amax_a, amax_b);
   else
-    hipLaunchKernelGGL((gemm_nt_kernel<TL, MODE>), dim3(tm * tn), dim3(256), 0, st, al, bl, ep, K, tm, tn, amax_a,
+    hipLaunchKernelGGL((gemm_nt_kernel<TL, MODE, TA>), dim3(tm * tn), dim3(256), 0, st, al, bl, ep, K, tm, tn, amax_a,
                        amax_b);
   PE_LAUNCH_CHECK();
   return PE_OK;
@@ -432,8 +435,8 @@ int launch_nt_wf(const RowLoader& al, const void* wf, const StoreEpi& ep, int M,
 }
 
 // ---- TN with split-K
-template <int BM, int BN, int MODE>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(KRowLoader<BM> al, KRowLoader<BN> bl, float* out,
+template <int BM, int BN, int MODE, class TA = float>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(KRowLoader<BM, TA> al, KRowLoader<BN, TA> bl, float* out,
                                                       long ldo, long split_stride, int M, int N, int K,
                                                       int k_per_split, int tiles_n, int accumulate,
                                                       const unsigned* amax_a, const unsigned* amax_b) {
@@ -494,24 +497,24 @@ void tn_plan(int M, int N, int K, int bm, int bn, int mode, int* splits, int* k_
   *k_per_split = kps;
 }
 
-template <int BM, int BN, int MODE>
-int launch_tn(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, int K,
+template <int BM, int BN, int MODE, class TA = float>
+int launch_tn(const TA* A, long lda, const TA* B, long ldb, float* C, long ldc, int M, int N, int K,
               int accumulate, float* ws, size_t ws_bytes, hipStream_t st, const unsigned* amax_a = nullptr,
               const unsigned* amax_b = nullptr) {
   int splits, kps;
   tn_plan(M, N, K, BM, BN, MODE, &splits, &kps);
-  KRowLoader<BM> al{A, lda, M, 0};
-  KRowLoader<BN> bl{B, ldb, N, 0};
+  KRowLoader<BM, TA> al{A, lda, M, 0};
+  KRowLoader<BN, TA> bl{B, ldb, N, 0};
   const int tm = pe_cdiv(M, BM), tn = pe_cdiv(N, BN);
   if (splits == 1) {
-    hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, MODE>), dim3(tm * tn, 1), dim3(256), 0, st, al, bl, C, ldc, 0L, M, N,
+    hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, MODE, TA>), dim3(tm * tn, 1), dim3(256), 0, st, al, bl, C, ldc, 0L, M, N,
                        K, kps, tn, accumulate, amax_a, amax_b);
     PE_LAUNCH_CHECK();
     return PE_OK;
   }
   const size_t need = (size_t)splits * M * N * sizeof(float);
   if (!ws || ws_bytes < need) return PE_E_WORKSPACE;
-  hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, MODE>), dim3(tm * tn * splits), dim3(256), 0, st, al, bl, ws, (long)N,
+  hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, MODE, TA>), dim3(tm * tn * splits), dim3(256), 0, st, al, bl, ws, (long)N,
                      (long)M * N, M, N, K, kps, tn, 0, amax_a, amax_b);
   PE_LAUNCH_CHECK();
   const long total = (long)M * N;
@@ -533,19 +536,20 @@ extern "C" int pe_gemm_nt_pipeline(int enable) {
 }
 #endif
 
-template <int MODE>
-static int gemm_nt_impl(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
+template <int MODE, class TA = float>
+static int gemm_nt_impl(const TA* A, long lda, const float* B, long ldb, TA* C, long ldc, int M, int N,
                         int K, const float* bias0, const float* bias1, int accumulate, void* stream,
                         const unsigned* amax_a = nullptr, const unsigned* amax_b = nullptr) {
   if (!A || !B || !C || M < 0 || N < 0 || K <= 0) return PE_E_ARG;
   if (MODE == kSplit2 && (!amax_a || !amax_b)) return PE_E_ARG;
   if (M == 0 || N == 0) return PE_OK;
-  if ((K & 3) || (lda & 3) || (ldb & 3) || !aligned16(A) || !aligned16(B)) return PE_E_UNSUPPORTED;
-  RowLoader al{A, lda, M, K, 0};
+  if ((K & 3) || (lda & 3) || (ldb & 3) || (reinterpret_cast<uintptr_t>(A) & (4 * sizeof(TA) - 1)) || !aligned16(B))
+    return PE_E_UNSUPPORTED;
+  RowLoaderT<TA> al{A, lda, M, K, 0};
   RowLoader bl{B, ldb, N, K, 0};
-  StoreEpi ep{C, ldc, bias0, bias1, M, N, accumulate};
+  StoreEpiT<TA> ep{C, ldc, bias0, bias1, M, N, accumulate};
   hipStream_t st = pe_stream(stream);
-  if constexpr (MODE == kSplit) {
+  if constexpr (MODE == kSplit && std::is_same<TA, float>::value) {
     // opt-in (PE_GEMM_NT_PIPE=1): measured at par with the two-workgroup kernels below on the step's shapes --
     // see the kernel's comment and DESIGN.md for the breakdown
     const bool pipe_off = !g_nt_pipeline;
@@ -553,12 +557,12 @@ static int gemm_nt_impl(const float* A, long lda, const float* B, long ldb, floa
     if (!pipe_off && N % 128 == 0 && K >= 256 && K % 32 == 0 && M >= 256 && (ldc & 3) == 0 && aligned16(C) && fits32)
       return launch_nt_pipe(al, bl, ep, M, N, K, st);
   }
-  if (N <= 32) return launch_nt<Tile<128, 32, 4, 1>, MODE>(al, bl, ep, M, N, K, st, amax_a, amax_b);
-  if (N <= 64) return launch_nt<Tile<256, 64, 4, 1>, MODE>(al, bl, ep, M, N, K, st, amax_a, amax_b);
+  if (N <= 32) return launch_nt<Tile<128, 32, 4, 1>, MODE, TA>(al, bl, ep, M, N, K, st, amax_a, amax_b);
+  if (N <= 64) return launch_nt<Tile<256, 64, 4, 1>, MODE, TA>(al, bl, ep, M, N, K, st, amax_a, amax_b);
   static const bool narrow = getenv("PE_GEMM_NT_TILE128") != nullptr;                 // A/B switch
   if (N % 192 == 0 && (N % 128 != 0 || MODE != kNative) && !(narrow && N % 128 == 0))   // bf16-term modes: the wider tile stages 17 % fewer rows per MFMA
-    return launch_nt<Tile<128, 192, 2, 2>, MODE>(al, bl, ep, M, N, K, st, amax_a, amax_b);
-  return launch_nt<Tile<128, 128, 2, 2>, MODE>(al, bl, ep, M, N, K, st, amax_a, amax_b);
+    return launch_nt<Tile<128, 192, 2, 2>, MODE, TA>(al, bl, ep, M, N, K, st, amax_a, amax_b);
+  return launch_nt<Tile<128, 128, 2, 2>, MODE, TA>(al, bl, ep, M, N, K, st, amax_a, amax_b);
 }
 
 #ifndef PE_F16_BUILD
@@ -573,6 +577,15 @@ extern "C" int PE_HALF(pe_gemm_nt)(const float* A, long lda, const float* B, lon
                                void* stream) {
   return gemm_nt_impl<kBf16>(A, lda, B, ldb, C, ldc, M, N, K, bias0, bias1, accumulate, stream);
 }
+
+#ifndef PE_F16_BUILD
+// mixed precision with bf16 ACTIVATION STORAGE: A and C are bf16 tensors in HBM (weights and biases stay fp32)
+extern "C" int pe_gemm_nt_bf16_a16(const void* A, long lda, const float* B, long ldb, void* C, long ldc, int M, int N,
+                                   int K, const float* bias0, const float* bias1, int accumulate, void* stream) {
+  return gemm_nt_impl<kBf16, act16_t>(static_cast<const act16_t*>(A), lda, B, ldb, static_cast<act16_t*>(C), ldc, M, N,
+                                      K, bias0, bias1, accumulate, stream);
+}
+#endif
 
 #ifndef PE_F16_BUILD
 extern "C" int pe_gemm_nt_x3(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
@@ -649,25 +662,27 @@ extern "C" size_t pe_gemm_tn_workspace_bytes(int M, int N, int K) {
 }
 #endif
 
-template <int MODE>
-static int gemm_tn_impl(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
+template <int MODE, class TA = float>
+static int gemm_tn_impl(const TA* A, long lda, const TA* B, long ldb, float* C, long ldc, int M, int N,
                         int K, int accumulate, float* workspace, size_t workspace_bytes, void* stream,
                         const unsigned* amax_a = nullptr, const unsigned* amax_b = nullptr) {
   if (!A || !B || !C || M < 0 || N < 0 || K <= 0) return PE_E_ARG;
   if (MODE == kSplit2 && (!amax_a || !amax_b)) return PE_E_ARG;
   if (M == 0 || N == 0) return PE_OK;
-  if ((M & 3) || (N & 3) || (lda & 3) || (ldb & 3) || !aligned16(A) || !aligned16(B)) return PE_E_UNSUPPORTED;
+  if ((M & 3) || (N & 3) || (lda & 3) || (ldb & 3) || (reinterpret_cast<uintptr_t>(A) & (4 * sizeof(TA) - 1)) ||
+      (reinterpret_cast<uintptr_t>(B) & (4 * sizeof(TA) - 1)))
+    return PE_E_UNSUPPORTED;
   hipStream_t st = pe_stream(stream);
   if (M <= 64 && N <= 64)
-    return launch_tn<64, 64, MODE>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, st, amax_a,
+    return launch_tn<64, 64, MODE, TA>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, st, amax_a,
                                    amax_b);
   if (M <= 64)
-    return launch_tn<64, 128, MODE>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, st, amax_a,
+    return launch_tn<64, 128, MODE, TA>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, st, amax_a,
                                     amax_b);
   if (N <= 64)
-    return launch_tn<128, 64, MODE>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, st, amax_a,
+    return launch_tn<128, 64, MODE, TA>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, st, amax_a,
                                     amax_b);
-  return launch_tn<128, 128, MODE>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, st, amax_a,
+  return launch_tn<128, 128, MODE, TA>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, st, amax_a,
                                    amax_b);
 }
 
@@ -694,3 +709,11 @@ extern "C" int PE_HALF(pe_gemm_tn)(const float* A, long lda, const float* B, lon
                                int K, int accumulate, float* workspace, size_t workspace_bytes, void* stream) {
   return gemm_tn_impl<kBf16>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, stream);
 }
+
+#ifndef PE_F16_BUILD
+extern "C" int pe_gemm_tn_bf16_a16(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N,
+                                   int K, int accumulate, float* workspace, size_t workspace_bytes, void* stream) {
+  return gemm_tn_impl<kBf16, act16_t>(static_cast<const act16_t*>(A), lda, static_cast<const act16_t*>(B), ldb, C, ldc,
+                                      M, N, K, accumulate, workspace, workspace_bytes, stream);
+}
+#endif

@@ -17,7 +17,7 @@
 // C[row = (g & 3) + 8 * (g >> 2) + 4 * (l >> 5)][col = l & 31].
 #pragma once
 #include <utility>
-#include "common.h"
+#include "act16.h"
 
 namespace pe {
 
@@ -58,27 +58,31 @@ __device__ __forceinline__ int xcd_remap(int bid, int ntiles) {
 // A loader hands out float4 = 4 consecutive k of one row.  `slot` i in [0, LOADS) addresses
 // row (tid >> 3) + 32 * i of the tile; k4 = (tid & 7) * 4 within the 32-wide k-tile.
 
-struct RowLoader {            // plain row-major matrix, rows x K, leading dimension ld
-  const float* p;
+template <class T>
+struct RowLoaderT {           // plain row-major matrix of T (float, or bf16 activations), rows x K, leading dimension ld
+  const T* p;
   long ld;
   int rows, K;
   int row0;
+  typedef typename RawQuad<T>::type Raw;
   __device__ __forceinline__ void init(int first_row) { row0 = first_row + (threadIdx.x >> 3); }
-  __device__ __forceinline__ float4 load(int slot, int kt) const {
+  __device__ __forceinline__ Raw load(int slot, int kt) const {
     const int row = row0 + 32 * slot;
     const int k = kt * kBK + (threadIdx.x & 7) * 4;
-    if (row < rows && k < K) return *reinterpret_cast<const float4*>(p + (long)row * ld + k);
-    return make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < rows && k < K) return ldraw(p + (long)row * ld + k);
+    return zero_raw<Raw>();
   }
 };
+typedef RowLoaderT<float> RowLoader;
 
-template <int SLOTS>
+template <int SLOTS, class TA = float>
 struct ConvLoader {           // implicit im2col of a channels-last [B][T][F][C] tensor, 3x3, pad 1
-  const float* p;
+  const TA* p;
   int T, F, C, rows;          // rows = B*T*F output pixels; K = 9*C ordered (kh, kw, c)
   int t_[SLOTS], f_[SLOTS];
   long base_[SLOTS];
   bool ok_[SLOTS];
+  typedef typename RawQuad<TA>::type Raw;
   __device__ __forceinline__ void init(int first_row) {
 #pragma unroll
     for (int i = 0; i < SLOTS; ++i) {
@@ -90,15 +94,15 @@ struct ConvLoader {           // implicit im2col of a channels-last [B][T][F][C]
       base_[i] = (long)r * C;
     }
   }
-  __device__ __forceinline__ float4 load(int slot, int kt) const {
+  __device__ __forceinline__ Raw load(int slot, int kt) const {
     const int kbase = kt * kBK;             // wave-uniform
     const int tap = kbase / C;              // C % 32 == 0: a k-tile never straddles taps
     const int c = kbase - tap * C + (threadIdx.x & 7) * 4;
     const int dt = tap / 3 - 1, df = tap % 3 - 1;
     const int tt = t_[slot] + dt, ff = f_[slot] + df;
     if (ok_[slot] && tt >= 0 && tt < T && ff >= 0 && ff < F)
-      return *reinterpret_cast<const float4*>(p + base_[slot] + (long)(dt * F + df) * C + c);
-    return make_float4(0.f, 0.f, 0.f, 0.f);
+      return ldraw(p + base_[slot] + (long)(dt * F + df) * C + c);
+    return zero_raw<Raw>();
   }
 };
 
@@ -185,6 +189,10 @@ __device__ __forceinline__ bf16x4 to_bf16x4(const float4& v) {     // RNE to the
   return o;
 }
 
+// the LDS image's four 16-bit operands of a raw quad: fp32 data is rounded (RNE); bf16 data is already there
+__device__ __forceinline__ bf16x4 to_half4(const float4& v) { return to_bf16x4(v); }
+__device__ __forceinline__ bf16x4 to_half4(const uint2& raw) { return __builtin_bit_cast(bf16x4, raw); }
+
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
 #ifdef PE_F16_BUILD
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
@@ -202,7 +210,8 @@ __device__ __forceinline__ void nt_mainloop_bf16(AL& al, BL& bl, int K, float* A
   const int wm = wv / TL::WAVES_N, wn = wv % TL::WAVES_N;
   const int r = lane & 31, h = lane >> 5;
   const int nk = (K + kBK - 1) / kBK;
-  float4 ra[TL::A_LOADS], rb[TL::B_LOADS];
+  decltype(al.load(0, 0)) ra[TL::A_LOADS];
+  decltype(bl.load(0, 0)) rb[TL::B_LOADS];
 #pragma unroll
   for (int i = 0; i < TL::A_LOADS; ++i) ra[i] = al.load(i, 0);
 #pragma unroll
@@ -216,10 +225,10 @@ __device__ __forceinline__ void nt_mainloop_bf16(AL& al, BL& bl, int K, float* A
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < TL::A_LOADS; ++i)
-      *reinterpret_cast<bf16x4*>(As + st_off + i * 32 * kLdsStrideH) = to_bf16x4(ra[i]);
+      *reinterpret_cast<bf16x4*>(As + st_off + i * 32 * kLdsStrideH) = to_half4(ra[i]);
 #pragma unroll
     for (int i = 0; i < TL::B_LOADS; ++i)
-      *reinterpret_cast<bf16x4*>(Bs + st_off + i * 32 * kLdsStrideH) = to_bf16x4(rb[i]);
+      *reinterpret_cast<bf16x4*>(Bs + st_off + i * 32 * kLdsStrideH) = to_half4(rb[i]);
     __syncthreads();
     if (kt + 1 < nk) {
 #pragma unroll
@@ -398,6 +407,14 @@ __device__ __forceinline__ void halo_store(__bf16* img, int img_elems, int row, 
   }
 }
 
+// the same for a quad that is still in its bf16 storage form: one rounded term needs no arithmetic at all
+template <int NT>
+__device__ __forceinline__ void halo_store(__bf16* img, int img_elems, int row, int piece, const uint2& raw,
+                                           float scale = 1.0f) {
+  if constexpr (NT == 1) *reinterpret_cast<uint2*>(img + swz_off(row, piece >> 1) + (piece & 1) * 4) = raw;
+  else halo_store<NT>(img, img_elems, row, piece, widen(raw), scale);
+}
+
 template <class TL, bool SW = false, int NT = 3, class AL, class BL>
 __device__ __forceinline__ void nt_mainloop_split(AL& al, BL& bl, int K, float* As_f, float* Bs_f,
                                                   f32x16 (&acc)[TL::TM][TL::TN], float sa = 1.0f, float sb = 1.0f) {
@@ -410,7 +427,8 @@ __device__ __forceinline__ void nt_mainloop_split(AL& al, BL& bl, int K, float* 
   const int wm = wv / TL::WAVES_N, wn = wv % TL::WAVES_N;
   const int r = lane & 31, h = lane >> 5;
   const int nk = (K + kBK - 1) / kBK;
-  float4 ra[TL::A_LOADS], rb[TL::B_LOADS];
+  decltype(al.load(0, 0)) ra[TL::A_LOADS];
+  decltype(bl.load(0, 0)) rb[TL::B_LOADS];
 #pragma unroll
   for (int i = 0; i < TL::A_LOADS; ++i) ra[i] = al.load(i, 0);
 #pragma unroll
@@ -514,17 +532,18 @@ struct TnGeom {
   __device__ static __forceinline__ int krow(int slot) { return threadIdx.x / TPR + ROWS * slot; }
 };
 
-template <int COLS>
+template <int COLS, class TA = float>
 struct KRowLoader {           // plain [K][cols] matrix
-  const float* p;
+  const TA* p;
   long ld;
   int cols;
   int col0;
+  typedef typename RawQuad<TA>::type Raw;
   __device__ __forceinline__ void init(int first_col, int /*k_begin*/) { col0 = first_col + TnGeom<COLS>::col4(); }
-  __device__ __forceinline__ float4 load(int slot, int k0, int k_end) const {
+  __device__ __forceinline__ Raw load(int slot, int k0, int k_end) const {
     const int k = k0 + TnGeom<COLS>::krow(slot);
-    if (k < k_end && col0 < cols) return *reinterpret_cast<const float4*>(p + (long)k * ld + col0);
-    return make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < k_end && col0 < cols) return ldraw(p + (long)k * ld + col0);
+    return zero_raw<Raw>();
   }
 };
 
@@ -674,6 +693,12 @@ __device__ __forceinline__ void tn_split_store(__bf16* img, int off, const float
   }
 }
 
+template <int COLS, int NT>
+__device__ __forceinline__ void tn_split_store(__bf16* img, int off, const uint2& raw, float scale = 1.0f) {
+  if constexpr (NT == 1) *reinterpret_cast<uint2*>(img + off) = raw;
+  else tn_split_store<COLS, NT>(img, off, widen(raw), scale);
+}
+
 template <int BM, int BN, int NT, class AL, class BL>
 __device__ __forceinline__ void tn_mainloop_split(AL& al, BL& bl, int k_begin, int k_end, float* As_f, float* Bs_f,
                                                   f32x16 (&acc)[BM / 64][BN / 64], float sa = 1.0f, float sb = 1.0f) {
@@ -686,7 +711,8 @@ __device__ __forceinline__ void tn_mainloop_split(AL& al, BL& bl, int k_begin, i
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm = wv >> 1, wn = wv & 1;
   const int h = lane >> 5, g1 = (lane >> 4) & 1, q = (lane & 15) >> 2, p4 = (lane & 3) * 4;
-  float4 ra[SA], rb[SB];
+  decltype(al.load(0, 0, 0)) ra[SA];
+  decltype(bl.load(0, 0, 0)) rb[SB];
 #pragma unroll
   for (int i = 0; i < SA; ++i) ra[i] = al.load(i, k_begin, k_end);
 #pragma unroll

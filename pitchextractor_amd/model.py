@@ -837,7 +837,7 @@ class JDCNet(nn.Module):
             raise ValueError("JDCNet geometry expects 80 mel bins (F/40 == 2)")
         s.bnp = _bn(self.pool_block[0], s.rb3, train, st3)
         pooled = ops.bn_act_pool_fwd(s.rb3, s.bnp, pool=4, slope=slope)            # [B,T,2,256]
-        s.concat = torch.empty((B, T, 2, 640), dtype=torch.float32, device=x.device)
+        s.concat = torch.empty((B, T, 2, 640), dtype=s.rb3.dtype, device=x.device)     # (bf16 under ops.ACT_BF16)
         p_blk = self.block_dropout if train else 0.0
         cslice = s.concat.view(-1, 640)[:, 384:640]
         _, s.mask_pool = _dropout(self.dropout_cfg, _flat2(pooled), p_blk, out2d=cslice)
@@ -912,7 +912,7 @@ class JDCNet(nn.Module):
 
         # detector branch (model.py:103-112)
         p_blk = self.block_dropout
-        d_ddrop = torch.empty((B, T, 2, 256), dtype=torch.float32, device=dev)
+        d_ddrop = torch.empty((B, T, 2, 256), dtype=s.concat.dtype, device=dev)
         ops.seq_to_nhwc(dseq_d, d_ddrop, 256)
         d_dact = _dropout_bwd(_flat2(d_ddrop), p_blk, s.mask_det).view(B, T, 2, 256)
         bn1 = self.detector_conv[1]
@@ -924,7 +924,7 @@ class JDCNet(nn.Module):
         d_concat = d_concat.view(B, T, 2, 640)
         # classifier branch joins at the pool_block output (channels 384..639 of the concat)
         ops.seq_to_nhwc(dseq_c, d_concat, 256, coff=384, accumulate=True)
-        d_pool = torch.empty((B, T, 2, 256), dtype=torch.float32, device=dev)
+        d_pool = torch.empty((B, T, 2, 256), dtype=s.concat.dtype, device=dev)
         _dropout_bwd(d_concat.view(-1, 640)[:, 384:640], p_blk if s.mask_pool is not None else 0.0, s.mask_pool,
                      out2d=_flat2(d_pool))
         bnp = self.pool_block[0]

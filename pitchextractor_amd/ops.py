@@ -35,9 +35,40 @@ def _dense(t: torch.Tensor, name: str) -> torch.Tensor:
     return t
 
 
-def _rows2d(t: torch.Tensor, name: str):
-    """(rows, cols, ld) of a 2-D row-major view whose rows may be strided."""
-    _f32c(t, name)
+# Mixed precision with bf16 ACTIVATION STORAGE (reference trainer.py:226-235 / README.md:36: autocast keeps conv and
+# linear outputs in 16 bits): when True (Trainer's mixed-precision scope with the bf16 dtype turns it on) the first
+# convolution writes a bf16 tensor and every pass of the conv stack follows the dtype of its inputs -- the `*_a16`
+# entry points of the C ABI.  The temporal heads, the losses and all parameters stay fp32.
+ACT_BF16 = False
+
+
+def act_dtype():
+    return torch.bfloat16 if (ACT_BF16 and MATMUL_BF16 and HALF_DTYPE == "bf16") else torch.float32
+
+
+def _actc(t: torch.Tensor, name: str) -> torch.Tensor:
+    """An activation tensor of the conv stack: float32, or bfloat16 under ``ACT_BF16``."""
+    _chk(t.is_cuda, f"{name}: expected a HIP device tensor (no CPU fallback)")
+    _chk(t.dtype in (torch.float32, torch.bfloat16), f"{name}: expected float32 or bfloat16")
+    return t
+
+
+def _actd(t: torch.Tensor, name: str) -> torch.Tensor:
+    _actc(t, name)
+    _chk(t.is_contiguous(), f"{name}: expected a contiguous tensor")
+    return t
+
+
+def _a16(*tensors) -> str:
+    """"_a16" if the given activation tensors are bfloat16, "" if float32; mixing is an error."""
+    kinds = {t.dtype for t in tensors if t is not None}
+    _chk(len(kinds) == 1, "activation tensors of one call must share a dtype")
+    return "_a16" if kinds.pop() == torch.bfloat16 else ""
+
+
+def _rows2d(t: torch.Tensor, name: str, act=False):
+    """(rows, cols, ld) of a 2-D row-major view whose rows may be strided (``act``: bf16 activations allowed)."""
+    (_actc if act else _f32c)(t, name)
     _chk(t.dim() == 2 and t.stride(1) == 1, f"{name}: expected 2-D with unit column stride")
     ld = t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
     return t.shape[0], t.shape[1], ld
@@ -245,21 +276,24 @@ def _nt_suffix():
 
 
 class matmul_bf16:
-    """``with ops.matmul_bf16(True): ...`` -- the autocast-like scope Trainer.run opens for a mixed-precision step."""
+    """``with ops.matmul_bf16(True): ...`` -- the autocast-like scope Trainer.run opens for a mixed-precision step.
+    ``act16=True`` (bf16 only) additionally stores the conv stack's activations and their gradients as bf16 tensors
+    (``ACT_BF16``)."""
 
-    def __init__(self, enabled=True, dtype="bf16"):
+    def __init__(self, enabled=True, dtype="bf16", act16=False):
         _chk(dtype in ("bf16", "f16"), "matmul_bf16: dtype must be 'bf16' or 'f16'")
         self.enabled, self.dtype = bool(enabled), dtype
+        self.act16 = bool(act16) and self.enabled and dtype == "bf16"
 
     def __enter__(self):
-        global MATMUL_BF16, HALF_DTYPE
-        self._prev = (MATMUL_BF16, HALF_DTYPE)
-        MATMUL_BF16, HALF_DTYPE = self.enabled, self.dtype
+        global MATMUL_BF16, HALF_DTYPE, ACT_BF16
+        self._prev = (MATMUL_BF16, HALF_DTYPE, ACT_BF16)
+        MATMUL_BF16, HALF_DTYPE, ACT_BF16 = self.enabled, self.dtype, self.act16
         return self
 
     def __exit__(self, *exc):
-        global MATMUL_BF16, HALF_DTYPE
-        MATMUL_BF16, HALF_DTYPE = self._prev
+        global MATMUL_BF16, HALF_DTYPE, ACT_BF16
+        MATMUL_BF16, HALF_DTYPE, ACT_BF16 = self._prev
         return False
 
 
@@ -274,14 +308,20 @@ GEMM_WFRAG = os.environ.get("PE_GEMM_WFRAG", "0") == "1"
 def gemm_nt(A, B, bias0=None, bias1=None, out=None, accumulate=False, amax_a=None, amax_b=None):
     """out[M,N] = A[M,K] @ B[N,K]^T + bias0 + bias1 (+ out).  ``amax_*``: the operands' absmax words when the caller
     already has them ("h2" mode; computed here otherwise)."""
-    M, K, lda = _rows2d(A, "A")
+    M, K, lda = _rows2d(A, "A", act=True)
     N, K2, ldb = _rows2d(B, "B")
     _chk(K == K2, "gemm_nt: K mismatch")
     if out is None:
         _chk(not accumulate, "accumulate needs out")
-        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
-    Mo, No, ldc = _rows2d(out, "out")
+        out = torch.empty((M, N), dtype=A.dtype, device=A.device)
+    Mo, No, ldc = _rows2d(out, "out", act=True)
     _chk((Mo, No) == (M, N), "gemm_nt: out shape")
+    a16 = _a16(A, out)
+    if a16:
+        _chk(_nt_suffix() == "_bf16", "bfloat16 activations need the bf16 mixed-precision mode")
+        _call("pe_gemm_nt_bf16_a16", A.data_ptr(), lda, B.data_ptr(), ldb, out.data_ptr(), ldc, M, N, K,
+              _lib.ptr(bias0), _lib.ptr(bias1), int(bool(accumulate)), _s(), work=2.0 * M * N * K)
+        return out
     for b in (bias0, bias1):
         if b is not None:
             _chk(_dense(b, "bias").numel() == N, "bias size")
@@ -306,8 +346,8 @@ def gemm_nt(A, B, bias0=None, bias1=None, out=None, accumulate=False, amax_a=Non
 
 def gemm_tn(A, B, out=None, accumulate=False, amax_a=None, amax_b=None):
     """out[M,N] = A[K,M]^T @ B[K,N] (+ out); deterministic split-K."""
-    K, M, lda = _rows2d(A, "A")
-    K2, N, ldb = _rows2d(B, "B")
+    K, M, lda = _rows2d(A, "A", act=True)
+    K2, N, ldb = _rows2d(B, "B", act=True)
     _chk(K == K2, "gemm_tn: K mismatch")
     if out is None:
         _chk(not accumulate, "accumulate needs out")
@@ -317,6 +357,11 @@ def gemm_tn(A, B, out=None, accumulate=False, amax_a=None, amax_b=None):
     lib = _lib.load()
     need = lib.pe_gemm_tn_workspace_bytes(M, N, K)
     ws = workspace(need, A.device)
+    if _a16(A, B):
+        _chk(_tn_suffix() == "_bf16", "bfloat16 activations need the bf16 mixed-precision mode")
+        _call("pe_gemm_tn_bf16_a16", A.data_ptr(), lda, B.data_ptr(), ldb, out.data_ptr(), ldc, M, N, K,
+              int(bool(accumulate)), ws.data_ptr(), ws.numel(), _s(), work=2.0 * M * N * K)
+        return out
     if _tn_suffix() == "_h2":
         amax_a = absmax(A) if amax_a is None else amax_a
         amax_b = absmax(B) if amax_b is None else amax_b
@@ -412,7 +457,7 @@ def conv3x3_fwd(x, w_packed, out=None, accumulate=False, bn_stats=None, amax=Non
     ``bn_stats`` True / False (not None) returns (y, partials): with True the fragment-fed kernel leaves the BatchNorm
     column sums of its final outputs behind ([tiles, 2, N] float64, for ``bn_train_stats(..., partials=)``);
     partials is None when not asked for or when another kernel ran."""
-    x = _dense(x, "x")
+    x = _actd(x, "x")
     pw = w_packed if isinstance(w_packed, PackedWeight) else PackedWeight(w_packed)
     w32 = _dense(pw.fp32, "w_packed")
     _chk(x.dim() == 4 and w32.dim() == 2, "conv3x3_fwd: ranks")
@@ -421,9 +466,12 @@ def conv3x3_fwd(x, w_packed, out=None, accumulate=False, bn_stats=None, amax=Non
     _chk(w32.shape[1] == 9 * Cc, "conv3x3_fwd: weight K")
     if out is None:
         _chk(not accumulate, "accumulate needs out")
-        out = torch.empty((B, T, F, N), dtype=torch.float32, device=x.device)
-    _chk(_dense(out, "out").shape == (B, T, F, N), "conv3x3_fwd: out shape")
+        out = torch.empty((B, T, F, N), dtype=x.dtype, device=x.device)
+    _chk(_actd(out, "out").shape == (B, T, F, N), "conv3x3_fwd: out shape")
+    a16 = _a16(x, out)
     sfx = _nt_suffix()
+    _chk(not a16 or sfx == "_bf16", "bfloat16 activations need the bf16 mixed-precision mode")
+    sfx += a16
     h2 = ()
     if sfx == "_h2":
         amax_w = pw.amax if pw.amax is not None else absmax(w32)
@@ -444,12 +492,18 @@ def conv3x3_fwd(x, w_packed, out=None, accumulate=False, bn_stats=None, amax=Non
 
 def conv3x3_wgrad(x, dy, dw, amax_x=None, amax_dy=None):
     """dw (OIHW view, contiguous) = grad of conv3x3 wrt weights."""
-    x = _dense(x, "x")
-    dy = _dense(dy, "dy")
+    x = _actd(x, "x")
+    dy = _actd(dy, "dy")
     dw = _dense(dw, "dw")
     B, T, F, Ci = x.shape
     Co = dy.shape[3]
     _chk(dy.shape[:3] == (B, T, F), "conv3x3_wgrad: dy shape")
+    if _a16(x, dy):
+        _chk(_tn_suffix() == "_bf16", "bfloat16 activations need the bf16 mixed-precision mode")
+        ws = workspace(_lib.load().pe_conv3x3_wgrad_workspace_bytes(B, T, F, Ci, Co), x.device)
+        _call("pe_conv3x3_wgrad_bf16_a16", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, T, F, Ci, Co, ws.data_ptr(),
+              ws.numel(), _s(), work=2.0 * B * T * F * Co * 9 * Ci)
+        return dw
     _chk(dw.shape == (Co, Ci, 3, 3), "conv3x3_wgrad: dw shape")
     lib = _lib.load()
     ws = workspace(lib.pe_conv3x3_wgrad_workspace_bytes(B, T, F, Ci, Co), x.device)
@@ -476,25 +530,25 @@ def conv3x3_c1_fwd(x_btf, w, out=None, bn_stats=None):
     w = _dense(w, "w")
     _chk(w.shape == (64, 1, 3, 3), "first conv is 1 -> 64")
     if out is None:
-        out = torch.empty((B, T, F, 64), dtype=torch.float32, device=x_btf.device)
-    _chk(_dense(out, "out").shape == (B, T, F, 64), "conv3x3_c1_fwd: out shape")
+        out = torch.empty((B, T, F, 64), dtype=act_dtype(), device=x_btf.device)
+    _chk(_actd(out, "out").shape == (B, T, F, 64), "conv3x3_c1_fwd: out shape")
     parts = None
     if bn_stats:
         parts = torch.empty((_lib.load().pe_conv3x3_c1_stat_parts(B, T, F), 2, 64), dtype=torch.float64,
                             device=x_btf.device)
-    _call("pe_conv3x3_c1_fwd", x_btf.data_ptr(), sb, st, sf, w.data_ptr(), out.data_ptr(), B, T, F, _lib.ptr(parts),
+    _call("pe_conv3x3_c1_fwd" + _a16(out), x_btf.data_ptr(), sb, st, sf, w.data_ptr(), out.data_ptr(), B, T, F, _lib.ptr(parts),
           _s())
     return out if bn_stats is None else (out, parts)
 
 
 def conv3x3_c1_wgrad(x_btf, dy, dw):
     (B, T, F), (sb, st, sf) = _btf_view(x_btf)
-    dy = _dense(dy, "dy")
+    dy = _actd(dy, "dy")
     dw = _dense(dw, "dw")
     _chk(dy.shape == (B, T, F, 64) and dw.shape == (64, 1, 3, 3), "conv3x3_c1_wgrad: shapes")
     lib = _lib.load()
     ws = workspace(lib.pe_conv3x3_wgrad_workspace_bytes(B, T, F, 1, 64), dy.device)
-    _call("pe_conv3x3_c1_wgrad", x_btf.data_ptr(), sb, st, sf, dy.data_ptr(), dw.data_ptr(), B, T, F,
+    _call("pe_conv3x3_c1_wgrad" + _a16(dy), x_btf.data_ptr(), sb, st, sf, dy.data_ptr(), dw.data_ptr(), B, T, F,
           ws.data_ptr(), ws.numel(), _s())
     return dw
 
@@ -511,7 +565,7 @@ class BnState:
 def bn_train_stats(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1, partials=None):
     """Train-mode BatchNorm statistics of x [.., C].  ``partials`` ([parts, 2, C] float64 column sums / sums of
     squares left behind by the kernel that produced x) skips the pass over x."""
-    x = _dense(x, "x")
+    x = _actd(x, "x")
     Cc = x.shape[-1]
     for t, n in ((gamma, "gamma"), (beta, "beta"), (running_mean, "running_mean"), (running_var, "running_var")):
         if t is not None:
@@ -527,7 +581,7 @@ def bn_train_stats(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum
               st.invstd.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), ws.data_ptr(), ws.numel(), _s())
         return st
     ws = workspace(lib.pe_bn_workspace_bytes(Cc), x.device)
-    _call("pe_bn_train_stats", x.data_ptr(), x.numel() // Cc, Cc, gamma.data_ptr(), beta.data_ptr(), eps, momentum,
+    _call("pe_bn_train_stats" + _a16(x), x.data_ptr(), x.numel() // Cc, Cc, gamma.data_ptr(), beta.data_ptr(), eps, momentum,
           _lib.ptr(running_mean), _lib.ptr(running_var), st.mean.data_ptr(), st.invstd.data_ptr(),
           st.scale.data_ptr(), st.shift.data_ptr(), ws.data_ptr(), ws.numel(), _s())
     return st
@@ -545,7 +599,7 @@ def bn_eval_affine(gamma, beta, running_mean, running_var, eps=1e-5):
 
 def _slice_target(out, B, T, Fo, Cc, coff):
     """out is a dense [B,T,Fo,Ctot] tensor; we write channels [coff, coff+C)."""
-    _dense(out, "out")
+    _actd(out, "out")
     _chk(out.dim() == 4 and out.shape[:3] == (B, T, Fo), "output pixel grid mismatch")
     ld = out.shape[3]
     _chk(0 <= coff and coff + Cc <= ld, "channel slice out of range")
@@ -554,27 +608,36 @@ def _slice_target(out, B, T, Fo, Cc, coff):
 
 def bn_act_pool_fwd(x, st: BnState, pool=1, slope=0.01, out=None, coff=0, amax_out=None):
     """``amax_out``: a zeroed word from ``amax_word()``; the pass leaves the absmax of its output there."""
-    x = _dense(x, "x")
+    x = _actd(x, "x")
     B, T, F, Cc = x.shape
     Fo = F // pool
     if out is None:
-        out = torch.empty((B, T, Fo, Cc), dtype=torch.float32, device=x.device)
+        out = torch.empty((B, T, Fo, Cc), dtype=x.dtype, device=x.device)
     ld = _slice_target(out, B, T, Fo, Cc, coff)
+    if _a16(x, out):
+        _call("pe_bn_act_pool_fwd_a16", x.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), slope, out.data_ptr(),
+              B * T, F, Cc, pool, ld, coff, _s())
+        return out
     _call("pe_bn_act_pool_fwd", x.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), slope, out.data_ptr(),
           B * T, F, Cc, pool, ld, coff, _lib.ptr(amax_out), _s())
     return out
 
 
 def bn_act_pool_bwd(x, dy, st: BnState, dgamma, dbeta, pool=1, slope=0.01, coff=0, dx=None, amax_out=None):
-    x = _dense(x, "x")
+    x = _actd(x, "x")
     B, T, F, Cc = x.shape
     ld = _slice_target(dy, B, T, F // pool, Cc, coff)
     if dx is None:
         dx = torch.empty_like(x)
-    _chk(_dense(dx, "dx").shape == x.shape, "dx shape")
+    _chk(_actd(dx, "dx").shape == x.shape, "dx shape")
     _chk(_dense(dgamma, "dgamma").numel() == Cc and _dense(dbeta, "dbeta").numel() == Cc, "dgamma/dbeta size")
     lib = _lib.load()
     ws = workspace(lib.pe_bn_workspace_bytes(Cc) + 8 * Cc, x.device)
+    if _a16(x, dy, dx):
+        _call("pe_bn_act_pool_bwd_a16", x.data_ptr(), dy.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(),
+              st.mean.data_ptr(), st.invstd.data_ptr(), slope, dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+              B * T, F, Cc, pool, ld, coff, ws.data_ptr(), ws.numel(), _s())
+        return dx
     _call("pe_bn_act_pool_bwd", x.data_ptr(), dy.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(),
           st.mean.data_ptr(), st.invstd.data_ptr(), slope, dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
           B * T, F, Cc, pool, ld, coff, ws.data_ptr(), ws.numel(), _lib.ptr(amax_out), _s())
@@ -584,14 +647,14 @@ def bn_act_pool_bwd(x, dy, st: BnState, dgamma, dbeta, pool=1, slope=0.01, coff=
 def maxpool_fwd(x, pool, out=None, coff=0, want_argmax=False):
     """MaxPool2d((1, pool)) into a channel slice.  ``want_argmax``: also return the uint8 window positions of the
     maxima ([B, T, F // pool, C]) for ``maxpool_bwd_add(argmax=...)``: returns (out, argmax)."""
-    x = _dense(x, "x")
+    x = _actd(x, "x")
     B, T, F, Cc = x.shape
     Fo = F // pool
     if out is None:
-        out = torch.empty((B, T, Fo, Cc), dtype=torch.float32, device=x.device)
+        out = torch.empty((B, T, Fo, Cc), dtype=x.dtype, device=x.device)
     ld = _slice_target(out, B, T, Fo, Cc, coff)
     arg = torch.empty((B, T, Fo, Cc), dtype=torch.uint8, device=x.device) if want_argmax else None
-    _call("pe_maxpool_fwd", x.data_ptr(), out.data_ptr(), B * T, F, Cc, pool, ld, coff, _lib.ptr(arg), _s())
+    _call("pe_maxpool_fwd" + _a16(x, out), x.data_ptr(), out.data_ptr(), B * T, F, Cc, pool, ld, coff, _lib.ptr(arg), _s())
     return (out, arg) if want_argmax else out
 
 
@@ -599,12 +662,16 @@ def maxpool_bwd_add(x, dy, dx, pool, coff=0, amax_out=None, argmax=None):
     """dx[first maximum of each window] += dy.  With ``argmax`` (from ``maxpool_fwd``) x is only used for its shape."""
     B, T, F, Cc = x.shape
     if argmax is None:
-        x = _dense(x, "x")
+        x = _actd(x, "x")
     else:
         _chk(argmax.is_cuda and argmax.dtype == torch.uint8 and argmax.is_contiguous()
              and argmax.shape == (B, T, F // pool, Cc), "maxpool_bwd_add: argmax shape")
     ld = _slice_target(dy, B, T, F // pool, Cc, coff)
-    _chk(_dense(dx, "dx").shape == x.shape, "dx shape")
+    _chk(_actd(dx, "dx").shape == x.shape, "dx shape")
+    if _a16(dy, dx, x if argmax is None else None):
+        _call("pe_maxpool_bwd_add_a16", x.data_ptr() if argmax is None else 0, _lib.ptr(argmax), dy.data_ptr(),
+              dx.data_ptr(), B * T, F, Cc, pool, ld, coff, _s())
+        return dx
     _call("pe_maxpool_bwd_add", x.data_ptr() if argmax is None else 0, _lib.ptr(argmax), dy.data_ptr(), dx.data_ptr(),
           B * T, F, Cc, pool, ld, coff, _lib.ptr(amax_out), _s())
     return dx
@@ -612,10 +679,10 @@ def maxpool_bwd_add(x, dy, dx, pool, coff=0, amax_out=None, argmax=None):
 
 def dropout(x2d, p, out2d=None, mask_in=None, want_mask=True, seed=0, offset=0):
     """Row-strided 2-D dropout.  Returns (out, mask uint8 [rows, cols] or None)."""
-    rows, cols, ldx = _rows2d(x2d, "x")
+    rows, cols, ldx = _rows2d(x2d, "x", act=True)
     if out2d is None:
-        out2d = torch.empty((rows, cols), dtype=torch.float32, device=x2d.device)
-    r2, c2, ldy = _rows2d(out2d, "out")
+        out2d = torch.empty((rows, cols), dtype=x2d.dtype, device=x2d.device)
+    r2, c2, ldy = _rows2d(out2d, "out", act=True)
     _chk((r2, c2) == (rows, cols), "dropout: out shape")
     mask_out = None
     if mask_in is not None:
@@ -623,37 +690,37 @@ def dropout(x2d, p, out2d=None, mask_in=None, want_mask=True, seed=0, offset=0):
              and mask_in.numel() == rows * cols, "dropout: mask_in")
     elif want_mask:
         mask_out = torch.empty((rows, cols), dtype=torch.uint8, device=x2d.device)
-    _call("pe_dropout_fwd", x2d.data_ptr(), ldx, out2d.data_ptr(), ldy, _lib.ptr(mask_in), _lib.ptr(mask_out),
+    _call("pe_dropout_fwd" + _a16(x2d, out2d), x2d.data_ptr(), ldx, out2d.data_ptr(), ldy, _lib.ptr(mask_in), _lib.ptr(mask_out),
           rows, cols, float(p), int(seed), int(offset), _s())
     return out2d, (mask_in if mask_in is not None else mask_out)
 
 
 def nhwc_to_seq(x, Cc, coff=0, out=None):
     """x dense [B,T,2,Ctot] (channels [coff,coff+C)) -> seq [B,T,2C] with feature c*2+w."""
-    x = _dense(x, "x")
+    x = _actd(x, "x")
     B, T, two, ld = x.shape
     _chk(two == 2 and coff + Cc <= ld, "nhwc_to_seq: shape")
     if out is None:
         out = torch.empty((B, T, 2 * Cc), dtype=torch.float32, device=x.device)
-    _chk(_dense(out, "out").shape == (B, T, 2 * Cc), "nhwc_to_seq: out shape")
-    _call("pe_nhwc_to_seq", x.data_ptr(), ld, coff, out.data_ptr(), B * T, Cc, _s())
+    _chk(_dense(out, "out").shape == (B, T, 2 * Cc), "nhwc_to_seq: out shape")       # the temporal heads read fp32
+    _call("pe_nhwc_to_seq" + _a16(x), x.data_ptr(), ld, coff, out.data_ptr(), B * T, Cc, _s())
     return out
 
 
 def seq_to_nhwc(seq, out, Cc, coff=0, accumulate=False):
     seq = _dense(seq, "seq")
-    out = _dense(out, "out")
+    out = _actd(out, "out")
     B, T, two, ld = out.shape
     _chk(two == 2 and coff + Cc <= ld and seq.shape == (B, T, 2 * Cc), "seq_to_nhwc: shape")
-    _call("pe_seq_to_nhwc", seq.data_ptr(), out.data_ptr(), ld, coff, B * T, Cc, int(bool(accumulate)), _s())
+    _call("pe_seq_to_nhwc" + _a16(out), seq.data_ptr(), out.data_ptr(), ld, coff, B * T, Cc, int(bool(accumulate)), _s())
     return out
 
 
 def copy2d(src2d, dst2d, accumulate=False):
-    r, c, lds = _rows2d(src2d, "src")
-    r2, c2, ldd = _rows2d(dst2d, "dst")
+    r, c, lds = _rows2d(src2d, "src", act=True)
+    r2, c2, ldd = _rows2d(dst2d, "dst", act=True)
     _chk((r, c) == (r2, c2), "copy2d: shape")
-    _call("pe_copy2d", src2d.data_ptr(), lds, dst2d.data_ptr(), ldd, r, c, int(bool(accumulate)), _s())
+    _call("pe_copy2d" + _a16(src2d, dst2d), src2d.data_ptr(), lds, dst2d.data_ptr(), ldd, r, c, int(bool(accumulate)), _s())
     return dst2d
 
 

@@ -75,7 +75,8 @@ class Trainer(object):
     def __init__(self, model=None, criterion=None, optimizer=None, scheduler=None, config={}, loss_config={},
                  device=torch.device("cpu"), logger=logger, train_dataloader=None, val_dataloader=None,
                  initial_steps=0, initial_epochs=0, use_mixed_precision=False, gradient_checkpointing=False,
-                 checkpoint_use_reentrant=None, mel_transform=None, data_parallel=None, amp_dtype="bf16"):
+                 checkpoint_use_reentrant=None, mel_transform=None, data_parallel=None, amp_dtype="bf16",
+                 activation_storage=None):
         kind = torch.device(device).type if isinstance(device, (str, torch.device)) else "cpu"
         if kind != "cuda":
             raise RuntimeError("pitchextractor_amd.Trainer runs the HIP path only: device must be a HIP "
@@ -107,6 +108,15 @@ class Trainer(object):
             raise ValueError("amp_dtype must be 'bf16' or 'fp16'")
         self.amp_dtype = amp_dtype
         self.scaler = GradScaler() if (self.use_amp and amp_dtype == "f16") else None
+        # activation_storage: "bf16" keeps the conv stack's activations and their gradients as bf16 tensors in HBM,
+        # as autocast keeps conv outputs in half precision (trainer.py:226-235, README.md:36: the VRAM saving);
+        # "fp32" rounds MFMA operands only.  Default: bf16 with bf16 mixed precision, fp32 otherwise.
+        if activation_storage is None:
+            activation_storage = os.environ.get("PE_ACT_STORAGE") or ("bf16" if (self.use_amp and amp_dtype == "bf16")
+                                                                      else "fp32")
+        if activation_storage not in ("bf16", "fp32"):
+            raise ValueError("activation_storage must be 'bf16' or 'fp32'")
+        self.act16 = activation_storage == "bf16" and self.use_amp and amp_dtype == "bf16"
         self.gradient_checkpointing = bool(gradient_checkpointing)
         self.gradient_checkpoint_use_reentrant = checkpoint_use_reentrant
         if self.use_amp:
@@ -206,7 +216,7 @@ class Trainer(object):
                                sil.reshape(-1), lam, grad_scale, want_grads)
 
     def _forward_backward(self, x, f0, sil):
-        with ops.matmul_bf16(self.use_amp, self.amp_dtype):
+        with ops.matmul_bf16(self.use_amp, self.amp_dtype, self.act16):
             self.model.checkpoint_forward = self.gradient_checkpointing
             try:
                 f0_pred, sil_pred = self.model(x.transpose(-1, -2))
@@ -318,7 +328,7 @@ class Trainer(object):
     @torch.no_grad()
     def _eval_step(self, batch):
         x, f0, sil = self._inputs(batch)
-        with ops.matmul_bf16(self.use_amp, self.amp_dtype):
+        with ops.matmul_bf16(self.use_amp, self.amp_dtype, self.act16):
             f0_pred, sil_pred = self.model(x.transpose(-1, -2))
         out3, _, _ = self._loss(f0_pred, sil_pred, f0, sil, False)
         word = ops.persistent_lstm_error_word(x.device)        # this rank's word only: no collective in evaluation
@@ -327,7 +337,7 @@ class Trainer(object):
             return {"loss": loss, "f0": loss_f0, "sil": loss_sil}
         loss, loss_f0, loss_sil, fault = torch.cat([out3, word.float()]).tolist()     # one device->host copy
         if fault != 0.0 and self._lstm_fault(x.device, collective=False):
-            with ops.matmul_bf16(self.use_amp, self.amp_dtype):
+            with ops.matmul_bf16(self.use_amp, self.amp_dtype, self.act16):
                 f0_pred, sil_pred = self.model(x.transpose(-1, -2))
             out3, _, _ = self._loss(f0_pred, sil_pred, f0, sil, False)
             loss, loss_f0, loss_sil = out3.tolist()

@@ -77,11 +77,11 @@ def _worker(rank, world, port, out_dir, amp=False, payload=None):
         for r in range(world):
             n2, _, _ = _make(state, dev)
             x, f0, sil = _batch(r, dev)
-            with ops.matmul_bf16(amp, "bf16"):
+            with ops.matmul_bf16(amp, "bf16", act16=amp):          # (the trainer stores bf16 activations in this mode)
                 cls, det = n2(x.transpose(-1, -2))
             _, d_f0, d_sil = ops.f0_sil_loss(cls.detach().reshape(-1), f0.reshape(-1), det.detach().reshape(-1),
                                              sil.reshape(-1), 0.1)
-            with ops.matmul_bf16(amp, "bf16"):
+            with ops.matmul_bf16(amp, "bf16", act16=amp):          # (the trainer stores bf16 activations in this mode)
                 torch.autograd.backward([cls, det], [d_f0.view_as(cls), d_sil.view_as(det)])
             grads.append(n2.flat_gradients().clone())
         ref, ropt, _ = _make(state, dev)

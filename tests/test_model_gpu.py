@@ -303,15 +303,20 @@ def test_full_size_training_step_matches_oracle_by_tiling(hip_device, oracle_b8,
     assert not bad, bad
 
 
-def test_full_size_mixed_precision_step_by_tiling(hip_device, oracle_b8, dtype="bf16"):
+@pytest.mark.parametrize("act16", [False, True])
+def test_full_size_mixed_precision_step_by_tiling(hip_device, oracle_b8, act16, dtype="bf16"):
     """BASELINE config[3]'s per-GPU shape (B = 256, default BiLSTM, 16-bit operands: the shipped config.yml's
     `mixed_precision: true`, `precision: bf16`): the same tiling argument with the mixed-precision kernels -- bf16 conv,
     GEMM and weight-gradient products and the 16-bit persistent recurrences on the full 192-workgroup grid.  Both runs
     round their operands alike, so only summation orders differ: gradients within 1e-4 of the B = 8 run's largest
-    element (measured 3.7e-6).  (fp16 operands are not comparable this way without the GradScaler: the per-element
+    element (measured 3.7e-6).  The same bound holds with bf16 ACTIVATION STORAGE (act16, the trainer's default in this
+    mode; measured 9.2e-7): per-sample sums run in the same order at both batch sizes, so the stored bf16 values are
+    the same and only the batch-level reductions differ.
+    (fp16 operands are not comparable this way without the GradScaler: the per-element
     loss gradient is 32x smaller at B = 256 and underflows differently; that mode has its own test.)"""
     state, x8, f0, sil, (_, _, ref_loss, _) = oracle_b8
-    with ops.matmul_bf16(True, dtype):
+    tol_out, tol_g = 1e-4, 1e-4
+    with ops.matmul_bf16(True, dtype, act16=act16):
         cls8, det8, loss8, g8 = _hip_step_grads(state, x8, f0, sil, hip_device)
         cls, det, loss, g = _hip_step_grads(state, x8.repeat(32, 1, 1, 1), f0.repeat(32, 1), sil.repeat(32, 1),
                                             hip_device)
@@ -319,15 +324,15 @@ def test_full_size_mixed_precision_step_by_tiling(hip_device, oracle_b8, dtype="
     assert abs(loss8 - ref_loss) <= 2e-2 * abs(ref_loss)            # 16-bit operands vs the float64 oracle
     assert abs(loss - loss8) <= 1e-6 * abs(loss8)
     for r in (0, 13, 31):
-        assert (cls[8 * r:8 * r + 8] - cls8).abs().max().item() <= 1e-4 * cls8.abs().max().item()
-        assert (det[8 * r:8 * r + 8] - det8).abs().max().item() <= 1e-4 * det8.abs().max().item()
+        assert (cls[8 * r:8 * r + 8] - cls8).abs().max().item() <= tol_out * cls8.abs().max().item()
+        assert (det[8 * r:8 * r + 8] - det8).abs().max().item() <= tol_out * det8.abs().max().item()
     ratios = sorted(((g[n] - g8[n]).abs().max().item() / (g8[n].abs().max().item() + 1e-30), n,
                      g8[n].abs().max().item()) for n in g)
     print("worst five:", [(n, f"{r:.2e}", f"top {t:.2e}") for r, n, t in ratios[-5:]])
     worst = ratios[-1][0]
-    print(f"{dtype}: loss {loss:.6f} (B=8 {loss8:.6f}, float64 fp32-model oracle {ref_loss:.6f}); worst gradient element "
-          f"error / tensor max = {worst:.2e}")
-    assert worst <= 1e-4
+    print(f"{dtype} (bf16 activation storage: {act16}): loss {loss:.6f} (B=8 {loss8:.6f}, float64 fp32-model oracle "
+          f"{ref_loss:.6f}); worst gradient element error / tensor max = {worst:.2e}")
+    assert worst <= tol_g
 
 
 def test_side_stream_weight_gradients_change_nothing(hip_device, oracle_b8, monkeypatch):

@@ -278,22 +278,24 @@ def test_weight_fragment_pack_layout(hip_device):
 
 @pytest.mark.parametrize("B,T,Fq,Ci,Co", [(3, 16, 40, 128, 128), (2, 5, 20, 128, 192), (1, 3, 80, 64, 64),
                                           (1, 6, 10, 192, 256), (2, 7, 40, 128, 64)])
-@pytest.mark.parametrize("bf16", [False, True])
-def test_conv3x3_fragment_fed_kernel_is_bit_identical(hip_device, B, T, Fq, Ci, Co, bf16, monkeypatch):
-    """The kernel that takes its weight operands as pre-packed fragments from L2 issues the same MFMAs on the same
-    operand bits in the same order as the one that stages weight slabs through LDS: equal outputs, bit for bit."""
-    monkeypatch.setattr(ops, "FP32_MATMUL", "x3")
+@pytest.mark.parametrize("mode", ["h2", "x3", "bf16"])
+def test_conv3x3_fragment_fed_kernel_matches_implicit_gemm(hip_device, B, T, Fq, Ci, Co, mode, monkeypatch):
+    """The halo-staged kernel (weights as pre-packed MFMA fragments from L2) and the implicit-GEMM kernel (im2col
+    gathered on the fly, weights through LDS) multiply the same operand terms; they differ only in the order the k
+    (tap, channel) blocks are summed, so outputs agree to fp32 accumulation accuracy, forward and data gradient."""
+    monkeypatch.setattr(ops, "FP32_MATMUL", mode if mode != "bf16" else "x3")
     x = nhwc(rnd(B, Ci, T, Fq, seed=1)).to(hip_device)
     w = rnd(Co, Ci, 3, 3, seed=2, scale=0.1).to(hip_device)
     outs = {}
     for frag in (True, False):
         monkeypatch.setattr(ops, "CONV_WFRAG", frag)
-        with ops.matmul_bf16(bf16):
+        with ops.matmul_bf16(mode == "bf16"):
             wf, wd = ops.conv3x3_repack(w)
             assert (wf.frag is not None) == frag
             y = ops.conv3x3_fwd(x, wf)
             outs[frag] = (y, ops.conv3x3_fwd(y, wd))
-    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
+    for a, b in zip(outs[True], outs[False]):
+        assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item()
 
 
 @pytest.mark.parametrize("B,T,Fq,Ci,Co,acc", [(3, 16, 40, 128, 128, False), (2, 5, 20, 128, 192, True), (1, 3, 80, 64, 64, False),
