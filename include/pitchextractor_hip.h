@@ -42,6 +42,9 @@ extern "C" {
 int pe_abi_version(void);
 /* number of HIP devices visible, or negative hipError_t */
 int pe_device_count(void);
+/* *stream_out = a new non-blocking stream of the current device at its lowest priority (side work that must not
+ * compete with the critical chain); created in this library's HIP runtime, owned by the caller. */
+int pe_stream_create_low_priority(void** stream_out);
 
 /* ---- mel front end ---------------------------------------------------------
  * Replaces MelDataset.to_melspec = torchaudio.transforms.MelSpectrogram(
@@ -110,21 +113,6 @@ int pe_absmax(const float* x, long rows, int cols, long ld, unsigned* out, void*
  * arrays; every parameter of a model that lives in one flat buffer). */
 int pe_absmax_segments(const float* base, const long* seg_off, const long* seg_len, int nseg, unsigned* out,
                        void* stream);
-/* pe_gemm_nt_wf_*: the same product with B given as pe_wfrag_pack(B, ldb, N, K, terms) (see the convolution
- * section): the weight operand comes from L2 in MFMA fragment order, only A is staged through LDS. */
-int pe_gemm_nt_wf_x3(const float* A, long lda, const void* wfrag, float* C, long ldc, int M, int N, int K,
-                     const float* bias0, const float* bias1, int accumulate, void* stream);
-int pe_gemm_nt_wf_bf16(const float* A, long lda, const void* wfrag, float* C, long ldc, int M, int N, int K,
-                       const float* bias0, const float* bias1, int accumulate, void* stream);
-/* Diagnostic only (tools/ablate_gemm.py): pe_gemm_nt_wf_x3's 128 x 192 kernel with parts of its loop removed
- * (mask bits: 1 weight loads, 2 A split + LDS store, 4 A global loads, 8 epilogue, 16 barrier, 32 A LDS reads);
- * the output is meaningless for mask != 0. */
-int pe_gemm_nt_wf_ablate(int mask, const float* A, long lda, const void* wfrag, float* C, long ldc, int M, int N,
-                         int K, void* stream);
-/* pe_gemm_nt_x3 variant selection: 1 routes eligible shapes (N % 128 == 0, K % 32 == 0, K >= 256, M >= 256) to the
- * software-pipelined 256 x 128 kernel (one workgroup per CU; bit-identical results), 0 keeps the two-workgroup
- * kernels.  Default 0 unless PE_GEMM_NT_PIPE=1 is in the environment.  Returns the previous setting. */
-int pe_gemm_nt_pipeline(int enable);
 size_t pe_gemm_tn_workspace_bytes(int M, int N, int K);
 int pe_gemm_tn(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
                int K, int accumulate, float* workspace, size_t workspace_bytes, void* stream);
@@ -214,8 +202,6 @@ int pe_attn_bwd(const float* qkv, long ld_qkv, const float* o, const float* d_o,
  * pe_wfrag_pack_f16: fragment order of pe_wfrag_pack with one fp16 term per weight. */
 int pe_gemm_nt_f16(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
                     int K, const float* bias0, const float* bias1, int accumulate, void* stream);
-int pe_gemm_nt_wf_f16(const float* A, long lda, const void* wfrag, float* C, long ldc, int M, int N, int K,
-                       const float* bias0, const float* bias1, int accumulate, void* stream);
 int pe_gemm_tn_f16(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N,
                     int K, int accumulate, float* workspace, size_t workspace_bytes, void* stream);
 int pe_conv3x3_fwd_f16(const float* x, const float* w_packed, float* y, int B, int T, int F, int C, int N,
@@ -300,22 +286,17 @@ int pe_lstm_bwd(int ncells, const float* const* whh_t, float* const* gates, cons
  * sticky error flag (non-zero = a bounded spin timed out: results invalid).  Only when pe_lstm_persistent_supported() returns 1. */
 size_t pe_lstm_persistent_sync_bytes(int ncells, int B);
 int pe_lstm_persistent_supported(int ncells, int B, int H);
-int pe_lstm_fwd_persistent(int ncells, const float* const* whh, float* const* gates, float* const* y,
-                           float* const* cbuf, const int* reverse, long ldy, int B, int T, int H,
-                           unsigned* sync, void* stream);
-int pe_lstm_bwd_persistent(int ncells, const float* const* whh_t, float* const* gates,
-                           const float* const* cbuf, const float* const* dy, const int* reverse, long lddy,
-                           int B, int T, int H, float* const* dbias_rows, unsigned* const* dgates_amax,
-                           unsigned* sync, void* stream);
-/* dbias_rows (nullable): per cell a [pe_lstm_bwd_persistent_dbias_rows()][4H] buffer that receives the per-batch-tile
+/* Persistent recurrences (H = 384): ONE launch per layer for all cells, W_hh resident on chip, workgroups hand h /
+ * partial dh tiles to each other through memory.  The recurrent products are 16-bit-term MFMAs: `_x3` = the exact
+ * three-term bf16 split (fp32-accurate), `_bf16` / `_f16` = operands rounded to 16 bits (mixed precision).  There is
+ * no native-fp32 persistent form: pe_lstm_fwd / pe_lstm_bwd (one launch per time step) serve that mode and every
+ * shape pe_lstm_persistent_supported() declines.
+ * dbias_rows (nullable): per cell a [pe_lstm_bwd_persistent_dbias_rows()][4H] buffer that receives the per-batch-tile
  * column sums of the gate gradients (their row sum is dL/db_ih = dL/db_hh), replacing a pe_colsum pass over the
- * [B*T][4H] gradient tensor.  Written only when the query below returns non-zero for the configuration
- * (terms: 0 pe_lstm_bwd_persistent, 3 _x3, 1 _bf16 / _f16).
- * dgates_amax (nullable): per cell a device word the caller zeroed; under the same condition the kernel max-merges
- * the IEEE bits of the largest gate-gradient magnitude into it (the "h2" scale source of the dX / dW products). */
-int pe_lstm_bwd_persistent_dbias_rows(int terms, int ncells, int B, int T, int H, long lddy);
-/* same recurrences with the recurrent products as the exact three-term bf16 split (H % 64 == 0; other
- * hidden sizes run the native fp32 MFMA form) */
+ * [B*T][4H] gradient tensor.
+ * dgates_amax (nullable): per cell a device word the caller zeroed; the kernel max-merges the IEEE bits of the largest
+ * gate-gradient magnitude into it (the "h2" scale source of the dX / dW products). */
+int pe_lstm_bwd_persistent_dbias_rows(int ncells, int B, int T, int H, long lddy);
 int pe_lstm_fwd_persistent_x3(int ncells, const float* const* whh, float* const* gates, float* const* y,
                            float* const* cbuf, const int* reverse, long ldy, int B, int T, int H,
                            unsigned* sync, void* stream);
@@ -331,6 +312,9 @@ int pe_lstm_bwd_persistent_bf16(int ncells, const float* const* whh_t, float* co
                            const float* const* cbuf, const float* const* dy, const int* reverse, long lddy,
                            int B, int T, int H, float* const* dbias_rows, unsigned* const* dgates_amax,
                            unsigned* sync, void* stream);
+/* Diagnostic (tools/stamp_lstm.py): 1 = run the stamped instantiations of the x3 kernels (s_memtime per region of an
+ * iteration; grid <= 128 workgroups).  Returns the previous setting.  The product path never calls it. */
+int pe_lstm_configure_stamps(int enable);
 size_t pe_lstm_whh_grad_workspace_bytes(int B, int T, int H);
 int pe_lstm_whh_grad(const float* dgates, const float* y, long ldy, float* dwhh, int B, int T, int H,
                      int reverse, float* workspace, size_t workspace_bytes, void* stream);

@@ -34,6 +34,7 @@ _ip = C.POINTER(C.c_int)
 PROTOTYPES = {
     "pe_abi_version": (_i, []),
     "pe_device_count": (_i, []),
+    "pe_stream_create_low_priority": (_i, [C.POINTER(_p)]),
     "pe_mel_plan_create": (_i, [C.POINTER(_p), _i, _i, _i, _i, _i, _f, _f]),
     "pe_mel_plan_destroy": (_i, [_p]),
     "pe_mel_num_frames": (_i, [_p, _i]),
@@ -45,10 +46,6 @@ PROTOTYPES = {
     "pe_gemm_nt_h2": (_i, [_p, _l, _p, _l, _p, _l, _i, _i, _i, _p, _p, _i, _p, _p, _p]),
     "pe_absmax": (_i, [_p, _l, _i, _l, _p, _p]),
     "pe_absmax_segments": (_i, [_p, _p, _p, _i, _p, _p]),
-    "pe_gemm_nt_wf_x3": (_i, [_p, _l, _p, _p, _l, _i, _i, _i, _p, _p, _i, _p]),
-    "pe_gemm_nt_wf_bf16": (_i, [_p, _l, _p, _p, _l, _i, _i, _i, _p, _p, _i, _p]),
-    "pe_gemm_nt_wf_ablate": (_i, [_i, _p, _l, _p, _p, _l, _i, _i, _i, _p]),
-    "pe_gemm_nt_pipeline": (_i, [_i]),
     "pe_gemm_tn_workspace_bytes": (_z, [_i, _i, _i]),
     "pe_gemm_tn": (_i, [_p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _p, _z, _p]),
     "pe_gemm_tn_x3": (_i, [_p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _p, _z, _p]),
@@ -93,10 +90,9 @@ PROTOTYPES = {
     "pe_lstm_bwd": (_i, [_i, _pp, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _p]),
     "pe_lstm_persistent_sync_bytes": (_z, [_i, _i]),
     "pe_lstm_persistent_supported": (_i, [_i, _i, _i]),
-    "pe_lstm_fwd_persistent": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _p, _p]),
-    "pe_lstm_bwd_persistent": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _pp, _pp, _p, _p]),
     "pe_lstm_fwd_persistent_x3": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _p, _p]),
-    "pe_lstm_bwd_persistent_dbias_rows": (_i, [_i, _i, _i, _i, _i, _l]),
+    "pe_lstm_bwd_persistent_dbias_rows": (_i, [_i, _i, _i, _i, _l]),
+    "pe_lstm_configure_stamps": (_i, [_i]),
     "pe_lstm_bwd_persistent_x3": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _pp, _pp, _p, _p]),
     "pe_lstm_fwd_persistent_bf16": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _p, _p]),
     "pe_lstm_bwd_persistent_bf16": (_i, [_i, _pp, _pp, _pp, _pp, _ip, _l, _i, _i, _i, _pp, _pp, _p, _p]),
@@ -132,7 +128,6 @@ PROTOTYPES = {
     "pe_f0_bins_ce_workspace_bytes": (_z, [_l]),
     "pe_f0_bins_ce_loss": (_i, [_p, _l, _i, _p, _p, _p, _f, _l, _f, _p, _p, _l, _p, _p, _z, _p]),
     "pe_gemm_nt_f16": (_i, [_p, _l, _p, _l, _p, _l, _i, _i, _i, _p, _p, _i, _p]),
-    "pe_gemm_nt_wf_f16": (_i, [_p, _l, _p, _p, _l, _i, _i, _i, _p, _p, _i, _p]),
     "pe_gemm_tn_f16": (_i, [_p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _p, _z, _p]),
     "pe_conv3x3_fwd_f16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "pe_conv3x3_fwd_wf_f16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),

@@ -288,226 +288,6 @@ __device__ __forceinline__ void group_of_block(int NJ, int& jt, int& gidx) {
   }
 }
 
-// --------------------------------------------------------------------------------------- forward
-// TERMS: 0 = native fp32 MFMA, 3 = exact three-term split, 1 = operands rounded to bf16 (mixed precision)
-template <int H, int TERMS>
-__global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_kernel(const PFwdCells cells, int B, int T, long ldy,
-                                                                     unsigned y_bytes, unsigned* sync) {
-  constexpr bool X3 = TERMS != 0;                   // bf16-term pipeline (3 or 1 terms)
-  constexpr int KQ = H / 4, KH = KQ / 2, NV = KH / 4, NJ = H / 32;
-  constexpr int ASTR = H + 4;                       // LDS row stride of the staged h rows
-  constexpr int ROW4 = H / 4;                       // float4 per row
-  static_assert(H % 32 == 0, "hidden size is a multiple of 32");
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                                 // [32][ASTR]
-  // X3: the partial tiles reuse the operand rows' space (one more barrier per item buys 50 KB of LDS for
-  // W lo terms, i.e. 48 registers per lane)
-  float* red = X3 ? smem : smem + 32 * ASTR;        // [4][32][kRs]
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int r = lane & 31, hh = lane >> 5;
-  const int nbt = (B + 63) / 64;
-  int jt, gidx;
-  group_of_block(NJ, jt, gidx);                    // the NJ workgroups of a group share one XCD
-  const int bt = gidx % nbt, cell = gidx / nbt;
-  const int j0 = jt * 32, b0 = bt * 64;
-  const int rev = cells.reverse[cell];
-  float* y = cells.y[cell];
-  float* gates = cells.gates[cell];
-  float* cb = cells.c[cell];
-  unsigned* err = sync;
-  unsigned* ctr = sync + kCtrStride * (1 + (cell * nbt + bt) * 2);
-  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(y, 0, y_bytes, 0x00020000);
-
-  // W_hh slice of this wave / lane: rows {g*H + j0 + r}, k = wv*KQ + hh*KH + s
-  constexpr int NB = X3 ? KH / 8 : 1;               // 8-k blocks per lane (X3)
-  constexpr int NBR = TERMS == 3 ? fwd_lo_reg_blocks<H>() : NB;   // one term: no lo terms at all
-  static_assert(!X3 || KH % 8 == 0, "X3 needs H % 64 == 0");
-  float bw[X3 ? 1 : 4][X3 ? 1 : KH];
-  bf16x8 bwhm[X3 ? 4 : 1][NB][2], bwlo[X3 ? 4 : 1][NBR];
-  uint4* wlo_lds = reinterpret_cast<uint4*>(smem + (4 * 32 * kRs > 32 * ASTR ? 4 * 32 * kRs : 32 * ASTR));   // [4][NB - NBR][256]
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const float* src = cells.whh[cell] + (long)(g * H + j0 + r) * H + wv * KQ + hh * KH;
-    if constexpr (X3) {
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const float4 w0 = *reinterpret_cast<const float4*>(src + 8 * b);
-        const float4 w1 = *reinterpret_cast<const float4*>(src + 8 * b + 4);
-        if constexpr (TERMS == 3) {
-          bf16x8 t3[3];
-          split8(w0, w1, t3);
-          bwhm[g][b][0] = t3[0];
-          bwhm[g][b][1] = t3[1];
-          if (b < NBR) bwlo[g][b < NBR ? b : 0] = t3[2];
-          else wlo_lds[(g * (NB - NBR) + (b - NBR)) * 256 + tid] = __builtin_bit_cast(uint4, t3[2]);
-        } else {
-          bwhm[g][b][0] = round8(w0, w1);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        const float4 t4 = *reinterpret_cast<const float4*>(src + 4 * v);
-        bw[g][4 * v] = t4.x; bw[g][4 * v + 1] = t4.y; bw[g][4 * v + 2] = t4.z; bw[g][4 * v + 3] = t4.w;
-      }
-    }
-  }
-  const int prow = tid >> 3, pq = tid & 7;          // cell-update item: row prow, hidden units j0 + 4 pq .. +3
-  float4 creg[2];
-  creg[0] = creg[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-  // Software pipeline over items (step, half): while item i runs its MFMAs, the h rows of item i+1
-  // (published a half-phase ago by the group) are already in flight into `stage`.
-  constexpr int NST = ROW4 / 8;                     // float4 per thread: 8 threads cover a row in NST passes
-  static_assert(ROW4 % 8 == 0, "hidden size is a multiple of 32");
-  float4 stage[NST];
-  auto fetch = [&](int step_n, int hf_n) {            // wait for + load h_{t-1} rows of item (step_n, hf_n)
-    const int tn_ = rev ? T - 1 - step_n : step_n;
-    const int tpn = rev ? tn_ + 1 : tn_ - 1;
-    group_wait(ctr + kCtrStride * hf_n, (unsigned)(NJ * step_n), err);
-    // staging assignment: 8 threads per row, float4 column (tid & 7) + 8 j -- one multiply per fetch and an
-    // immediate offset per load (byte offsets fit 32 bits: checked by the host)
-    const int brow = b0 + 32 * hf_n + (tid >> 3);
-    const unsigned base = ((unsigned)(brow * T + tpn) * (unsigned)ldy + (unsigned)(tid & 7) * 4u) * 4u;
-#pragma unroll
-    for (int v = 0; v < NST; ++v)
-      stage[v] = brow < B ? load_sc1(yrs, base + (unsigned)v * 128u) : make_float4(0.f, 0.f, 0.f, 0.f);
-  };
-
-  for (int step = 0; step < T; ++step) {
-    const int t = rev ? T - 1 - step : step;
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-      const int rb0 = b0 + 32 * hf;
-      const int pb = rb0 + prow;
-      const long prow_i = (long)pb * T + t;
-      float4 xp[4];
-      auto load_xp = [&]() {
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          xp[g] = pb < B ? *reinterpret_cast<const float4*>(gates + prow_i * 4 * H + g * H + j0 + 4 * pq)
-                         : make_float4(0.f, 0.f, 0.f, 0.f);
-      };
-      if (!X3) load_xp();                           // X3: after the MFMA phase (the register file is full during it)
-      f32x16 acc[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc[g][q] = 0.f;
-      if (step > 0) {
-        float* adst = As + (tid >> 3) * ASTR + (tid & 7) * 4;
-#pragma unroll
-        for (int v = 0; v < NST; ++v) *reinterpret_cast<float4*>(adst + 32 * v) = stage[v];
-        __syncthreads();
-      }
-      // next item's operand rows: (step, 1) after (step, 0); (step + 1, 0) after (step, 1).  Native form:
-      // fetched before the MFMA phase (hidden under it).  X3: the register file is full of W terms during
-      // the MFMAs, so the fetch is issued right after them and lands under the cell update instead.
-      auto fetch_next = [&]() {
-        const int step_n = hf == 0 ? step : step + 1, hf_n = hf ^ 1;
-        if (step_n > 0 && step_n < T) fetch(step_n, hf_n);
-      };
-      if (!X3) fetch_next();
-      if (X3 && step > 0) {
-        if constexpr (X3) {
-          const float* asrc = As + r * ASTR + wv * KQ + hh * KH;
-#pragma unroll
-          for (int b = 0; b < NB; ++b) {
-            const float4 a0 = *reinterpret_cast<const float4*>(asrc + 8 * b);
-            const float4 a1 = *reinterpret_cast<const float4*>(asrc + 8 * b + 4);
-            if constexpr (TERMS == 3) {
-              bf16x8 fa[3];                           // 36 VALU per 24 MFMAs: cheap enough not to pipeline
-              split8(a0, a1, fa);
-              bf16x8 wl[4];
-#pragma unroll
-              for (int g = 0; g < 4; ++g)
-                wl[g] = b < NBR ? bwlo[g][b < NBR ? b : 0]
-                                : __builtin_bit_cast(bf16x8, wlo_lds[(g * (NB - NBR) + (b - NBR)) * 256 + tid]);
-#pragma unroll
-              for (int t6 = 0; t6 < 6; ++t6)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                  acc[g] = mfma_bf16(kTb[t6] == 2 ? wl[g] : bwhm[g][b][kTb[t6]], fa[kTa[t6]], acc[g]);
-            } else {
-              const bf16x8 fa = round8(a0, a1);
-#pragma unroll
-              for (int g = 0; g < 4; ++g) acc[g] = mfma_bf16(bwhm[g][b][0], fa, acc[g]);
-            }
-          }
-        }
-      }
-      if (!X3 && step > 0) {
-        // operands come out of LDS in two chunks to keep the live register set small
-        constexpr int AC = (NV % 2 == 0) ? NV / 2 : NV;
-        const float* asrc = As + r * ASTR + wv * KQ + hh * KH;
-#pragma unroll
-        for (int ch = 0; ch < NV / AC; ++ch) {
-          float av[4 * AC];
-#pragma unroll
-          for (int v = 0; v < AC; ++v) {
-            const float4 t4 = *reinterpret_cast<const float4*>(asrc + 4 * (ch * AC + v));
-            av[4 * v] = t4.x; av[4 * v + 1] = t4.y; av[4 * v + 2] = t4.z; av[4 * v + 3] = t4.w;
-          }
-#pragma unroll
-          for (int s = 0; s < 4 * AC; ++s)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = mfma32(bw[g][ch * 4 * AC + s], av[s], acc[g]);
-        }
-      }
-      if (X3) {
-        load_xp();
-        fetch_next();
-        __syncthreads();                            // every wave is done reading As before red overwrites it
-      }
-      // W is the MFMA A operand, so a lane holds 4 consecutive hidden units of ONE batch row per register
-      // quad: the partial tiles go out as 16 ds_write_b128 instead of 64 ds_write_b32
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4)
-          *reinterpret_cast<float4*>(red + (wv * 32 + r) * kRs + g * 32 + 8 * q4 + 4 * hh) =
-              make_float4(acc[g][4 * q4], acc[g][4 * q4 + 1], acc[g][4 * q4 + 2], acc[g][4 * q4 + 3]);
-      __syncthreads();
-      if (pb < B) {
-        float4 pre[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float* rp = red + prow * kRs + g * 32 + 4 * pq;
-          const float4 p0 = *reinterpret_cast<const float4*>(rp);
-          const float4 p1 = *reinterpret_cast<const float4*>(rp + 32 * kRs);
-          const float4 p2 = *reinterpret_cast<const float4*>(rp + 2 * 32 * kRs);
-          const float4 p3 = *reinterpret_cast<const float4*>(rp + 3 * 32 * kRs);
-          pre[g].x = ((p0.x + p1.x) + (p2.x + p3.x)) + xp[g].x;
-          pre[g].y = ((p0.y + p1.y) + (p2.y + p3.y)) + xp[g].y;
-          pre[g].z = ((p0.z + p1.z) + (p2.z + p3.z)) + xp[g].z;
-          pre[g].w = ((p0.w + p1.w) + (p2.w + p3.w)) + xp[g].w;
-        }
-        const float4 gi = make_float4(sigm(pre[0].x), sigm(pre[0].y), sigm(pre[0].z), sigm(pre[0].w));
-        const float4 gf = make_float4(sigm(pre[1].x), sigm(pre[1].y), sigm(pre[1].z), sigm(pre[1].w));
-        const float4 gg = make_float4(tanh_fast(pre[2].x), tanh_fast(pre[2].y), tanh_fast(pre[2].z), tanh_fast(pre[2].w));
-        const float4 go = make_float4(sigm(pre[3].x), sigm(pre[3].y), sigm(pre[3].z), sigm(pre[3].w));
-        float4 cn;
-        cn.x = cell_c(gf.x, creg[hf].x, gi.x, gg.x);
-        cn.y = cell_c(gf.y, creg[hf].y, gi.y, gg.y);
-        cn.z = cell_c(gf.z, creg[hf].z, gi.z, gg.z);
-        cn.w = cell_c(gf.w, creg[hf].w, gi.w, gg.w);
-        creg[hf] = cn;
-        const float4 hv = make_float4(go.x * tanh_fast(cn.x), go.y * tanh_fast(cn.y), go.z * tanh_fast(cn.z),
-                                      go.w * tanh_fast(cn.w));
-        // h_t first and write-through: it is what the other workgroups wait for
-        store_sc1(yrs, (unsigned)((prow_i * ldy + j0 + 4 * pq) * 4), hv);
-        float* gp = gates + prow_i * 4 * H + j0 + 4 * pq;
-        *reinterpret_cast<float4*>(gp) = gi;
-        *reinterpret_cast<float4*>(gp + H) = gf;
-        *reinterpret_cast<float4*>(gp + 2 * H) = gg;
-        *reinterpret_cast<float4*>(gp + 3 * H) = go;
-        *reinterpret_cast<float4*>(cb + prow_i * H + j0 + 4 * pq) = cn;
-      }
-      group_arrive(ctr + kCtrStride * hf);          // (its barrier also frees As / red for the next item)
-    }
-  }
-}
-
 // --------------------------------------------------------------------------------------- forward, overlapped
 // Same tiling, same hand-off protocol, same arithmetic (bit for bit) as lstm_fwd_persistent_kernel, but the part of
 // an item that is not MFMA work -- partial-tile exchange, gate functions, the stores of h / gates / c, the store
@@ -961,246 +741,6 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_persistent_v2_kernel(const PF
   }
 }
 
-// --------------------------------------------------------------------------------------- backward
-// dh_t = dY_t + dgates_{t+1} . W_hh  (K = 4H: wave w owns gate block w; each lane half takes H/2
-// contiguous k, streamed through LDS in chunks of CH per lane).  W_hh^T rows j0 + r stay in registers.
-template <int H, int TERMS>
-__global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_kernel(const PBwdCells cells, int B, int T, long lddy,
-                                                                     unsigned g_bytes, unsigned* sync) {
-  constexpr bool X3 = TERMS != 0;                   // bf16-term pipeline (3 or 1 terms)
-  constexpr int KH = H / 2, NJ = H / 32, K = 4 * H;
-  constexpr int CH = (KH % 48 == 0) ? 48 : 16;      // k per lane per chunk
-  constexpr int NCH = KH / CH;
-  constexpr int CW = 8 * CH;                        // staged floats per row per chunk (4 waves x 2 halves)
-  constexpr int ASTR = CW + 4;
-  constexpr int ROW4 = CW / 4;
-  constexpr int NLD = (32 * ROW4) / 256;            // float4 per thread per chunk
-  static_assert(KH % CH == 0 && (32 * ROW4) % 256 == 0, "chunking");
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As0 = smem;                                // [2][32][ASTR]
-  float* red = smem + 2 * 32 * ASTR;                // [4][32][kRb]
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int r = lane & 31, hh = lane >> 5;
-  const int nbt = (B + 63) / 64;
-  int jt, gidx;
-  group_of_block(NJ, jt, gidx);                    // the NJ workgroups of a group share one XCD
-  const int bt = gidx % nbt, cell = gidx / nbt;
-  const int j0 = jt * 32, b0 = bt * 64;
-  const int rev = cells.reverse[cell];
-  float* gates = cells.gates[cell];
-  const float* cb = cells.c[cell];
-  const float* dy = cells.dy[cell];
-  unsigned* err = sync;
-  unsigned* ctr = sync + kCtrStride * (1 + (cell * nbt + bt) * 2);
-  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(gates, 0, g_bytes, 0x00020000);
-
-  constexpr int NBK = X3 ? KH / 8 : 1;              // 8-k blocks per lane (X3)
-  constexpr int NBR = TERMS == 3 ? bwd_lo_reg_blocks<H>() : NBK;
-  static_assert(!X3 || (KH % 8 == 0 && CH % 8 == 0), "X3 needs H % 16 == 0");
-  float bw[X3 ? 1 : KH];
-  bf16x8 bwhm[NBK][2], bwlo[NBR];
-  uint4* wlo_lds = reinterpret_cast<uint4*>(smem + 2 * 32 * ASTR + 4 * 32 * kRb);   // [NBK - NBR][256]
-  {
-    const float* src = cells.whh_t[cell] + (long)(j0 + r) * K + wv * H + hh * KH;
-    if constexpr (X3) {
-#pragma unroll
-      for (int b = 0; b < NBK; ++b) {
-        const float4 w0 = *reinterpret_cast<const float4*>(src + 8 * b);
-        const float4 w1 = *reinterpret_cast<const float4*>(src + 8 * b + 4);
-        if constexpr (TERMS == 3) {
-          bf16x8 t3[3];
-          split8(w0, w1, t3);
-          bwhm[b][0] = t3[0];
-          bwhm[b][1] = t3[1];
-          if (b < NBR) bwlo[b < NBR ? b : 0] = t3[2];
-          else wlo_lds[(b - NBR) * 256 + tid] = __builtin_bit_cast(uint4, t3[2]);
-        } else {
-          bwhm[b][0] = round8(w0, w1);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int v = 0; v < KH / 4; ++v) {
-        const float4 t4 = *reinterpret_cast<const float4*>(src + 4 * v);
-        bw[4 * v] = t4.x; bw[4 * v + 1] = t4.y; bw[4 * v + 2] = t4.z; bw[4 * v + 3] = t4.w;
-      }
-    }
-  }
-  const int prow = tid >> 3, pq = tid & 7;
-  float4 dcar[2];
-  dcar[0] = dcar[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-  // staged column c of a chunk <-> global k:  seg = c / CH = wave*2 + half,
-  //                                           k = (seg >> 1)*H + (seg & 1)*KH + chunk*CH + c % CH
-  // `stage` always holds the chunk that is committed next; across items it carries chunk 0 of the
-  // next (step, half), fetched behind that item's group wait while this item still computes.
-  float4 stage[NLD];
-  // staging assignment: 8 threads per row, float4 column (tid & 7) + 8 v of the chunk's 8*CH staged floats;
-  // 32-bit offsets (checked by the host), one multiply per chunk
-  // Staged column 4*(t7 + 8 v) of a chunk advances by 32 floats per v, i.e. by two lane-half segments every
-  // CH / 16 loads: k(v + CH/16) = k(v) + H.  Only the first CH / 16 offsets are computed (once per kernel).
-  constexpr int PER = CH / 16;
-  int kbase[PER];
-#pragma unroll
-  for (int n = 0; n < PER; ++n) {
-    const int el = ((tid & 7) + 8 * n) * 4;
-    const int seg = el / CH, e = el - seg * CH;
-    kbase[n] = (seg >> 1) * H + (seg & 1) * KH + e;
-  }
-  auto load_chunk = [&](int rb0_, int tn_, int c) {
-    const int brow = rb0_ + (tid >> 3);
-    const unsigned rowbase = ((unsigned)(brow * T + tn_) * (unsigned)K + (unsigned)(c * CH)) * 4u;
-    unsigned kb[PER];
-#pragma unroll
-    for (int n = 0; n < PER; ++n) {
-      kb[n] = rowbase + (unsigned)kbase[n] * 4u;
-      asm volatile("" : "+v"(kb[n]));                 // one add per load below; precomputing all NLD offsets spills
-    }
-#pragma unroll
-    for (int v = 0; v < NLD; ++v)
-      stage[v] = brow < B ? load_sc1(grs, kb[v % PER] + (unsigned)((v / PER) * H) * 4u) : make_float4(0.f, 0.f, 0.f, 0.f);
-  };
-  auto fetch_next = [&](int step, int hf) {          // (step, 0) -> (step, 1) -> (step + 1, 0)
-    const int step_n = hf == 0 ? step : step + 1, hf_n = hf ^ 1;
-    if (step_n > 0 && step_n < T) {
-      const int t_n = rev ? step_n : T - 1 - step_n;
-      group_wait(ctr + kCtrStride * hf_n, (unsigned)(NJ * step_n), err);
-      load_chunk(b0 + 32 * hf_n, rev ? t_n - 1 : t_n + 1, 0);
-    }
-  };
-
-  for (int step = 0; step < T; ++step) {
-    const int t = rev ? step : T - 1 - step;
-    const int tn = rev ? t - 1 : t + 1;
-    const int tp = rev ? t + 1 : t - 1;
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-      const int rb0 = b0 + 32 * hf;
-      const int pb = rb0 + prow;
-      const long prow_i = (long)pb * T + t;
-      const int j = j0 + 4 * pq;
-      // inputs of the gate-gradient update, issued before the MFMA phase
-      float4 in_dy = make_float4(0.f, 0.f, 0.f, 0.f), in_c = in_dy, in_cp = in_dy;
-      float4 in_g[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) in_g[g] = in_dy;
-      const bool has_prev = rev ? (tp < T) : (tp >= 0);
-      if (pb < B) {
-        in_dy = *reinterpret_cast<const float4*>(dy + prow_i * lddy + j);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) in_g[g] = *reinterpret_cast<const float4*>(gates + prow_i * K + g * H + j);
-        in_c = *reinterpret_cast<const float4*>(cb + prow_i * H + j);
-        if (has_prev) in_cp = *reinterpret_cast<const float4*>(cb + ((long)pb * T + tp) * H + j);
-      }
-      f32x16 acc, acc2;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[q] = acc2[q] = 0.f;
-      if (step > 0) {
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-          float* cur = As0 + (c & 1) * 32 * ASTR;
-          float* adst = cur + (tid >> 3) * ASTR + (tid & 7) * 4;
-#pragma unroll
-          for (int v = 0; v < NLD; ++v) *reinterpret_cast<float4*>(adst + 32 * v) = stage[v];
-          __syncthreads();
-          if (c + 1 < NCH) load_chunk(rb0, tn, c + 1);
-          else fetch_next(step, hf);
-          constexpr int AC = (CH / 4) % 2 == 0 ? CH / 8 : CH / 4;     // float4 per operand sub-chunk
-          const float* asrc = cur + r * ASTR + (wv * 2 + hh) * CH;
-          if constexpr (X3) {
-            // two accumulators (even / odd blocks); the next block's operand is split under this block's MFMAs
-            if constexpr (TERMS == 3) {
-              bf16x8 fa[3];
-              split8(*reinterpret_cast<const float4*>(asrc), *reinterpret_cast<const float4*>(asrc + 4), fa);
-#pragma unroll
-              for (int b = 0; b < CH / 8; ++b) {
-                const int gb = c * (CH / 8) + b;                        // block index within this lane's k range
-                bf16x8 fn[3];
-                if (b + 1 < CH / 8)
-                  split8(*reinterpret_cast<const float4*>(asrc + 8 * (b + 1)),
-                         *reinterpret_cast<const float4*>(asrc + 8 * (b + 1) + 4), fn);
-                const bf16x8 wl = gb < NBR ? bwlo[gb < NBR ? gb : 0]
-                                           : __builtin_bit_cast(bf16x8, wlo_lds[(gb - NBR) * 256 + tid]);
-#pragma unroll
-                for (int t6 = 0; t6 < 6; ++t6) {
-                  const bf16x8 wt = kTb[t6] == 2 ? wl : bwhm[gb][kTb[t6]];
-                  if (b & 1) acc2 = mfma_bf16(fa[kTa[t6]], wt, acc2);
-                  else acc = mfma_bf16(fa[kTa[t6]], wt, acc);
-                }
-                if (b + 1 < CH / 8) { fa[0] = fn[0]; fa[1] = fn[1]; fa[2] = fn[2]; }
-              }
-            } else {
-#pragma unroll
-              for (int b = 0; b < CH / 8; ++b) {
-                const int gb = c * (CH / 8) + b;
-                const bf16x8 fa = round8(*reinterpret_cast<const float4*>(asrc + 8 * b),
-                                         *reinterpret_cast<const float4*>(asrc + 8 * b + 4));
-                if (b & 1) acc2 = mfma_bf16(fa, bwhm[gb][0], acc2);
-                else acc = mfma_bf16(fa, bwhm[gb][0], acc);
-              }
-            }
-          } else {
-#pragma unroll
-            for (int sc = 0; sc < (CH / 4) / AC; ++sc) {
-              float av[4 * AC];
-#pragma unroll
-              for (int v = 0; v < AC; ++v) {
-                const float4 t4 = *reinterpret_cast<const float4*>(asrc + 4 * (sc * AC + v));
-                av[4 * v] = t4.x; av[4 * v + 1] = t4.y; av[4 * v + 2] = t4.z; av[4 * v + 3] = t4.w;
-              }
-#pragma unroll
-              for (int s2 = 0; s2 < 4 * AC; ++s2) acc = mfma32(av[s2], bw[c * CH + sc * 4 * AC + s2], acc);
-            }
-          }
-        }
-      } else {
-        fetch_next(step, hf);
-      }
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
-        red[(wv * 32 + row) * kRb + r] = X3 ? acc[q] + acc2[q] : acc[q];
-      }
-      __syncthreads();
-      if (pb < B) {
-        const float* rp = red + prow * kRb + 4 * pq;
-        const float4 p0 = *reinterpret_cast<const float4*>(rp);
-        const float4 p1 = *reinterpret_cast<const float4*>(rp + 32 * kRb);
-        const float4 p2 = *reinterpret_cast<const float4*>(rp + 2 * 32 * kRb);
-        const float4 p3 = *reinterpret_cast<const float4*>(rp + 3 * 32 * kRb);
-        const float dhv[4] = {in_dy.x + ((p0.x + p1.x) + (p2.x + p3.x)), in_dy.y + ((p0.y + p1.y) + (p2.y + p3.y)),
-                              in_dy.z + ((p0.z + p1.z) + (p2.z + p3.z)), in_dy.w + ((p0.w + p1.w) + (p2.w + p3.w))};
-        const float gi[4] = {in_g[0].x, in_g[0].y, in_g[0].z, in_g[0].w};
-        const float gf[4] = {in_g[1].x, in_g[1].y, in_g[1].z, in_g[1].w};
-        const float gg[4] = {in_g[2].x, in_g[2].y, in_g[2].z, in_g[2].w};
-        const float go[4] = {in_g[3].x, in_g[3].y, in_g[3].z, in_g[3].w};
-        const float cn[4] = {in_c.x, in_c.y, in_c.z, in_c.w};
-        const float cp[4] = {in_cp.x, in_cp.y, in_cp.z, in_cp.w};
-        float dcv[4] = {dcar[hf].x, dcar[hf].y, dcar[hf].z, dcar[hf].w};
-        float oi[4], of[4], og[4], oo[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float tc = tanh_fast(cn[e]);
-          const float dc = dhv[e] * go[e] * (1.f - tc * tc) + dcv[e];
-          oi[e] = dc * gg[e] * gi[e] * (1.f - gi[e]);
-          of[e] = dc * cp[e] * gf[e] * (1.f - gf[e]);
-          og[e] = dc * gi[e] * (1.f - gg[e] * gg[e]);
-          oo[e] = dhv[e] * tc * go[e] * (1.f - go[e]);
-          dcv[e] = dc * gf[e];
-        }
-        dcar[hf] = make_float4(dcv[0], dcv[1], dcv[2], dcv[3]);
-        // dgates_t feed the next step of every workgroup in the group: write-through
-        const unsigned off = (unsigned)((prow_i * K + j) * 4);
-        store_sc1(grs, off, make_float4(oi[0], oi[1], oi[2], oi[3]));
-        store_sc1(grs, off + (unsigned)(H * 4), make_float4(of[0], of[1], of[2], of[3]));
-        store_sc1(grs, off + (unsigned)(2 * H * 4), make_float4(og[0], og[1], og[2], og[3]));
-        store_sc1(grs, off + (unsigned)(3 * H * 4), make_float4(oo[0], oo[1], oo[2], oo[3]));
-      }
-      group_arrive(ctr + kCtrStride * hf);
-    }
-  }
-}
-
 // --------------------------------------------------------------------------------------- backward, k-split
 // dh_t = dY_t + dgates_{t+1} . W_hh.  The kernel above gives workgroup jt the 32 output columns j of dh and has it
 // read ALL 4H gate gradients of its 32 batch rows: 192 KB per item and workgroup through one CU's 64 B/clk L1 path,
@@ -1590,38 +1130,6 @@ int device_cus() {
   return cus;
 }
 
-template <int H, int TERMS>
-constexpr size_t fwd_lds() {
-  constexpr bool X3 = TERMS != 0;
-  constexpr int NB = H / 64, NBR = TERMS == 3 ? fwd_lo_reg_blocks<H>() : NB;
-  constexpr size_t as = 32 * (H + 4), rd = 4 * 32 * kRs;
-  return X3 ? (as > rd ? as : rd) * sizeof(float) + (size_t)4 * (NB - NBR) * 256 * 16 : (as + rd) * sizeof(float);
-}
-
-template <int H, int TERMS>
-constexpr size_t bwd_lds() {
-  constexpr bool X3 = TERMS == 3;
-  constexpr int KH = H / 2;
-  constexpr int CH = (KH % 48 == 0) ? 48 : 16;
-  constexpr int NBK = KH / 8, NBR = TERMS == 3 ? bwd_lo_reg_blocks<H>() : NBK;
-  return (size_t)(2 * 32 * (8 * CH + 4) + 4 * 32 * kRb) * sizeof(float) + (X3 ? (size_t)(NBK - NBR) * 256 * 16 : 0);
-}
-
-template <int H, int X3>
-int launch_fwd(const PFwdCells& cells, int grid, int B, int T, long ldy, unsigned* sync, hipStream_t st) {
-  static bool attr = false;
-  if (!attr) {
-    PE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_persistent_kernel<H, X3>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds<H, X3>()));
-    attr = true;
-  }
-  const unsigned y_bytes = (unsigned)((size_t)B * T * ldy * sizeof(float));
-  hipLaunchKernelGGL((lstm_fwd_persistent_kernel<H, X3>), dim3(grid), dim3(256), (fwd_lds<H, X3>()), st, cells, B, T, ldy, y_bytes,
-                     sync);
-  PE_LAUNCH_CHECK();
-  return PE_OK;
-}
-
 template <int H, int TERMS, int NBR>
 constexpr size_t fwd_v2_lds() {
   constexpr int NB = H / 64, NBL = TERMS == 3 ? NB - NBR : 0;
@@ -1668,26 +1176,9 @@ int launch_bwd_v2(const PBwdCells& cells, int grid, int B, int T, long lddy, uns
   return PE_OK;
 }
 
-// PE_LSTM_V1=1 selects the non-overlapped kernels (A/B timing, tools/bench_lstm.py)
-bool lstm_use_v2() {
-  static const bool v2 = !(getenv("PE_LSTM_V1") && getenv("PE_LSTM_V1")[0] == '1');
-  return v2;
-}
-
-template <int H, int X3>
-int launch_bwd(const PBwdCells& cells, int grid, int B, int T, long lddy, unsigned* sync, hipStream_t st) {
-  static bool attr = false;
-  if (!attr) {
-    PE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_persistent_kernel<H, X3>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds<H, X3>()));
-    attr = true;
-  }
-  const unsigned g_bytes = (unsigned)((size_t)B * T * 4 * H * sizeof(float));
-  hipLaunchKernelGGL((lstm_bwd_persistent_kernel<H, X3>), dim3(grid), dim3(256), (bwd_lds<H, X3>()), st, cells, B, T, lddy,
-                     g_bytes, sync);
-  PE_LAUNCH_CHECK();
-  return PE_OK;
-}
+// diagnostic instantiation with s_memtime stamps (tools/stamp_lstm.py): selected by pe_lstm_configure_stamps, never
+// by the environment
+static bool g_lstm_stamps = false;
 
 int sync_words(int ncells, int B) { return kCtrStride * (1 + 2 * ncells * ((B + 63) / 64)); }
 
@@ -1707,23 +1198,39 @@ extern "C" size_t pe_lstm_persistent_sync_bytes(int ncells, int B) {
 }
 #endif
 
-// 1 if the persistent kernels can run this shape on the current device (hidden size instantiated,
-// and the whole grid is co-resident at one workgroup per CU), else 0.
+// 1 if the persistent kernels can run this shape on the current device: the hidden size they are instantiated for
+// (H = 384, the reference's default, model.py:198), every tensor of a cell addressable with 32-bit offsets below 2 GiB,
+// the flag blocks within the sync buffer, and the whole grid co-resident at one workgroup per CU; else 0 (run the
+// one-launch-per-time-step kernels of lstm.hip).  The recurrent products are 16-bit-term MFMAs (three exact bf16 terms
+// or one rounded term): there is no native-fp32 persistent form.
 #ifndef PE_F16_BUILD
 extern "C" int pe_lstm_persistent_supported(int ncells, int B, int H) {
-  if (ncells < 1 || ncells > kMaxCells || B <= 0) return 0;
-  if (!(H == 32 || H == 64 || H == 96 || H == 384)) return 0;
+  if (ncells < 1 || ncells > kMaxCells || B <= 0 || H != 384) return 0;
+  if (sync_words(ncells, B) > kXchgWord || ncells * ((B + 63) / 64) * 128 > kFlagWords) return 0;
   const int grid = ncells * ((B + 63) / 64) * (H / 32);
   return grid <= device_cus() ? 1 : 0;
 }
+
+// Diagnostic: 1 = run the stamped instantiations (s_memtime per region, tools/stamp_lstm.py) where they exist (x3,
+// grid <= 128 workgroups).  Returns the previous setting.  Not used by the product path.
+extern "C" int pe_lstm_configure_stamps(int enable) {
+  const int old = g_lstm_stamps ? 1 : 0;
+  g_lstm_stamps = enable != 0;
+  return old;
+}
+#else
+extern "C" int pe_lstm_persistent_supported(int ncells, int B, int H);
 #endif
+
+static bool small_enough(int B, int T, int H, long ld) {
+  return (size_t)B * T * 4 * H * sizeof(float) < (1ull << 31) && (size_t)B * T * (size_t)ld * sizeof(float) < (1ull << 31);
+}
 
 static int lstm_fwd_persistent_impl(int terms, int ncells, const float* const* whh, float* const* gates,
                                     float* const* y, float* const* cbuf, const int* reverse, long ldy, int B, int T,
                                     int H, unsigned* sync, void* stream) {
   if (!whh || !gates || !y || !cbuf || !reverse || !sync || T <= 0) return PE_E_ARG;
-  if (!pe_lstm_persistent_supported(ncells, B, H) || (ldy & 3)) return PE_E_UNSUPPORTED;
-  if ((size_t)B * T * ldy * sizeof(float) >= (1ull << 32)) return PE_E_UNSUPPORTED;      // 32-bit buffer offsets
+  if (!pe_lstm_persistent_supported(ncells, B, H) || (ldy & 3) || !small_enough(B, T, H, ldy)) return PE_E_UNSUPPORTED;
   PFwdCells cells{};
   for (int i = 0; i < ncells; ++i) {
     if (!whh[i] || !gates[i] || !y[i] || !cbuf[i]) return PE_E_ARG;
@@ -1734,36 +1241,12 @@ static int lstm_fwd_persistent_impl(int terms, int ncells, const float* const* w
   // word 0 is the sticky error flag (cleared only by the owner of the buffer); counters start at line 1
   PE_CHECK_HIP(hipMemsetAsync(sync + kCtrStride, 0, (size_t)(sync_words(ncells, B) - kCtrStride) * 4, st));
   const int grid = ncells * ((B + 63) / 64) * (H / 32);
-  if (lstm_use_v2() && terms != 0 && (size_t)B * T * 4 * H * sizeof(float) < (1ull << 31) &&
-      (size_t)B * T * ldy * sizeof(float) < (1ull << 31)) {
-    if (H == 64) return terms == 3 ? launch_fwd_v2<64, 3, 1>(cells, grid, B, T, ldy, sync, st)
-                                   : launch_fwd_v2<64, 1, 1>(cells, grid, B, T, ldy, sync, st);
-    static const bool stamp = getenv("PE_LSTM_STAMP") && getenv("PE_LSTM_STAMP")[0] == '1';
-    if (H == 384 && terms == 3 && stamp && grid <= 128)
-      return launch_fwd_v2<384, 3, 4, true>(cells, grid, B, T, ldy, sync, st);
-    if (H == 384) return terms == 3 ? launch_fwd_v2<384, 3, 4>(cells, grid, B, T, ldy, sync, st)
-                                    : launch_fwd_v2<384, 1, 6>(cells, grid, B, T, ldy, sync, st);
-  }
-  switch (H) {                                   // the split form needs H % 64 == 0; other sizes stay native
-    case 32: return launch_fwd<32, 0>(cells, grid, B, T, ldy, sync, st);
-    case 64: return terms == 3 ? launch_fwd<64, 3>(cells, grid, B, T, ldy, sync, st)
-                  : terms == 1 ? launch_fwd<64, 1>(cells, grid, B, T, ldy, sync, st)
-                               : launch_fwd<64, 0>(cells, grid, B, T, ldy, sync, st);
-    case 96: return launch_fwd<96, 0>(cells, grid, B, T, ldy, sync, st);
-    case 384: return terms == 3 ? launch_fwd<384, 3>(cells, grid, B, T, ldy, sync, st)
-                   : terms == 1 ? launch_fwd<384, 1>(cells, grid, B, T, ldy, sync, st)
-                                : launch_fwd<384, 0>(cells, grid, B, T, ldy, sync, st);
-  }
-  return PE_E_UNSUPPORTED;
+  if (terms == 3 && g_lstm_stamps && grid <= 128) return launch_fwd_v2<384, 3, 4, true>(cells, grid, B, T, ldy, sync, st);
+  return terms == 3 ? launch_fwd_v2<384, 3, 4>(cells, grid, B, T, ldy, sync, st)
+                    : launch_fwd_v2<384, 1, 6>(cells, grid, B, T, ldy, sync, st);
 }
 
 #ifndef PE_F16_BUILD
-extern "C" int pe_lstm_fwd_persistent(int ncells, const float* const* whh, float* const* gates, float* const* y,
-                                      float* const* cbuf, const int* reverse, long ldy, int B, int T, int H,
-                                      unsigned* sync, void* stream) {
-  return lstm_fwd_persistent_impl(0, ncells, whh, gates, y, cbuf, reverse, ldy, B, T, H, sync, stream);
-}
-
 extern "C" int pe_lstm_fwd_persistent_x3(int ncells, const float* const* whh, float* const* gates, float* const* y,
                                          float* const* cbuf, const int* reverse, long ldy, int B, int T, int H,
                                          unsigned* sync, void* stream) {
@@ -1771,21 +1254,12 @@ extern "C" int pe_lstm_fwd_persistent_x3(int ncells, const float* const* whh, fl
 }
 #endif
 
-// does this configuration run the k-split backward kernel (the one that can also emit the bias-gradient rows)?
-static bool bwd_ks_eligible(int terms, int ncells, int B, int T, int H, long lddy) {
-  const bool small = (size_t)B * T * 4 * H * sizeof(float) < (1ull << 31) &&
-                     ((size_t)B * T * (size_t)lddy) * sizeof(float) < (1ull << 31);
-  return lstm_use_v2() && terms != 0 && small && sync_words(ncells, B) <= kXchgWord &&
-         ncells * ((B + 63) / 64) * 128 <= kFlagWords && H == 384;
-}
-
 static int lstm_bwd_persistent_impl(int terms, int ncells, const float* const* whh_t, float* const* gates,
                                     const float* const* cbuf, const float* const* dy, const int* reverse, long lddy,
                                     int B, int T, int H, float* const* dbias_rows, unsigned* const* dgates_amax,
                                     unsigned* sync, void* stream) {
   if (!whh_t || !gates || !cbuf || !dy || !reverse || !sync || T <= 0) return PE_E_ARG;
-  if (!pe_lstm_persistent_supported(ncells, B, H) || (lddy & 3)) return PE_E_UNSUPPORTED;
-  if ((size_t)B * T * 4 * H * sizeof(float) >= (1ull << 32)) return PE_E_UNSUPPORTED;
+  if (!pe_lstm_persistent_supported(ncells, B, H) || (lddy & 3) || !small_enough(B, T, H, lddy)) return PE_E_UNSUPPORTED;
   PBwdCells cells{};
   for (int i = 0; i < ncells; ++i) {
     if (!whh_t[i] || !gates[i] || !cbuf[i] || !dy[i]) return PE_E_ARG;
@@ -1796,42 +1270,19 @@ static int lstm_bwd_persistent_impl(int terms, int ncells, const float* const* w
   }
   hipStream_t st = pe_stream(stream);
   PE_CHECK_HIP(hipMemsetAsync(sync + kCtrStride, 0, (size_t)(sync_words(ncells, B) - kCtrStride) * 4, st));
+  PE_CHECK_HIP(hipMemsetAsync(sync + kXchgWord, 0, (size_t)ncells * ((B + 63) / 64) * 128 * sizeof(unsigned), st));
   const int grid = ncells * ((B + 63) / 64) * (H / 32);
-  // (the k-split kernel addresses every tensor of a cell with 32-bit offsets below 2 GiB)
-  if (bwd_ks_eligible(terms, ncells, B, T, H, lddy)) {
-    PE_CHECK_HIP(hipMemsetAsync(sync + kXchgWord, 0, (size_t)ncells * ((B + 63) / 64) * 128 * sizeof(unsigned), st));
-    static const bool stamp = getenv("PE_LSTM_STAMP") && getenv("PE_LSTM_STAMP")[0] == '1';
-    if (H == 384 && terms == 3 && stamp && grid <= 128) return launch_bwd_v2<384, 3, 8, true>(cells, grid, B, T, lddy, sync, st);
-    if (H == 384) return terms == 3 ? launch_bwd_v2<384, 3, 8>(cells, grid, B, T, lddy, sync, st)
-                                    : launch_bwd_v2<384, 1, 24>(cells, grid, B, T, lddy, sync, st);
-  }
-  switch (H) {
-    case 32: return launch_bwd<32, 0>(cells, grid, B, T, lddy, sync, st);
-    case 64: return terms == 3 ? launch_bwd<64, 3>(cells, grid, B, T, lddy, sync, st)
-                  : terms == 1 ? launch_bwd<64, 1>(cells, grid, B, T, lddy, sync, st)
-                               : launch_bwd<64, 0>(cells, grid, B, T, lddy, sync, st);
-    case 96: return launch_bwd<96, 0>(cells, grid, B, T, lddy, sync, st);
-    case 384: return terms == 3 ? launch_bwd<384, 3>(cells, grid, B, T, lddy, sync, st)
-                   : terms == 1 ? launch_bwd<384, 1>(cells, grid, B, T, lddy, sync, st)
-                                : launch_bwd<384, 0>(cells, grid, B, T, lddy, sync, st);
-  }
-  return PE_E_UNSUPPORTED;
+  if (terms == 3 && g_lstm_stamps && grid <= 128) return launch_bwd_v2<384, 3, 8, true>(cells, grid, B, T, lddy, sync, st);
+  return terms == 3 ? launch_bwd_v2<384, 3, 8>(cells, grid, B, T, lddy, sync, st)
+                    : launch_bwd_v2<384, 1, 24>(cells, grid, B, T, lddy, sync, st);
 }
 
 #ifndef PE_F16_BUILD
-extern "C" int pe_lstm_bwd_persistent(int ncells, const float* const* whh_t, float* const* gates,
-                                      const float* const* cbuf, const float* const* dy, const int* reverse,
-                                      long lddy, int B, int T, int H, float* const* dbias_rows,
-                                      unsigned* const* dgates_amax, unsigned* sync, void* stream) {
-  return lstm_bwd_persistent_impl(0, ncells, whh_t, gates, cbuf, dy, reverse, lddy, B, T, H, dbias_rows, dgates_amax, sync,
-                                  stream);
-}
-
-// Rows ([ceil(B / 64)][4H] per cell) that pe_lstm_bwd_persistent* (terms: 0 native, 3 split, 1 bf16 / fp16 operands)
-// writes into a non-null dbias_rows for this configuration; 0 = that kernel does not emit them (use pe_colsum).
-extern "C" int pe_lstm_bwd_persistent_dbias_rows(int terms, int ncells, int B, int T, int H, long lddy) {
-  if (!pe_lstm_persistent_supported(ncells, B, H) || (lddy & 3) || T <= 0) return 0;
-  return bwd_ks_eligible(terms, ncells, B, T, H, lddy) ? (B + 63) / 64 : 0;
+// Rows ([ceil(B / 64)][4H] per cell) that pe_lstm_bwd_persistent_* writes into a non-null dbias_rows for this
+// configuration; 0 = the persistent kernel does not serve it (run pe_lstm_bwd and pe_colsum).
+extern "C" int pe_lstm_bwd_persistent_dbias_rows(int ncells, int B, int T, int H, long lddy) {
+  if (!pe_lstm_persistent_supported(ncells, B, H) || (lddy & 3) || T <= 0 || !small_enough(B, T, H, lddy)) return 0;
+  return (B + 63) / 64;
 }
 
 extern "C" int pe_lstm_bwd_persistent_x3(int ncells, const float* const* whh_t, float* const* gates,

@@ -338,16 +338,12 @@ def _side_stream(dev):
     if key not in _SIDE_STREAMS:
         stream = None
         if os.environ.get("PE_SIDE_STREAM_PRIORITY", "low") == "low":
-            try:
-                import ctypes
-                hip = ctypes.CDLL("libamdhip64.so")
-                with torch.cuda.device(key):
-                    least, greatest, handle = ctypes.c_int(), ctypes.c_int(), ctypes.c_void_p()
-                    if (hip.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) == 0 and
-                            hip.hipStreamCreateWithPriority(ctypes.byref(handle), 1, least.value) == 0 and handle.value):
-                        stream = torch.cuda.ExternalStream(handle.value, device=key)     # 1 = hipStreamNonBlocking
-            except OSError:
-                stream = None
+            import ctypes
+            from . import _lib
+            handle = ctypes.c_void_p()
+            with torch.cuda.device(key):         # created by the HIP library's own runtime (include/pitchextractor_hip.h)
+                _lib.check(_lib.load().pe_stream_create_low_priority(ctypes.byref(handle)), "pe_stream_create_low_priority")
+            stream = torch.cuda.ExternalStream(handle.value, device=key)
         _SIDE_STREAMS[key] = stream if stream is not None else torch.cuda.Stream(device=key)
     return _SIDE_STREAMS[key]
 

@@ -298,13 +298,6 @@ class matmul_bf16:
 
 
 # ------------------------------------------------------------------ GEMM
-# x3 / bf16 modes, opt-in: pack gemm_nt's B operand (always a weight matrix here) into MFMA fragment order per call
-# and let the kernel read it from L2, so only A goes through LDS.  Bit-identical to the default kernel; measured at
-# 0.97x its speed on the LSTM projection shapes (tools/ab_gemm.py: the fragment loads cost what the LDS staging
-# did, tools/ablate_gemm.py), so it stays off -- unlike the convolution, where the window reuse makes it +9 %.
-GEMM_WFRAG = os.environ.get("PE_GEMM_WFRAG", "0") == "1"
-
-
 def gemm_nt(A, B, bias0=None, bias1=None, out=None, accumulate=False, amax_a=None, amax_b=None):
     """out[M,N] = A[M,K] @ B[N,K]^T + bias0 + bias1 (+ out).  ``amax_*``: the operands' absmax words when the caller
     already has them ("h2" mode; computed here otherwise)."""
@@ -326,12 +319,6 @@ def gemm_nt(A, B, bias0=None, bias1=None, out=None, accumulate=False, amax_a=Non
         if b is not None:
             _chk(_dense(b, "bias").numel() == N, "bias size")
     sfx = _nt_suffix()
-    if GEMM_WFRAG and sfx and K % 16 == 0 and N > 32 and M >= 128 and N * K <= (1 << 23) and lda % 4 == 0 \
-            and A.data_ptr() % 16 == 0:
-        wf = wfrag_pack(B, _mode_terms())
-        _call("pe_gemm_nt_wf" + sfx, A.data_ptr(), lda, wf.data_ptr(), out.data_ptr(), ldc, M, N, K,
-              _lib.ptr(bias0), _lib.ptr(bias1), int(bool(accumulate)), _s(), work=2.0 * M * N * K)
-        return out
     if sfx == "_h2":
         amax_a = absmax(A) if amax_a is None else amax_a
         amax_b = absmax(B) if amax_b is None else amax_b
@@ -775,8 +762,10 @@ def clear_persistent_lstm_error(device) -> None:
         buf[0:1].zero_()
 
 
-def _persistent_ok(ncells, B, H, device):
-    if not USE_PERSISTENT_LSTM:
+def _persistent_ok(ncells, B, H, device, which="fwd"):
+    """The persistent recurrence kernels serve this configuration: enabled, a 16-bit-term product form selected (x3 /
+    bf16 / f16: there is no native-fp32 persistent kernel) and the shape / device admitted by the library."""
+    if not USE_PERSISTENT_LSTM or _lstm_suffix(which) == "":
         return False
     with torch.cuda.device(device):
         return bool(_lib.load().pe_lstm_persistent_supported(ncells, B, H))
@@ -797,7 +786,7 @@ def lstm_fwd(whh, gates, y_slices, cbuf, reverse, B, T, H):
         _chk(ldy in (None, ys.stride(1)), "all y slices share ldy")
         ldy = ys.stride(1)
     dev = gates[0].device
-    if _persistent_ok(n, B, H, dev):
+    if _persistent_ok(n, B, H, dev, "fwd"):
         sync = _lstm_sync(n, B, dev)
         _call("pe_lstm_fwd_persistent" + _lstm_suffix("fwd"), n, _ptr_array(whh), _ptr_array(gates), _ptr_array(y_slices),
               _ptr_array(cbuf), _int_array(reverse), ldy, B, T, H, sync.data_ptr(), _s(),
@@ -827,7 +816,7 @@ def lstm_bwd(whh_t, gates, cbuf, dy_slices, dcarry, reverse, B, T, H, dbias_rows
         _chk(ld in (None, d.stride(1)), "all dy slices share ld")
         ld = d.stride(1)
     dev = gates[0].device
-    if _persistent_ok(n, B, H, dev):
+    if _persistent_ok(n, B, H, dev, "bwd"):
         sync = _lstm_sync(n, B, dev)
         rows = lstm_bwd_dbias_rows(n, B, T, H, ld, dev) if dbias_rows is not None else 0
         if rows:
@@ -846,11 +835,9 @@ def lstm_bwd(whh_t, gates, cbuf, dy_slices, dcarry, reverse, B, T, H, dbias_rows
 def lstm_bwd_dbias_rows(n, B, T, H, ld, device) -> int:
     """Rows of the per-cell [rows][4H] bias-gradient partials lstm_bwd can emit for this configuration (0: it cannot;
     sum the gate gradients with colsum instead)."""
-    if not _persistent_ok(n, B, H, device):
+    if not _persistent_ok(n, B, H, device, "bwd"):
         return 0
-    sfx = _lstm_suffix("bwd")
-    terms = 3 if sfx == "_x3" else (1 if sfx in ("_bf16", "_f16") else 0)
-    return int(_lib.load().pe_lstm_bwd_persistent_dbias_rows(terms, n, B, T, H, ld))
+    return int(_lib.load().pe_lstm_bwd_persistent_dbias_rows(n, B, T, H, ld))
 
 
 def lstm_whh_grad(dgates, y_slice, dwhh, reverse, B, T, H, amax_dg=None, amax_y=None):

@@ -165,4 +165,7 @@ def test_rccl_backend_world1_rehearsal(tmp_path):
     g, gb = r["fp32_grad"], r["bf16_grad"]
     assert np.array_equal(r["plain_grad"], g) and not np.array_equal(g, gb)
     assert np.array_equal(gb, torch.from_numpy(g).to(torch.bfloat16).float().numpy())
-    np.testing.assert_allclose(r["bf16"], r["plain"], rtol=0, atol=1e-4)        # two AdamW steps at lr 3e-4
+    # two AdamW steps at lr 3e-4: an element whose gradient sits at the bf16 rounding of ~0 can move by lr in opposite
+    # directions in each step (eps = 1e-9 makes the update sign-like there): 4 of 2.9 M elements differ by up to 2e-4
+    np.testing.assert_allclose(r["bf16"], r["plain"], rtol=0, atol=7e-4)
+    assert np.mean(np.abs(r["bf16"] - r["plain"]) > 1e-4) < 1e-5

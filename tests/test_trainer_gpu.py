@@ -104,8 +104,8 @@ def test_fault_word_skips_the_update_on_the_device_and_the_step_is_redone(hip_de
     and redo the step: parameters, moments and step count afterwards equal those of a trainer that ran on the
     per-time-step kernels all along, bit for bit."""
     monkeypatch.setattr(ops, "USE_PERSISTENT_LSTM", True)
-    cfg = dict(SEQ_CFG, hidden_size=64, num_layers=2)
-    state = model_ref.seeded_state(5, hidden_size=64, num_layers=2)
+    cfg = dict(SEQ_CFG, num_layers=2)                       # hidden size 384: the persistent kernels' shape
+    state = model_ref.seeded_state(5, num_layers=2)
     x = golden_input(3, B=8)
     f0, sil = golden_targets(3, B=8)
     batch = (x.transpose(-1, -2).contiguous(), f0, sil)
@@ -119,7 +119,7 @@ def test_fault_word_skips_the_update_on_the_device_and_the_step_is_redone(hip_de
 
     net, tr = fresh()
     first = tr.run(batch)                                   # a clean step on the persistent kernels
-    assert ops._persistent_ok(4, 8, 64, hip_device) and not ops.persistent_lstm_error(hip_device)
+    assert ops._persistent_ok(4, 8, 384, hip_device) and not ops.persistent_lstm_error(hip_device)
     assert net.status_slot().item() == 0.0
     ops._SYNC[torch.device(hip_device)][0] = 1              # the sticky word a timed-out hand-off leaves behind
     got = tr.run(batch)

@@ -1,15 +1,17 @@
-"""Where does an item of the overlapped persistent LSTM forward spend its cycles?  PE_LSTM_STAMP=1 build of the
-kernel on 2 cells (grid 96 <= 128: the stamp area of the sync buffer), B=256, T=192, H=384; prints per-region
+"""Where does an item of the overlapped persistent LSTM forward spend its cycles?  The stamped instantiation of the
+kernel (pe_lstm_configure_stamps) on 2 cells (grid 96 <= 128: the stamp area of the sync buffer), B=256, T=192, H=384; prints per-region
 cycles per item (median over workgroups, wave 0)."""
 import os
 import sys
 from pathlib import Path
 
-os.environ["PE_LSTM_STAMP"] = "1"
 import torch  # noqa: E402
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-from pitchextractor_amd import ops  # noqa: E402
+from pitchextractor_amd import _lib, ops  # noqa: E402
+
+ops.FP32_MATMUL = "x3"
+_lib.load().pe_lstm_configure_stamps(1)
 
 dev = torch.device("cuda:0")
 B, T, H, NC = 256, 192, 384, 2
