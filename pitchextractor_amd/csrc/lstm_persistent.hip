@@ -207,6 +207,24 @@ __device__ __forceinline__ float4 load_sc1(__amdgpu_buffer_rsrc_t rs, unsigned b
   return make_float4(__uint_as_float(d.x), __uint_as_float(d.y), __uint_as_float(d.z), __uint_as_float(d.w));
 }
 
+// the same two for handed-off data kept in 16 bits (bf16, round to nearest even): 8 bytes per lane.  The mixed-
+// precision backward kernel exchanges its partial dh tiles this way -- it is bound by that exchange, not by its MFMAs
+// (the three-term and the one-term build took the same time), and the operands of these products are bf16 already.
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_sc1_h(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, float4 v) {
+  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const f2 lo = {v.x, v.y}, hi = {v.z, v.w};
+  const u32x2_t d = {__builtin_bit_cast(unsigned, __builtin_convertvector(lo, b2)),
+                     __builtin_bit_cast(unsigned, __builtin_convertvector(hi, b2))};
+  __builtin_amdgcn_raw_buffer_store_b64(d, rs, byte_off, 0, 16 /* sc1 */);
+}
+__device__ __forceinline__ float4 load_sc1_h(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+  const u32x2_t d = __builtin_amdgcn_raw_buffer_load_b64(rs, byte_off, 0, 16 /* sc1 */);
+  return make_float4(__uint_as_float(d.x << 16), __uint_as_float(d.x & 0xffff0000u), __uint_as_float(d.y << 16),
+                     __uint_as_float(d.y & 0xffff0000u));
+}
+
 // wait: one lane polls the counter (an sc1 load) until the group has arrived, then the workgroup
 // barrier releases the other waves.  Every load of handed-off bytes in these kernels is an sc1 load and
 // every such byte was stored sc1 and drained before the producer's atomic add (guide, Valid forms,
@@ -771,8 +789,17 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_ks_kernel(const PB
   constexpr int NKB = 8;                            // 16-k MFMA blocks over the 128 local k
   constexpr int NBK = NBW * NKB;                    // W blocks per lane
   constexpr int NBR = TERMS == 3 ? NBR_ : NBK;
-  constexpr unsigned TILE = 1024;                   // floats per 32 x 32 partial tile
+  constexpr unsigned TILE = 1024;                   // elements per 32 x 32 partial tile
   constexpr unsigned SLOT = NJ * NJ * TILE;
+  constexpr unsigned XB = TERMS == 1 ? 2u : 4u;      // bytes per exchanged tile element: bf16 in the one-term build
+  auto xstore = [&](__amdgpu_buffer_rsrc_t rs, unsigned off, float4 v) {
+    if constexpr (TERMS == 1) store_sc1_h(rs, off, v);
+    else store_sc1(rs, off, v);
+  };
+  auto xload = [&](__amdgpu_buffer_rsrc_t rs, unsigned off) -> float4 {
+    if constexpr (TERMS == 1) return load_sc1_h(rs, off);
+    else return load_sc1(rs, off);
+  };
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = TERMS == 3 ? 3 : 1;
   constexpr int DGH = NT * NKB * 2 * 32;            // uint4 per half
@@ -875,7 +902,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_ks_kernel(const PB
   // the NJ tiles addressed to this workgroup: tile p of (step, hf); group_wait(step, hf) must have returned
   auto tile_base = [&](int step, int hf) {
     return (((unsigned)(hf * 2 + (step & 1)) * NJ * NJ + (unsigned)jt * NJ) * TILE + (unsigned)(pq >> 1) * 256u +
-            (unsigned)prow * 8u + (unsigned)(pq & 1) * 4u) * 4u;
+            (unsigned)prow * 8u + (unsigned)(pq & 1) * 4u) * XB;
   };
   auto wait_peers = [&](int step, int hf, unsigned seen) {
     // No workgroup barrier: this slice's dg[hf] is protected by the barrier that ends the gate update between the
@@ -962,7 +989,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_ks_kernel(const PB
     const uint4* ap = dg + hf * DGH + hh * 32 + r;
     // lane (r, hh) ends up with, of batch row r, columns 8 i + 4 hh .. + 3 of consumer block wv * NBW + nb
     const unsigned xo = (((unsigned)(hf * 2 + (step & 1)) * NJ * NJ + (unsigned)jt) * TILE + (unsigned)r * 8u +
-                         (unsigned)hh * 4u) * 4u;
+                         (unsigned)hh * 4u) * XB;
     const unsigned tb = tile_base(pre_step, pre_hf);
     // two accumulator pairs (even / odd k groups), alternating per column block: the finished block's tile is summed
     // and stored piecewise in the next block's MFMA gaps instead of in one burst between the blocks
@@ -1019,12 +1046,12 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_ks_kernel(const PB
 #pragma unroll
           for (int u = 0; u < LPER; ++u) {
             const int p = (b - LPOLL) * LPER + u;
-            if (p < NJ) part[p < NJ ? p : 0] = load_sc1(xrs, tb + (unsigned)p * TILE * 4u);
+            if (p < NJ) part[p < NJ ? p : 0] = xload(xrs, tb + (unsigned)p * TILE * XB);
           }
         }
         if (nb > 0 && kb < 4)
-          store_sc1(xrs, xo + ((unsigned)((wv * NBW + nb - 1) * NJ) * TILE + (unsigned)kb * 256u) * 4u,
-                    tile_piece(accs[(nb - 1) & 1][0], accs[(nb - 1) & 1][1], kb));
+          xstore(xrs, xo + ((unsigned)((wv * NBW + nb - 1) * NJ) * TILE + (unsigned)kb * 256u) * XB,
+                 tile_piece(accs[(nb - 1) & 1][0], accs[(nb - 1) & 1][1], kb));
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (TERMS == 3) {
 #pragma unroll
@@ -1042,8 +1069,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_ks_kernel(const PB
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      store_sc1(xrs, xo + ((unsigned)((wv * NBW + NBW - 1) * NJ) * TILE + (unsigned)i * 256u) * 4u,
-                tile_piece(accs[(NBW - 1) & 1][0], accs[(NBW - 1) & 1][1], i));
+      xstore(xrs, xo + ((unsigned)((wv * NBW + NBW - 1) * NJ) * TILE + (unsigned)i * 256u) * XB,
+             tile_piece(accs[(NBW - 1) & 1][0], accs[(NBW - 1) & 1][1], i));
     PE_STAMP(2)                                                   // second half of the product, tile stores issued
   };
   // Hand-off of a product's tiles: each wave drains its own stores and arrives (no workgroup barrier: the next writer
@@ -1089,7 +1116,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_ks_kernel(const PB
       issue_inputs_all(step, 1);
       wait_peers(step, 1, flags_peek(flags + 64, 4 * NJ));
 #pragma unroll
-      for (int p = 0; p < NJ; ++p) part[p] = load_sc1(xrs, tile_base(step, 1) + (unsigned)p * TILE * 4u);
+      for (int p = 0; p < NJ; ++p) part[p] = xload(xrs, tile_base(step, 1) + (unsigned)p * TILE * XB);
       gate_update(step, H1{}, true, none);
     }
     PE_STAMP(5)

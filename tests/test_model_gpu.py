@@ -308,14 +308,17 @@ def test_full_size_mixed_precision_step_by_tiling(hip_device, oracle_b8, act16, 
     """BASELINE config[3]'s per-GPU shape (B = 256, default BiLSTM, 16-bit operands: the shipped config.yml's
     `mixed_precision: true`, `precision: bf16`): the same tiling argument with the mixed-precision kernels -- bf16 conv,
     GEMM and weight-gradient products and the 16-bit persistent recurrences on the full 192-workgroup grid.  Both runs
-    round their operands alike, so only summation orders differ: gradients within 1e-4 of the B = 8 run's largest
-    element (measured 3.7e-6).  The same bound holds with bf16 ACTIVATION STORAGE (act16, the trainer's default in this
-    mode; measured 9.2e-7): per-sample sums run in the same order at both batch sizes, so the stored bf16 values are
-    the same and only the batch-level reductions differ.
+    round their operands alike, so forward results agree to summation order: logits within 1e-4, loss 1e-6.  The
+    gradients agree to bf16 resolution only (2e-2 of each tensor's largest element; measured 5.5e-3, worst in front of
+    the first BatchNorms): the mixed-precision backward recurrence hands its partial dh tiles over in bf16, and a
+    1e-7 difference in an input (BatchNorm statistics summed over 256 instead of 8 samples) that lands on the other
+    side of a bf16 rounding boundary moves that tile element by 2^-8.  The recurrence kernels themselves are exactly
+    batch-size-, replica- and scale-invariant (tests/test_ops_gpu.py::test_mixed_precision_recurrences_are_exactly_
+    batch_and_scale_invariant).
     (fp16 operands are not comparable this way without the GradScaler: the per-element
     loss gradient is 32x smaller at B = 256 and underflows differently; that mode has its own test.)"""
     state, x8, f0, sil, (_, _, ref_loss, _) = oracle_b8
-    tol_out, tol_g = 1e-4, 1e-4
+    tol_out, tol_g = 1e-4, 2e-2
     with ops.matmul_bf16(True, dtype, act16=act16):
         cls8, det8, loss8, g8 = _hip_step_grads(state, x8, f0, sil, hip_device)
         cls, det, loss, g = _hip_step_grads(state, x8.repeat(32, 1, 1, 1), f0.repeat(32, 1), sil.repeat(32, 1),

@@ -524,6 +524,44 @@ def test_lstm_recurrence_mixed_precision(hip_device, B, T, H):
     assert not ops.persistent_lstm_error(dev)
 
 
+def test_mixed_precision_recurrences_are_exactly_batch_and_scale_invariant(hip_device):
+    """The persistent bf16 recurrences (forward; backward with its bf16 partial-tile exchange) on 4 cells: run-to-run
+    bit-identical, a sample's results do not depend on the batch it sits in (B = 256 of 32 replicas vs B = 8, and
+    replica vs replica), and scaling dY by 2^-5 scales every gate gradient by exactly 2^-5 (bf16 rounding is
+    scale-free): whatever differs between two batch sizes at model level comes from their inputs, not from here."""
+    dev = hip_device
+    T, H = 24, 384
+    torch.manual_seed(0)
+    whh = [torch.randn(4 * H, H, device=dev) * 0.05 for _ in range(4)]
+    g8 = [torch.randn(8, T, 4 * H, device=dev) for _ in range(4)]
+    dy8 = torch.randn(8, T, 2 * H, device=dev)
+
+    def run(B, scale=1.0):
+        reps = B // 8
+        gates = [g.repeat(reps, 1, 1).contiguous() for g in g8]
+        ys = [torch.empty(B, T, 2 * H, device=dev) for _ in range(2)]
+        ysl = [ys[i // 2][:, :, (i % 2) * H:(i % 2 + 1) * H] for i in range(4)]
+        cb = [torch.empty(B, T, H, device=dev) for _ in range(4)]
+        with ops.matmul_bf16(True):
+            assert ops._persistent_ok(4, B, H, dev)
+            ops.lstm_fwd(whh, gates, ysl, cb, [0, 1, 0, 1], B, T, H)
+            dy = (dy8 * scale).repeat(reps, 1, 1).contiguous()
+            dsl = [dy[:, :, (i % 2) * H:(i % 2 + 1) * H] for i in range(4)]
+            dc = [torch.empty(B, H, device=dev) for _ in range(4)]
+            ops.lstm_bwd([ops.transpose2d(w) for w in whh], gates, cb, dsl, dc, [0, 1, 0, 1], B, T, H)
+        return gates, ys
+
+    a, ya = run(256)
+    b, yb = run(256)
+    c, yc = run(8)
+    e, _ = run(256, 1.0 / 32)
+    for i in range(4):
+        assert torch.equal(a[i], b[i]) and torch.equal(ya[i // 2], yb[i // 2])
+        assert torch.equal(a[i][:8], c[i]) and torch.equal(a[i][8:16], a[i][:8]) and torch.equal(ya[i // 2][:8], yc[i // 2])
+        assert torch.equal(e[i][:8] * 32, c[i])
+    assert not ops.persistent_lstm_error(dev)
+
+
 # ------------------------------------------------------------------ heads / loss / AdamW
 def test_heads(hip_device):
     R, D = 777, 768
