@@ -10,9 +10,9 @@ already resident in HBM: fused mel front end -> JDCNet forward -> SmoothL1+BCE l
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints one JSON line.  ``value`` is the HBM-resident rate (inputs in HBM when the timed region
-starts).  ``roofline`` prices the dominant kernel family (the 3x3 implicit-GEMM convolutions: forward +
-data-gradient launches of ``conv3x3_halo_kernel``) by algorithmic FLOPs over HIP-event time measured inside
-the timed region; ``roofline_mel`` does the same for the fused mel front end against HBM bandwidth
+starts; the PCIe-inclusive rate is the side field ``from_host``).  ``roofline`` prices the dominant kernel family (the
+3x3 convolutions: forward + data-gradient launches of ``conv3x3_halo_wf_kernel``) by algorithmic FLOPs over HIP-event
+time measured inside the timed region, and carries ``whole_step`` = all of the step's algorithmic FLOPs over the step time; ``roofline_mel`` does the same for the fused mel front end against HBM bandwidth
 (1 520 B per frame).  After the timed region (N = 1 only, never part of ``value``):
 ``kernel_families`` = HIP events around every C-ABI call for a few extra steps (ms/step, share of the step,
 achieved rate and fraction of the matching peak, all computed here); ``from_host`` = the same step fed from
@@ -151,6 +151,7 @@ def _family_table(summ, steps, step_ms):
             else:
                 # the entry point's suffix names the pipe its products ran on
                 base = name.split("#")[0]           # "#tag": ops.timer_tag (e.g. the overlapped dgrad launches)
+                base = base[:-4] if base.endswith("_a16") else base
                 peak = (MFMA_BF16_PEAK_TFLOPS if base.endswith("_bf16") else
                         MFMA_BF16_PEAK_TFLOPS / 6.0 if base.endswith("_x3") else
                         MFMA_BF16_PEAK_TFLOPS / 3.0 if base.endswith("_h2") else MFMA_F32_PEAK_TFLOPS)
@@ -277,7 +278,8 @@ def main():
     fp32_mode = ops.FP32_MATMUL
     sfx = "_bf16" if bf16 else "_h2" if h2 else "_x3" if x3 else ""
     conv_key = "pe_conv3x3_fwd" + sfx
-    conv_keys = {conv_key, "pe_conv3x3_fwd_wf" + sfx}       # weights staged through LDS / fed as fragments from L2
+    # weights staged through LDS / fed as fragments from L2; "_a16": bf16 activation storage (mixed precision)
+    conv_keys = {conv_key, "pe_conv3x3_fwd_wf" + sfx, conv_key + "_a16", "pe_conv3x3_fwd_wf" + sfx + "_a16"}
     ops.TIMER = ops.KernelTimer(None if args.family_timing else conv_keys | {"pe_mel_forward"})
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -381,7 +383,7 @@ def main():
         # the roofline is taken over launches that run ALONE: forward + dgrad when nothing overlaps them, forward only
         # when the dgrad launches share the GPU with the side-stream weight-gradient kernels
         conv = fwd_only if (overlapped or dgrad is None) else fold(conv_keys | {k + "#dgrad" for k in conv_keys})
-        wf_used = ("pe_conv3x3_fwd_wf" + sfx) in summ
+        wf_used = ("pe_conv3x3_fwd_wf" + sfx) in summ or ("pe_conv3x3_fwd_wf" + sfx + "_a16") in summ
         roof = None
         if conv:
             tflops = conv["work"] / (conv["total_ms"] * 1e-3) / 1e12        # algorithmic 2*M*N*K per launch
@@ -402,7 +404,7 @@ def main():
             roof = {"bound": "mfma", "kernel": ("conv3x3_kernel (implicit-GEMM; " + which + ")" if not (bf16 or x3) else
                                                 ("conv3x3_halo_wf_kernel (halo-staged activations, weight fragments from L2; "
                                                  + which + ")" if wf_used else
-                                                 "conv3x3_halo_kernel (halo-staged implicit GEMM; " + which + ")")),
+                                                 "conv3x3_kernel (implicit GEMM, 16-bit terms; " + which + ")")),
                     "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak,
                     "peak_note": note, "traffic": pmc_traffic(conv_key)[0], "mfma_busy_pmc": pmc_traffic(conv_key)[1],
                     "traffic_source": pmc_source() + " (rocprofv3 --pmc passes of this command, committed; not "
