@@ -12,6 +12,8 @@
 
 namespace {
 using namespace pe;
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------- weight repack (OIHW -> packed)
 __global__ void repack3x3_kernel(const float* __restrict__ w, float* __restrict__ w_fwd,
@@ -193,32 +195,52 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_wf_kernel(const TA* __res
 
   typedef typename RawQuad<TA>::type Raw;      // the staged window keeps its storage form until the LDS stores
   Raw ra[PASSES];
+  // Branch-free loads: ONE buffer instruction per request, rows outside the window / the tensor point past the
+  // descriptor's range and read as zero (host: every tensor below 2 GiB).  With predicated global loads hipcc branches
+  // around each of them and can no longer count what is in flight: it waited `vmcnt(0)` in front of the first MFMA of
+  // every channel chunk, i.e. for the window of the NEXT chunk it had just requested from HBM (seen in the .s).
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<TA*>(x), 0, (unsigned)((long)P * C * (long)sizeof(TA)), 0x00020000);
+  unsigned voa[PASSES];
+#pragma unroll
+  for (int ps = 0; ps < PASSES; ++ps) {
+    const int wr = ps * 32 + srow;
+    const long q = (long)p0 - F - 1 + wr;
+    voa[ps] = (wr < WR && q >= 0 && q < P) ? (unsigned)((q * C + piece * 4) * (long)sizeof(TA)) : 0x80000000u;
+  }
   auto fetch_a = [&](int cc) {
+    const unsigned so = (unsigned)(cc * 32 * (int)sizeof(TA));
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
-      const int wr = ps * 32 + srow;
-      const long q = (long)p0 - F - 1 + wr;
-      ra[ps] = zero_raw<Raw>();
-      if (wr < WR && q >= 0 && q < P) ra[ps] = ldraw(x + q * C + cc * 32 + piece * 4);
+      if constexpr (std::is_same<TA, float>::value) {
+        const u32x4_t d = __builtin_amdgcn_raw_buffer_load_b128(xrs, voa[ps], so, 0);
+        ra[ps] = make_float4(__uint_as_float(d.x), __uint_as_float(d.y), __uint_as_float(d.z), __uint_as_float(d.w));
+      } else {
+        const u32x2_t d = __builtin_amdgcn_raw_buffer_load_b64(xrs, voa[ps], so, 0);
+        ra[ps] = make_uint2(d.x, d.y);
+      }
     }
   };
 
-  // weight fragments: element offsets (in uint4) of this wave's n-blocks; a tile hanging over N re-reads the last
-  // block (its columns are dropped by the epilogue)
+  // weight fragments: byte offsets of this wave's n-blocks inside a 16-k block; a tile hanging over N re-reads the
+  // last block (its columns are dropped by the epilogue)
   const int NB32 = (N + 31) >> 5, kb_tap = C >> 4;
-  int nbo[TN];
+  const int kb_stride = NB32 * NT * 64;                            // uint4 per 16-k block
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint4*>(wf), 0, (unsigned)((long)9 * kb_tap * kb_stride * 16), 0x00020000);
+  unsigned vow[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int nb = (n0 + wn * WN + j * 32) >> 5;
-    nbo[j] = (nb < NB32 ? nb : NB32 - 1) * NT * 64 + lane;
+    vow[j] = (unsigned)(((nb < NB32 ? nb : NB32 - 1) * NT * 64 + lane) * 16);
   }
-  const int kb_stride = NB32 * NT * 64;                            // uint4 per 16-k block
   bf16x8 ring[D][NT];
   auto issue = [&](int slot, int cc, int s) {                      // s = (tap * 2 + kk) * TN + j
     const int j = s % TN, kk = (s / TN) & 1, tap = s / (2 * TN);
-    const uint4* pw = wf + (long)(tap * kb_tap + cc * 2 + kk) * kb_stride + nbo[j];
+    const unsigned so = (unsigned)((tap * kb_tap + cc * 2 + kk) * kb_stride) * 16u;      // wave-uniform
 #pragma unroll
-    for (int c = 0; c < NT; ++c) ring[slot][c] = __builtin_bit_cast(bf16x8, pw[c * 64]);
+    for (int c = 0; c < NT; ++c)
+      ring[slot][c] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, vow[j], so + (unsigned)c * 1024u, 0));
   };
 
   f32x16 acc[TM][TN];
@@ -340,6 +362,8 @@ int launch_conv_halo_wf(const TA* x, const void* wf, TA* y, int B, int T, int F,
   PE_LAUNCH_CHECK();
   return PE_OK;
 }
+
+static inline size_t pe_wfrag_bytes_host(int N, int K, int terms) { return (size_t)((N + 31) / 32) * (K / 16) * terms * 1024; }
 
 // which staged-window variant serves (F, N): 7 passes + a 128/192-wide tile, 10 passes + a 64-wide tile
 // (two workgroups per CU must fit the LDS), or 0 = use the implicit-GEMM kernel
@@ -936,6 +960,9 @@ static int conv3x3_fwd_wf_impl(const TA* x, const void* wfrag, TA* y, int B, int
                                const unsigned* amax_w = nullptr) {
   if (!x || !wfrag || !y || B <= 0 || T <= 0 || F <= 0 || C <= 0 || N <= 0) return PE_E_ARG;
   if ((C % 32) != 0 || (long)B * T * F * (C > N ? C : N) >= (1L << 31)) return PE_E_UNSUPPORTED;
+  // the kernel addresses x and the fragment buffer through 32-bit buffer offsets, out-of-range = past 2 GiB
+  if ((long)B * T * F * C * (long)sizeof(TA) >= (1L << 31) || (long)pe_wfrag_bytes_host(N, 9 * C, mode_terms<MODE>()) >= (1L << 31))
+    return PE_E_UNSUPPORTED;
   if (MODE == kSplit2 && (!amax_x || !amax_w)) return PE_E_ARG;
   hipStream_t st = pe_stream(stream);
   const int passes = conv_halo_passes(F, N);
