@@ -46,6 +46,18 @@ __device__ __forceinline__ float4 widen(const uint2& u) {
   return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
                      __uint_as_float(u.y & 0xffff0000u));
 }
+// the same quad through a buffer descriptor: voffset / soffset in bytes, out-of-range requests read as zero
+template <class T> __device__ __forceinline__ typename RawQuad<T>::type ldraw_buffer(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff);
+template <> __device__ __forceinline__ float4 ldraw_buffer<float>(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+  const u4 d = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+  return make_float4(__uint_as_float(d.x), __uint_as_float(d.y), __uint_as_float(d.z), __uint_as_float(d.w));
+}
+template <> __device__ __forceinline__ uint2 ldraw_buffer<act16_t>(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+  typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+  const u2 d = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+  return make_uint2(d.x, d.y);
+}
 template <class R> __device__ __forceinline__ R zero_raw();
 template <> __device__ __forceinline__ float4 zero_raw<float4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 template <> __device__ __forceinline__ uint2 zero_raw<uint2>() { return make_uint2(0u, 0u); }

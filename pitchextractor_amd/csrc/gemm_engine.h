@@ -58,19 +58,32 @@ __device__ __forceinline__ int xcd_remap(int bid, int ntiles) {
 // A loader hands out float4 = 4 consecutive k of one row.  `slot` i in [0, LOADS) addresses
 // row (tid >> 3) + 32 * i of the tile; k4 = (tid & 7) * 4 within the 32-wide k-tile.
 
+// Loads go through a buffer descriptor based at the tile's first row: ONE instruction per request, rows past the
+// matrix (and the k tail) read as zero by the descriptor's range check.  Predicated global loads cost a branch, an exec
+// save/restore, a 64-bit address add and four zero-fill moves each in the k-loop, and hipcc, unable to count loads it
+// branches around, waits for ALL of them (vmcnt(0)) wherever one is needed.
 template <class T>
 struct RowLoaderT {           // plain row-major matrix of T (float, or bf16 activations), rows x K, leading dimension ld
   const T* p;
   long ld;
   int rows, K;
   int row0;
+  const T* base_ = nullptr;   // device state, set by init()
+  unsigned bytes_ = 0, vo_ = 0, rowstep_ = 0;
   typedef typename RawQuad<T>::type Raw;
-  __device__ __forceinline__ void init(int first_row) { row0 = first_row + (threadIdx.x >> 3); }
+  __device__ __forceinline__ void init(int first_row) {
+    row0 = first_row + (threadIdx.x >> 3);
+    const long left = (long)rows - first_row;                       // a tile spans at most 256 rows: offsets fit 32 bits
+    long bytes = left > 0 ? ((left - 1) * ld + K) * (long)sizeof(T) : 0;
+    bytes_ = (unsigned)(bytes < 0x7fffffffL ? bytes : 0x7fffffffL);
+    base_ = p + (long)first_row * ld;
+    vo_ = (unsigned)(((long)(threadIdx.x >> 3) * ld + (threadIdx.x & 7) * 4) * (long)sizeof(T));
+    rowstep_ = (unsigned)(32 * ld * (long)sizeof(T));
+  }
   __device__ __forceinline__ Raw load(int slot, int kt) const {
-    const int row = row0 + 32 * slot;
-    const int k = kt * kBK + (threadIdx.x & 7) * 4;
-    if (row < rows && k < K) return ldraw(p + (long)row * ld + k);
-    return zero_raw<Raw>();
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base_), 0, bytes_, 0x00020000);
+    const unsigned ktail = (kt * kBK + (int)(threadIdx.x & 7) * 4 < K) ? 0u : 0x80000000u;
+    return ldraw_buffer<T>(rs, (vo_ + (unsigned)slot * rowstep_) | ktail, (unsigned)(kt * kBK * (int)sizeof(T)));
   }
 };
 typedef RowLoaderT<float> RowLoader;
@@ -345,16 +358,26 @@ struct H2Scales {                                                   // s_a, s_b 
 
 struct Split2 { uint2 hi, lo; };                                    // 4 consecutive k of one row, packed fp16 pairs
 
+// lo pair of two elements: RN_f16(x * s - hi) with ONE mixed-precision FMA per element (fp32 x and s, fp16 hi read
+// straight from its packed half, fp16 result written into its half of the destination).  x * s - hi is exact in fp32
+// (s is a power of two and hi is within half an fp16 ulp of x * s), so this equals convert(fma) of the three-step form
+// and costs 2 VALU per pair instead of 4 (unpack, packed FMA, pack): the staging passes of the h2 kernels are VALU-bound.
+__device__ __forceinline__ unsigned split2_lo_pair(float x, float y, float s, unsigned hi) {
+  unsigned lo;
+  asm("v_fma_mixlo_f16 %0, %1, %3, -%4 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %0, %2, %3, -%4 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=&v"(lo) : "v"(x), "v"(y), "v"(s), "v"(hi));
+  return lo;
+}
+
 __device__ __forceinline__ Split2 split2(const float4& v, float s) {
   typedef _Float16 h2v __attribute__((ext_vector_type(2)));
   typedef float f2v __attribute__((ext_vector_type(2)));
   const f2v t0 = {v.x * s, v.y * s}, t1 = {v.z * s, v.w * s};
   const h2v h0 = __builtin_convertvector(t0, h2v), h1 = __builtin_convertvector(t1, h2v);
-  const f2v r0 = t0 - __builtin_convertvector(h0, f2v), r1 = t1 - __builtin_convertvector(h1, f2v);
-  const h2v l0 = __builtin_convertvector(r0, h2v), l1 = __builtin_convertvector(r1, h2v);
   Split2 o;
   o.hi = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
-  o.lo = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
+  o.lo = make_uint2(split2_lo_pair(v.x, v.y, s, o.hi.x), split2_lo_pair(v.z, v.w, s, o.hi.y));
   return o;
 }
 
@@ -533,17 +556,24 @@ struct TnGeom {
 };
 
 template <int COLS, class TA = float>
-struct KRowLoader {           // plain [K][cols] matrix
+struct KRowLoader {           // plain [K][cols] matrix; buffer loads based at the k-tile's first row (see RowLoaderT)
   const TA* p;
   long ld;
   int cols;
   int col0;
+  unsigned vo_ = 0, rowstep_ = 0;
   typedef typename RawQuad<TA>::type Raw;
-  __device__ __forceinline__ void init(int first_col, int /*k_begin*/) { col0 = first_col + TnGeom<COLS>::col4(); }
+  __device__ __forceinline__ void init(int first_col, int /*k_begin*/) {
+    col0 = first_col + TnGeom<COLS>::col4();
+    vo_ = (unsigned)(((long)(threadIdx.x / TnGeom<COLS>::TPR) * ld + col0) * (long)sizeof(TA)) | (col0 < cols ? 0u : 0x80000000u);
+    rowstep_ = (unsigned)(TnGeom<COLS>::ROWS * ld * (long)sizeof(TA));
+  }
   __device__ __forceinline__ Raw load(int slot, int k0, int k_end) const {
-    const int k = k0 + TnGeom<COLS>::krow(slot);
-    if (k < k_end && col0 < cols) return ldraw(p + (long)k * ld + col0);
-    return zero_raw<Raw>();
+    const long left = (long)k_end - k0;                               // wave-uniform: SALU
+    long bytes = left > 0 ? ((left - 1) * ld + cols) * (long)sizeof(TA) : 0;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<TA*>(p + (long)k0 * ld), 0, (unsigned)(bytes < 0x7fffffffL ? bytes : 0x7fffffffL), 0x00020000);
+    return ldraw_buffer<TA>(rs, vo_ + (unsigned)slot * rowstep_, 0u);
   }
 };
 
