@@ -560,22 +560,32 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(const TA* __r
   const int c4 = (tid & 15) * 4;
   typedef typename RawQuad<TA>::type Raw;
   Raw ry[2], rx[7];
+  // Branch-free requests (see RowLoaderT): the descriptors are re-based per k-tile in scalar registers -- dY at pixel
+  // k0 with the rows left in this split as its range, X at the first pixel of the three-row window (clamped to the
+  // tensor; offsets of pixels in front of it wrap to huge unsigned values) -- so every out-of-range pixel reads as zero.
+  constexpr unsigned kEsz = (unsigned)sizeof(TA);
+  unsigned voy[2], vox[7];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) voy[i] = (unsigned)(((tid >> 4) + 16 * i) * Cout + m0 + c4) * kEsz;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int wr = (tid >> 4) + 16 * i;
+    const int w = wr / 34, row = wr - w * 34;
+    vox[i] = wr < 102 ? (unsigned)((w * F + row) * Cin + n0 + c4) * kEsz : 0x80000000u;
+  }
   auto fetch = [&](int k0) {
+    const int rows_y = min(ke - k0, kBK);
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<TA*>(dy + (long)k0 * Cout), 0, (unsigned)(rows_y > 0 ? rows_y * Cout : 0) * kEsz, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int k = k0 + (tid >> 4) + 16 * i;
-      ry[i] = k < ke ? ldraw(dy + (long)k * Cout + m0 + c4) : zero_raw<Raw>();
-    }
+    for (int i = 0; i < 2; ++i) ry[i] = ldraw_buffer<TA>(rsy, voy[i], 0u);
+    const int first = k0 - F - 1, base_row = first > 0 ? first : 0;
+    const int nrows = min(P - base_row, 2 * F + 36);
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<TA*>(x + (long)base_row * Cin), 0, (unsigned)(nrows > 0 ? nrows * Cin : 0) * kEsz, 0x00020000);
+    const unsigned dlt = (unsigned)((first - base_row) * Cin) * kEsz;        // <= 0: wraps
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      const int wr = (tid >> 4) + 16 * i;
-      rx[i] = zero_raw<Raw>();
-      if (wr < 102) {
-        const int w = wr / 34, row = wr - w * 34;
-        const long q = (long)k0 + (long)(w - 1) * F + row - 1;
-        if (q >= 0 && q < P) rx[i] = ldraw(x + q * Cin + n0 + c4);
-      }
-    }
+    for (int i = 0; i < 7; ++i) rx[i] = ldraw_buffer<TA>(rsx, vox[i] + dlt, 0u);
   };
   auto store3 = [&](__bf16* img, int img_elems, int off, const Raw& raw, float scale) {
     if constexpr (NT == 1 && !std::is_same<TA, float>::value) {

@@ -438,7 +438,7 @@ __device__ __forceinline__ void halo_store(__bf16* img, int img_elems, int row, 
   else halo_store<NT>(img, img_elems, row, piece, widen(raw), scale);
 }
 
-template <class TL, bool SW = false, int NT = 3, class AL, class BL>
+template <class TL, bool SW = false, int NT = 3, int PF = 1, class AL, class BL>
 __device__ __forceinline__ void nt_mainloop_split(AL& al, BL& bl, int K, float* As_f, float* Bs_f,
                                                   f32x16 (&acc)[TL::TM][TL::TN], float sa = 1.0f, float sb = 1.0f) {
   // unpadded, XOR-swizzled term images (swz_off): 64 B per row and term, so a 128 x 128 tile takes 48 KB (three
@@ -450,27 +450,37 @@ __device__ __forceinline__ void nt_mainloop_split(AL& al, BL& bl, int K, float* 
   const int wm = wv / TL::WAVES_N, wn = wv % TL::WAVES_N;
   const int r = lane & 31, h = lane >> 5;
   const int nk = (K + kBK - 1) / kBK;
-  decltype(al.load(0, 0)) ra[TL::A_LOADS];
-  decltype(bl.load(0, 0)) rb[TL::B_LOADS];
-#pragma unroll
-  for (int i = 0; i < TL::A_LOADS; ++i) ra[i] = al.load(i, 0);
-#pragma unroll
-  for (int i = 0; i < TL::B_LOADS; ++i) rb[i] = bl.load(i, 0);
   const int srow = tid >> 3, piece = tid & 7;
+  // PF k-tiles of operand quads in flight in registers.  PF = 2: the loads of tile kt + 2 are issued while tile kt's
+  // products run and are first needed two stage phases later (one MFMA phase of a k-tile is ~0.7 us, an HBM round trip
+  // under load 1.5-2 us: with one tile in flight every stage phase began by waiting for memory, WAIT_INST_ANY 44 % in
+  // the PMC run).  Needs loaders whose requests are unconditional and read as zero past K (the buffer loaders), so the
+  // compiler counts vmcnt exactly and the stage of tile kt waits for its own quads only; 40 more registers.
+  decltype(al.load(0, 0)) ra[PF][TL::A_LOADS];
+  decltype(bl.load(0, 0)) rb[PF][TL::B_LOADS];
+#pragma unroll
+  for (int q = 0; q < PF; ++q) {
+#pragma unroll
+    for (int i = 0; i < TL::A_LOADS; ++i) ra[q][i] = al.load(i, q);
+#pragma unroll
+    for (int i = 0; i < TL::B_LOADS; ++i) rb[q][i] = bl.load(i, q);
+  }
 
-  for (int kt = 0; kt < nk; ++kt) {
+  auto tile = [&](auto qc, int kt) {
+    constexpr int q = decltype(qc)::value;
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < TL::A_LOADS; ++i) halo_store<NT>(As, A_IMG, srow + 32 * i, piece, ra[i], sa);
+    for (int i = 0; i < TL::A_LOADS; ++i) halo_store<NT>(As, A_IMG, srow + 32 * i, piece, ra[q][i], sa);
 #pragma unroll
-    for (int i = 0; i < TL::B_LOADS; ++i) halo_store<NT>(Bs, B_IMG, srow + 32 * i, piece, rb[i], sb);
+    for (int i = 0; i < TL::B_LOADS; ++i) halo_store<NT>(Bs, B_IMG, srow + 32 * i, piece, rb[q][i], sb);
     __syncthreads();
-    if (kt + 1 < nk) {
+    if (PF == 2 || kt + 1 < nk) {
 #pragma unroll
-      for (int i = 0; i < TL::A_LOADS; ++i) ra[i] = al.load(i, kt + 1);
+      for (int i = 0; i < TL::A_LOADS; ++i) ra[q][i] = al.load(i, kt + PF);
 #pragma unroll
-      for (int i = 0; i < TL::B_LOADS; ++i) rb[i] = bl.load(i, kt + 1);
+      for (int i = 0; i < TL::B_LOADS; ++i) rb[q][i] = bl.load(i, kt + PF);
     }
+    if constexpr (PF == 2) __builtin_amdgcn_sched_barrier(0);   // requests first, then the products: nothing of the next stage up here
 #pragma unroll
     for (int kk = 0; kk < kBK / 16; ++kk) {
       bf16x8 fa[TL::TM][NT], fb[TL::TN][NT];
@@ -489,7 +499,16 @@ __device__ __forceinline__ void nt_mainloop_split(AL& al, BL& bl, int K, float* 
 #pragma unroll
         for (int j = 0; j < TL::TN; ++j) acc[i][j] = mfma_terms<NT, SW>(fa[i], fb[j], acc[i][j]);
     }
+    if constexpr (PF == 2) __builtin_amdgcn_sched_barrier(0);   // (the other set's split, hoisted, would wait for ITS loads here)
+  };
+  int kt = 0;
+  if constexpr (PF == 2) {
+    for (; kt + 1 < nk; kt += 2) {           // straight-line pairs: a conditional second tile costs the exact vmcnt
+      tile(std::integral_constant<int, 0>{}, kt);
+      tile(std::integral_constant<int, 1>{}, kt + 1);
+    }
   }
+  for (; kt < nk; ++kt) tile(std::integral_constant<int, 0>{}, kt);
 }
 
 // compile-time loop: body(std::integral_constant<int, I>) for I = 0 .. N-1 (a plain `#pragma unroll` loop of a few
@@ -505,12 +524,12 @@ template <int MODE> constexpr int nt_row_floats() {
   return MODE == kSplit ? kSplitRowFloats : MODE == kSplit2 ? 2 * kBK / 2 : kLdsStride;
 }
 
-template <class TL, int MODE, bool SW = false, class AL, class BL>
+template <class TL, int MODE, bool SW = false, int PF = 1, class AL, class BL>
 __device__ __forceinline__ void nt_mainloop_mode(AL& al, BL& bl, int K, float* As, float* Bs,
                                                  f32x16 (&acc)[TL::TM][TL::TN], float sa = 1.0f, float sb = 1.0f) {
   if constexpr (MODE == kBf16) nt_mainloop_bf16<TL>(al, bl, K, As, Bs, acc);
-  else if constexpr (MODE == kSplit) nt_mainloop_split<TL, SW, 3>(al, bl, K, As, Bs, acc);
-  else if constexpr (MODE == kSplit2) nt_mainloop_split<TL, SW, 2>(al, bl, K, As, Bs, acc, sa, sb);
+  else if constexpr (MODE == kSplit) nt_mainloop_split<TL, SW, 3, PF>(al, bl, K, As, Bs, acc);
+  else if constexpr (MODE == kSplit2) nt_mainloop_split<TL, SW, 2, PF>(al, bl, K, As, Bs, acc, sa, sb);
   else nt_mainloop<TL>(al, bl, K, As, Bs, acc);
 }
 
@@ -729,7 +748,7 @@ __device__ __forceinline__ void tn_split_store(__bf16* img, int off, const uint2
   else tn_split_store<COLS, NT>(img, off, widen(raw), scale);
 }
 
-template <int BM, int BN, int NT, class AL, class BL>
+template <int BM, int BN, int NT, int PF = 1, class AL, class BL>
 __device__ __forceinline__ void tn_mainloop_split(AL& al, BL& bl, int k_begin, int k_end, float* As_f, float* Bs_f,
                                                   f32x16 (&acc)[BM / 64][BN / 64], float sa = 1.0f, float sb = 1.0f) {
   constexpr int TM = BM / 64, TN = BN / 64;
@@ -741,29 +760,35 @@ __device__ __forceinline__ void tn_mainloop_split(AL& al, BL& bl, int k_begin, i
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm = wv >> 1, wn = wv & 1;
   const int h = lane >> 5, g1 = (lane >> 4) & 1, q = (lane & 15) >> 2, p4 = (lane & 3) * 4;
-  decltype(al.load(0, 0, 0)) ra[SA];
-  decltype(bl.load(0, 0, 0)) rb[SB];
+  // PF k-tiles of operand quads in flight (see nt_mainloop_split; PF = 2 needs the buffer loaders)
+  decltype(al.load(0, 0, 0)) ra[PF][SA];
+  decltype(bl.load(0, 0, 0)) rb[PF][SB];
 #pragma unroll
-  for (int i = 0; i < SA; ++i) ra[i] = al.load(i, k_begin, k_end);
+  for (int u = 0; u < PF; ++u) {
 #pragma unroll
-  for (int i = 0; i < SB; ++i) rb[i] = bl.load(i, k_begin, k_end);
+    for (int i = 0; i < SA; ++i) ra[u][i] = al.load(i, k_begin + u * kBK, k_end);
+#pragma unroll
+    for (int i = 0; i < SB; ++i) rb[u][i] = bl.load(i, k_begin + u * kBK, k_end);
+  }
   const int sta = (tid / TnGeom<BM>::TPR) * STA + TnGeom<BM>::col4();
   const int stb = (tid / TnGeom<BN>::TPR) * STB + TnGeom<BN>::col4();
   const __bf16* a_rd = As + (8 * h + q) * STA + wm * (BM / 2) + 16 * g1 + p4;
   const __bf16* b_rd = Bs + (8 * h + q) * STB + wn * (BN / 2) + 16 * g1 + p4;
-  for (int k0 = k_begin; k0 < k_end; k0 += kBK) {
+  auto tile = [&](auto uc, int k0) {
+    constexpr int u = decltype(uc)::value;
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < SA; ++i) tn_split_store<BM, NT>(As, sta + i * TnGeom<BM>::ROWS * STA, ra[i], sa);
+    for (int i = 0; i < SA; ++i) tn_split_store<BM, NT>(As, sta + i * TnGeom<BM>::ROWS * STA, ra[u][i], sa);
 #pragma unroll
-    for (int i = 0; i < SB; ++i) tn_split_store<BN, NT>(Bs, stb + i * TnGeom<BN>::ROWS * STB, rb[i], sb);
+    for (int i = 0; i < SB; ++i) tn_split_store<BN, NT>(Bs, stb + i * TnGeom<BN>::ROWS * STB, rb[u][i], sb);
     __syncthreads();
-    if (k0 + kBK < k_end) {
+    if (PF == 2 || k0 + kBK < k_end) {
 #pragma unroll
-      for (int i = 0; i < SA; ++i) ra[i] = al.load(i, k0 + kBK, k_end);
+      for (int i = 0; i < SA; ++i) ra[u][i] = al.load(i, k0 + PF * kBK, k_end);
 #pragma unroll
-      for (int i = 0; i < SB; ++i) rb[i] = bl.load(i, k0 + kBK, k_end);
+      for (int i = 0; i < SB; ++i) rb[u][i] = bl.load(i, k0 + PF * kBK, k_end);
     }
+    if constexpr (PF == 2) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kk = 0; kk < kBK / 16; ++kk) {
       bf16x8 fa[TM][NT], fb[TN][NT];
@@ -780,7 +805,16 @@ __device__ __forceinline__ void tn_mainloop_split(AL& al, BL& bl, int k_begin, i
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = mfma_terms<NT>(fa[i], fb[j], acc[i][j]);
     }
+    if constexpr (PF == 2) __builtin_amdgcn_sched_barrier(0);
+  };
+  int k0 = k_begin;
+  if constexpr (PF == 2) {
+    for (; k0 + kBK < k_end; k0 += 2 * kBK) {
+      tile(std::integral_constant<int, 0>{}, k0);
+      tile(std::integral_constant<int, 1>{}, k0 + kBK);
+    }
   }
+  for (; k0 < k_end; k0 += kBK) tile(std::integral_constant<int, 0>{}, k0);
 }
 
 template <int MODE, int COLS> constexpr int tn_lds_floats() {
@@ -788,12 +822,12 @@ template <int MODE, int COLS> constexpr int tn_lds_floats() {
        : MODE == kBf16 ? tn_split_floats<COLS, 1>() : kBK * COLS;
 }
 
-template <int MODE, int BM, int BN, class AL, class BL>
+template <int MODE, int BM, int BN, int PF = 1, class AL, class BL>
 __device__ __forceinline__ void tn_mainloop_mode(AL& al, BL& bl, int k_begin, int k_end, float* As, float* Bs,
                                                  f32x16 (&acc)[BM / 64][BN / 64], float sa = 1.0f, float sb = 1.0f) {
-  if constexpr (MODE == kSplit) tn_mainloop_split<BM, BN, 3>(al, bl, k_begin, k_end, As, Bs, acc);
-  else if constexpr (MODE == kSplit2) tn_mainloop_split<BM, BN, 2>(al, bl, k_begin, k_end, As, Bs, acc, sa, sb);
-  else if constexpr (MODE == kBf16) tn_mainloop_split<BM, BN, 1>(al, bl, k_begin, k_end, As, Bs, acc);
+  if constexpr (MODE == kSplit) tn_mainloop_split<BM, BN, 3, PF>(al, bl, k_begin, k_end, As, Bs, acc);
+  else if constexpr (MODE == kSplit2) tn_mainloop_split<BM, BN, 2, PF>(al, bl, k_begin, k_end, As, Bs, acc, sa, sb);
+  else if constexpr (MODE == kBf16) tn_mainloop_split<BM, BN, 1, PF>(al, bl, k_begin, k_end, As, Bs, acc);
   else tn_mainloop<BM, BN>(al, bl, k_begin, k_end, As, Bs, acc);
 }
 
