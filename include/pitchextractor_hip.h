@@ -194,6 +194,15 @@ int pe_attn_fwd(const float* qkv, long ld_qkv, float* o, long ld_o, float* lse, 
 int pe_attn_bwd(const float* qkv, long ld_qkv, const float* o, const float* d_o, long ld_o, const float* lse,
                 const unsigned char* mask, float* dqkv, int B, int T, int H, int dh, float scale, float p_drop,
                 void* stream);
+/* The same two passes with the matmul operands (Q, K, V, dO, the probabilities and the score gradients) rounded to
+ * bf16 and multiplied on v_mfma_f32_16x16x16_bf16, as torch.autocast runs the attention of trainer.py:226-235; softmax,
+ * log-sum-exp, accumulation and every tensor in memory stay fp32, masks and Philox counters as above. */
+int pe_attn_fwd_bf16(const float* qkv, long ld_qkv, float* o, long ld_o, float* lse, const unsigned char* mask_in,
+                     unsigned char* mask_out, int B, int T, int H, int dh, float scale, float p_drop,
+                     unsigned long long seed, unsigned long long offset, void* stream);
+int pe_attn_bwd_bf16(const float* qkv, long ld_qkv, const float* o, const float* d_o, long ld_o, const float* lse,
+                     const unsigned char* mask, float* dqkv, int B, int T, int H, int dh, float scale, float p_drop,
+                     void* stream);
 
 /* ---- fp16 operands (the reference's autocast default dtype, trainer.py:64-102) -------------------------------
  * Same contracts as the *_bf16 entry points above with operands rounded (RNE) to IEEE half instead of bf16 and

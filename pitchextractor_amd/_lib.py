@@ -110,6 +110,8 @@ PROTOTYPES = {
     "pe_attn_supported": (_i, [_i, _i]),
     "pe_attn_fwd": (_i, [_p, _l, _p, _l, _p, _p, _p, _i, _i, _i, _i, _f, _f, _u64, _u64, _p]),
     "pe_attn_bwd": (_i, [_p, _l, _p, _p, _l, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p]),
+    "pe_attn_fwd_bf16": (_i, [_p, _l, _p, _l, _p, _p, _p, _i, _i, _i, _i, _f, _f, _u64, _u64, _p]),
+    "pe_attn_bwd_bf16": (_i, [_p, _l, _p, _p, _l, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p]),
     "pe_softmax_fwd": (_i, [_p, _l, _i, _f, _p]),
     "pe_softmax_bwd": (_i, [_p, _p, _l, _i, _f, _p]),
     "pe_layernorm_fwd": (_i, [_p, _p, _p, _i, _p, _p, _f, _p, _p, _p, _p, _l, _i, _p]),

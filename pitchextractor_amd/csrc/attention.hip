@@ -20,6 +20,7 @@
 // and no score tile is ever transposed through LDS.  The backward recomputes S twice (two kernels) instead:
 // deterministic, no atomics, no cross-workgroup reduction.
 #include "common.h"
+#include "act16.h"
 
 // XCD-aware block order (workgroups b and b + 8 share an XCD and its L2): give every XCD a contiguous run of
 // logical blocks, so the workgroups that read the same K / V rows hit the same L2.  Bijective for any grid size.
@@ -38,6 +39,32 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f32x4v mfma16(float a, float b, f32x4v c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// Four k-slots at once: c += sum_n a_n * b_n, the four exact-fp32 MFMAs above in the order n = 0..3, or -- mixed
+// precision, as autocast runs these matmuls -- ONE v_mfma_f32_16x16x16_bf16 on the operands rounded to bf16.  The maps
+// agree: the fp32 MFMA n of a group reads A[i][k = g] = a_n of lane (i, g), the bf16 MFMA reads A[i][k = 4 g + n] from
+// the n-th element of lane (i, g)'s quad, likewise B; the accumulator layouts are the same, so "accumulator as the next
+// operand" carries over (the four registers of a score tile, rounded, ARE the bf16 B quad).
+typedef short bf16x4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x4s pack4(float a, float b, float c, float d) {
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  const u2 v = {pe::pack_bf16_rne(a, b), pe::pack_bf16_rne(c, d)};
+  return __builtin_bit_cast(bf16x4s, v);
+}
+template <bool BF>
+__device__ __forceinline__ f32x4v mm4(float a0, float a1, float a2, float a3, float b0, float b1, float b2, float b3,
+                                      f32x4v c) {
+  if constexpr (BF) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pack4(a0, a1, a2, a3), pack4(b0, b1, b2, b3), c, 0, 0, 0);
+  } else {
+    c = mfma16(a0, b0, c); c = mfma16(a1, b1, c); c = mfma16(a2, b2, c); c = mfma16(a3, b3, c);
+    return c;
+  }
+}
+template <bool BF>
+__device__ __forceinline__ f32x4v mm4(const float4& a, const float4& b, f32x4v c) {
+  return mm4<BF>(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c);
 }
 
 struct AttnArgs {
@@ -87,7 +114,7 @@ __device__ __forceinline__ void row_dots(const float* __restrict__ a, long lda, 
 // and ran at a third of this rate: nothing hid the LDS and exp latencies.)
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int T>
+template <int T, bool BF>
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs a) {
   constexpr int NT = T / 16, HR = T / 2, NH = NT / 2;       // HR rows / NH tiles per half
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -130,10 +157,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs a) {
       for (int s = 0; s < 4; ++s) {
         const float4 k0 = *reinterpret_cast<const float4*>(Ks + (16 * kl + j) * kStr + 16 * s + 4 * g);
         const float4 k1 = *reinterpret_cast<const float4*>(Ks + (16 * kl + 16 + j) * kStr + 16 * s + 4 * g);
-        acc[kt] = mfma16(k0.x, qf[s].x, acc[kt]);         acc[kt + 1] = mfma16(k1.x, qf[s].x, acc[kt + 1]);
-        acc[kt] = mfma16(k0.y, qf[s].y, acc[kt]);         acc[kt + 1] = mfma16(k1.y, qf[s].y, acc[kt + 1]);
-        acc[kt] = mfma16(k0.z, qf[s].z, acc[kt]);         acc[kt + 1] = mfma16(k1.z, qf[s].z, acc[kt + 1]);
-        acc[kt] = mfma16(k0.w, qf[s].w, acc[kt]);         acc[kt + 1] = mfma16(k1.w, qf[s].w, acc[kt + 1]);
+        acc[kt] = mm4<BF>(k0, qf[s], acc[kt]);
+        acc[kt + 1] = mm4<BF>(k1, qf[s], acc[kt + 1]);
       }
     }
   }
@@ -196,14 +221,14 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
     for (int kl = 0; kl < NH; ++kl) {
       const int kt = half * NH + kl;
+      float4 vf[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float4 vf = *reinterpret_cast<const float4*>(Vs + (16 * kl + 4 * g + r) * kStr + 4 * j);
-        o[0] = mfma16(vf.x, acc[kt][r], o[0]);
-        o[1] = mfma16(vf.y, acc[kt][r], o[1]);
-        o[2] = mfma16(vf.z, acc[kt][r], o[2]);
-        o[3] = mfma16(vf.w, acc[kt][r], o[3]);
-      }
+      for (int r = 0; r < 4; ++r) vf[r] = *reinterpret_cast<const float4*>(Vs + (16 * kl + 4 * g + r) * kStr + 4 * j);
+      const f32x4v pk = acc[kt];
+      o[0] = mm4<BF>(vf[0].x, vf[1].x, vf[2].x, vf[3].x, pk[0], pk[1], pk[2], pk[3], o[0]);
+      o[1] = mm4<BF>(vf[0].y, vf[1].y, vf[2].y, vf[3].y, pk[0], pk[1], pk[2], pk[3], o[1]);
+      o[2] = mm4<BF>(vf[0].z, vf[1].z, vf[2].z, vf[3].z, pk[0], pk[1], pk[2], pk[3], o[2]);
+      o[3] = mm4<BF>(vf[0].w, vf[1].w, vf[2].w, vf[3].w, pk[0], pk[1], pk[2], pk[3], o[3]);
     }
   }
   // lane (j, g) holds d = 16 g + 4 r + dt of query q0 + j: 64 contiguous bytes
@@ -215,7 +240,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs a) {
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
 // Wave owns one key tile; scores with QUERIES on the rows, keys on the lane.  The K / V fragments of the key tile are
 // loaded from global into registers once; Q and dO pass through LDS in two halves; lse / delta of all queries in LDS.
-template <int T>
+template <int T, bool BF>
 __global__ __launch_bounds__(256, 3) void attn_bwd_kv_kernel(const AttnArgs a) {
   constexpr int NT = T / 16, HR = T / 2, NH = NT / 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -266,10 +291,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kv_kernel(const AttnArgs a) {
       for (int s = 0; s < 4; ++s) {
         const float4 qa = *reinterpret_cast<const float4*>(Qs + (qb + j) * kStr + 16 * s + 4 * g);
         const float4 ga = *reinterpret_cast<const float4*>(Gs + (qb + j) * kStr + 16 * s + 4 * g);
-        sc = mfma16(qa.x, kf[s].x, sc); dp = mfma16(ga.x, vf[s].x, dp);
-        sc = mfma16(qa.y, kf[s].y, sc); dp = mfma16(ga.y, vf[s].y, dp);
-        sc = mfma16(qa.z, kf[s].z, sc); dp = mfma16(ga.z, vf[s].z, dp);
-        sc = mfma16(qa.w, kf[s].w, sc); dp = mfma16(ga.w, vf[s].w, dp);
+        sc = mm4<BF>(qa, kf[s], sc);
+        dp = mm4<BF>(ga, vf[s], dp);
       }
       f32x4v pd, ds;
 #pragma unroll
@@ -282,15 +305,20 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kv_kernel(const AttnArgs a) {
         ds[r] = p * (dp[r] * keep - dl_s[q]) * a.scale;             // gradient of the raw score
       }
       // dV^T[d][key] += dO[query][d] Pd[query][key];  dK^T[d][key] += Q[query][d] dS[query][key]
+      float4 gq[4], qq[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float4 gf = *reinterpret_cast<const float4*>(Gs + (qb + 4 * g + r) * kStr + 4 * j);
-        const float4 qf = *reinterpret_cast<const float4*>(Qs + (qb + 4 * g + r) * kStr + 4 * j);
-        dv[0] = mfma16(gf.x, pd[r], dv[0]); dk[0] = mfma16(qf.x, ds[r], dk[0]);
-        dv[1] = mfma16(gf.y, pd[r], dv[1]); dk[1] = mfma16(qf.y, ds[r], dk[1]);
-        dv[2] = mfma16(gf.z, pd[r], dv[2]); dk[2] = mfma16(qf.z, ds[r], dk[2]);
-        dv[3] = mfma16(gf.w, pd[r], dv[3]); dk[3] = mfma16(qf.w, ds[r], dk[3]);
+        gq[r] = *reinterpret_cast<const float4*>(Gs + (qb + 4 * g + r) * kStr + 4 * j);
+        qq[r] = *reinterpret_cast<const float4*>(Qs + (qb + 4 * g + r) * kStr + 4 * j);
       }
+      dv[0] = mm4<BF>(gq[0].x, gq[1].x, gq[2].x, gq[3].x, pd[0], pd[1], pd[2], pd[3], dv[0]);
+      dk[0] = mm4<BF>(qq[0].x, qq[1].x, qq[2].x, qq[3].x, ds[0], ds[1], ds[2], ds[3], dk[0]);
+      dv[1] = mm4<BF>(gq[0].y, gq[1].y, gq[2].y, gq[3].y, pd[0], pd[1], pd[2], pd[3], dv[1]);
+      dk[1] = mm4<BF>(qq[0].y, qq[1].y, qq[2].y, qq[3].y, ds[0], ds[1], ds[2], ds[3], dk[1]);
+      dv[2] = mm4<BF>(gq[0].z, gq[1].z, gq[2].z, gq[3].z, pd[0], pd[1], pd[2], pd[3], dv[2]);
+      dk[2] = mm4<BF>(qq[0].z, qq[1].z, qq[2].z, qq[3].z, ds[0], ds[1], ds[2], ds[3], dk[2]);
+      dv[3] = mm4<BF>(gq[0].w, gq[1].w, gq[2].w, gq[3].w, pd[0], pd[1], pd[2], pd[3], dv[3]);
+      dk[3] = mm4<BF>(qq[0].w, qq[1].w, qq[2].w, qq[3].w, ds[0], ds[1], ds[2], ds[3], dk[3]);
     }
   }
   float* drow = a.dqkv + ((long)b * T + k0 + j) * a.ld_qkv + a.D + h * kDh + 16 * g;
@@ -303,7 +331,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kv_kernel(const AttnArgs a) {
 
 // ------------------------------------------------------------------------------------------------ backward: dQ
 // Wave owns one query tile; scores with KEYS on the rows, queries on the lane (the forward's orientation).
-template <int T>
+template <int T, bool BF>
 __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const AttnArgs a) {
   constexpr int NT = T / 16, HR = T / 2, NH = NT / 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -357,10 +385,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const AttnArgs a) {
       for (int s = 0; s < 4; ++s) {
         const float4 ka = *reinterpret_cast<const float4*>(Ks + (kb + j) * kStr + 16 * s + 4 * g);
         const float4 va = *reinterpret_cast<const float4*>(Vs + (kb + j) * kStr + 16 * s + 4 * g);
-        sc = mfma16(ka.x, qf[s].x, sc); dp = mfma16(va.x, gf[s].x, dp);
-        sc = mfma16(ka.y, qf[s].y, sc); dp = mfma16(va.y, gf[s].y, dp);
-        sc = mfma16(ka.z, qf[s].z, sc); dp = mfma16(va.z, gf[s].z, dp);
-        sc = mfma16(ka.w, qf[s].w, sc); dp = mfma16(va.w, gf[s].w, dp);
+        sc = mm4<BF>(ka, qf[s], sc);
+        dp = mm4<BF>(va, gf[s], dp);
       }
       float keep[4] = {1.f, 1.f, 1.f, 1.f};
       if (drop) {
@@ -375,14 +401,13 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const AttnArgs a) {
         ds[r] = p * (dp[r] * keep[r] - delta) * a.scale;
       }
       // dQ^T[d][query] += K[key][d] dS^T[key][query]
+      float4 kq[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float4 kf = *reinterpret_cast<const float4*>(Ks + (kb + 4 * g + r) * kStr + 4 * j);
-        dq[0] = mfma16(kf.x, ds[r], dq[0]);
-        dq[1] = mfma16(kf.y, ds[r], dq[1]);
-        dq[2] = mfma16(kf.z, ds[r], dq[2]);
-        dq[3] = mfma16(kf.w, ds[r], dq[3]);
-      }
+      for (int r = 0; r < 4; ++r) kq[r] = *reinterpret_cast<const float4*>(Ks + (kb + 4 * g + r) * kStr + 4 * j);
+      dq[0] = mm4<BF>(kq[0].x, kq[1].x, kq[2].x, kq[3].x, ds[0], ds[1], ds[2], ds[3], dq[0]);
+      dq[1] = mm4<BF>(kq[0].y, kq[1].y, kq[2].y, kq[3].y, ds[0], ds[1], ds[2], ds[3], dq[1]);
+      dq[2] = mm4<BF>(kq[0].z, kq[1].z, kq[2].z, kq[3].z, ds[0], ds[1], ds[2], ds[3], dq[2]);
+      dq[3] = mm4<BF>(kq[0].w, kq[1].w, kq[2].w, kq[3].w, ds[0], ds[1], ds[2], ds[3], dq[3]);
     }
   }
   float* drow = a.dqkv + ((long)b * T + q0 + j) * a.ld_qkv + h * kDh + 16 * g;
@@ -402,9 +427,10 @@ int set_lds(K kernel, size_t bytes) {
 
 extern "C" int pe_attn_supported(int T, int dh) { return attn_shape_ok(T, dh) ? 1 : 0; }
 
-extern "C" int pe_attn_fwd(const float* qkv, long ld_qkv, float* o, long ld_o, float* lse, const unsigned char* mask_in,
-                           unsigned char* mask_out, int B, int T, int H, int dh, float scale, float p_drop,
-                           unsigned long long seed, unsigned long long offset, void* stream) {
+template <bool BF>
+static int attn_fwd_impl(const float* qkv, long ld_qkv, float* o, long ld_o, float* lse, const unsigned char* mask_in,
+                         unsigned char* mask_out, int B, int T, int H, int dh, float scale, float p_drop,
+                         unsigned long long seed, unsigned long long offset, void* stream) {
   if (!qkv || !o || !lse || B <= 0 || H <= 0 || p_drop < 0.f || p_drop >= 1.f) return PE_E_ARG;
   if (!attn_shape_ok(T, dh) || (ld_qkv & 3) || (ld_o & 3) || ld_qkv < 3L * H * dh || ld_o < (long)H * dh)
     return PE_E_UNSUPPORTED;
@@ -414,15 +440,30 @@ extern "C" int pe_attn_fwd(const float* qkv, long ld_qkv, float* o, long ld_o, f
   a.keep_scale = 1.0f / (1.0f - p_drop); a.seed = seed; a.offset = offset;
   const size_t lds = (size_t)2 * 96 * kStr * sizeof(float);
   static bool attr = false;
-  if (!attr) { PE_CHECK_HIP((hipError_t)set_lds(&attn_fwd_kernel<192>, lds)); attr = true; }
-  hipLaunchKernelGGL(attn_fwd_kernel<192>, dim3(B * H * 3), dim3(256), lds, pe_stream(stream), a);
+  if (!attr) { PE_CHECK_HIP((hipError_t)set_lds(&attn_fwd_kernel<192, BF>, lds)); attr = true; }
+  hipLaunchKernelGGL((attn_fwd_kernel<192, BF>), dim3(B * H * 3), dim3(256), lds, pe_stream(stream), a);
   PE_LAUNCH_CHECK();
   return PE_OK;
 }
 
-extern "C" int pe_attn_bwd(const float* qkv, long ld_qkv, const float* o, const float* d_o, long ld_o, const float* lse,
-                           const unsigned char* mask, float* dqkv, int B, int T, int H, int dh, float scale,
-                           float p_drop, void* stream) {
+extern "C" int pe_attn_fwd(const float* qkv, long ld_qkv, float* o, long ld_o, float* lse, const unsigned char* mask_in,
+                           unsigned char* mask_out, int B, int T, int H, int dh, float scale, float p_drop,
+                           unsigned long long seed, unsigned long long offset, void* stream) {
+  return attn_fwd_impl<false>(qkv, ld_qkv, o, ld_o, lse, mask_in, mask_out, B, T, H, dh, scale, p_drop, seed, offset,
+                              stream);
+}
+extern "C" int pe_attn_fwd_bf16(const float* qkv, long ld_qkv, float* o, long ld_o, float* lse,
+                                const unsigned char* mask_in, unsigned char* mask_out, int B, int T, int H, int dh,
+                                float scale, float p_drop, unsigned long long seed, unsigned long long offset,
+                                void* stream) {
+  return attn_fwd_impl<true>(qkv, ld_qkv, o, ld_o, lse, mask_in, mask_out, B, T, H, dh, scale, p_drop, seed, offset,
+                             stream);
+}
+
+template <bool BF>
+static int attn_bwd_impl(const float* qkv, long ld_qkv, const float* o, const float* d_o, long ld_o, const float* lse,
+                         const unsigned char* mask, float* dqkv, int B, int T, int H, int dh, float scale,
+                         float p_drop, void* stream) {
   if (!qkv || !o || !d_o || !lse || !dqkv || B <= 0 || H <= 0 || p_drop < 0.f || p_drop >= 1.f) return PE_E_ARG;
   if (p_drop > 0.f && !mask) return PE_E_ARG;
   if (!attn_shape_ok(T, dh) || (ld_qkv & 3) || (ld_o & 3) || ld_qkv < 3L * H * dh || ld_o < (long)H * dh)
@@ -434,14 +475,25 @@ extern "C" int pe_attn_bwd(const float* qkv, long ld_qkv, const float* o, const 
   const size_t lds_kv = (size_t)(2 * 96 * kStr + 2 * 192) * sizeof(float), lds_q = (size_t)2 * 96 * kStr * sizeof(float);
   static bool attr = false;
   if (!attr) {
-    PE_CHECK_HIP((hipError_t)set_lds(&attn_bwd_kv_kernel<192>, lds_kv));
-    PE_CHECK_HIP((hipError_t)set_lds(&attn_bwd_q_kernel<192>, lds_q));
+    PE_CHECK_HIP((hipError_t)set_lds(&attn_bwd_kv_kernel<192, BF>, lds_kv));
+    PE_CHECK_HIP((hipError_t)set_lds(&attn_bwd_q_kernel<192, BF>, lds_q));
     attr = true;
   }
   hipStream_t st = pe_stream(stream);
-  hipLaunchKernelGGL(attn_bwd_kv_kernel<192>, dim3(B * H * 3), dim3(256), lds_kv, st, a);
+  hipLaunchKernelGGL((attn_bwd_kv_kernel<192, BF>), dim3(B * H * 3), dim3(256), lds_kv, st, a);
   PE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(attn_bwd_q_kernel<192>, dim3(B * H * 3), dim3(256), lds_q, st, a);
+  hipLaunchKernelGGL((attn_bwd_q_kernel<192, BF>), dim3(B * H * 3), dim3(256), lds_q, st, a);
   PE_LAUNCH_CHECK();
   return PE_OK;
+}
+
+extern "C" int pe_attn_bwd(const float* qkv, long ld_qkv, const float* o, const float* d_o, long ld_o, const float* lse,
+                           const unsigned char* mask, float* dqkv, int B, int T, int H, int dh, float scale,
+                           float p_drop, void* stream) {
+  return attn_bwd_impl<false>(qkv, ld_qkv, o, d_o, ld_o, lse, mask, dqkv, B, T, H, dh, scale, p_drop, stream);
+}
+extern "C" int pe_attn_bwd_bf16(const float* qkv, long ld_qkv, const float* o, const float* d_o, long ld_o,
+                                const float* lse, const unsigned char* mask, float* dqkv, int B, int T, int H, int dh,
+                                float scale, float p_drop, void* stream) {
+  return attn_bwd_impl<true>(qkv, ld_qkv, o, d_o, ld_o, lse, mask, dqkv, B, T, H, dh, scale, p_drop, stream);
 }

@@ -985,6 +985,12 @@ def attn_supported(T, dh):
     return bool(FUSED_ATTENTION and _lib.load().pe_attn_supported(int(T), int(dh)))
 
 
+def _attn_suffix():
+    """Mixed precision with bf16 operands runs the attention matmuls on the bf16 MFMA as autocast does (softmax, the
+    log-sum-exp and every tensor in memory stay fp32); the fp16 mode and the fp32 modes keep the exact-fp32 MFMAs."""
+    return "_bf16" if (MATMUL_BF16 and HALF_DTYPE == "bf16") else ""
+
+
 def attn_fwd(qkv, B, T, H, scale, p=0.0, mask_in=None, seed=0, offset=0):
     """Fused softmax(Q K^T * scale) -> dropout(p) -> . V for packed projections qkv [B*T, 3*H*dh].
     Returns (o [B*T, H*dh], lse [B*H*T], keep mask uint8 [B*H*T, T] or None)."""
@@ -1002,7 +1008,7 @@ def attn_fwd(qkv, B, T, H, scale, p=0.0, mask_in=None, seed=0, offset=0):
                  and mask_in.numel() == B * H * T * T, "attn_fwd: mask_in")
         else:
             mask_out = torch.empty((B * H * T, T), dtype=torch.uint8, device=qkv.device)
-    _call("pe_attn_fwd", qkv.data_ptr(), D3, o.data_ptr(), D, lse.data_ptr(), _lib.ptr(mask_in if p > 0.0 else None),
+    _call("pe_attn_fwd" + _attn_suffix(), qkv.data_ptr(), D3, o.data_ptr(), D, lse.data_ptr(), _lib.ptr(mask_in if p > 0.0 else None),
           _lib.ptr(mask_out), B, T, H, dh, float(scale), float(p), int(seed), int(offset), _s(),
           work=4.0 * B * H * T * T * dh)
     return o, lse, (mask_in if (p > 0.0 and mask_in is not None) else mask_out)
@@ -1019,7 +1025,7 @@ def attn_bwd(qkv, o, d_o, lse, mask, B, T, H, scale, p=0.0):
         _chk(mask is not None and mask.is_cuda and mask.dtype == torch.uint8 and mask.numel() == B * H * T * T,
              "attn_bwd: mask")
     dqkv = torch.empty_like(qkv)
-    _call("pe_attn_bwd", qkv.data_ptr(), D3, o.data_ptr(), d_o.data_ptr(), D, lse.data_ptr(),
+    _call("pe_attn_bwd" + _attn_suffix(), qkv.data_ptr(), D3, o.data_ptr(), d_o.data_ptr(), D, lse.data_ptr(),
           _lib.ptr(mask if p > 0.0 else None), dqkv.data_ptr(), B, T, H, dh, float(scale), float(p), _s(),
           work=10.0 * B * H * T * T * dh)
     return dqkv

@@ -256,6 +256,48 @@ def test_fused_attention_fwd_bwd(hip_device, p):
         assert torch.equal(o, o2)
 
 
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_fused_attention_bf16_operands(hip_device, p):
+    """Mixed precision (bf16): pe_attn_fwd_bf16 / pe_attn_bwd_bf16 round the matmul operands to bf16 and keep softmax,
+    log-sum-exp and accumulation in fp32.  Forward against a float64 restatement that rounds at the same points (Q, K, V
+    and the dropped-out probabilities): 1e-3 of the tensor maximum (a probability that sits near a bf16 rounding boundary
+    rounds differently from fp32 than from float64: measured 3.5e-4); log-sum-exp likewise; gradients against the EXACT
+    float64 gradient within 2e-2 of each tensor's maximum (bf16 operands: 2^-9 per product term); same masks and the
+    same Philox stream as the fp32 kernels."""
+    B, H, T, dh = 3, 8, 192, 64
+    D = H * dh
+    qkv = (rnd(B * T, 3 * D, seed=1) * 1.5).to(hip_device)
+    d_o = rnd(B * T, D, seed=2)
+    o32, lse32, mask32 = ops.attn_fwd(qkv, B, T, H, 0.125, p, seed=11, offset=1000)
+    with ops.matmul_bf16(True, "bf16"):
+        o, lse, mask = ops.attn_fwd(qkv, B, T, H, 0.125, p, seed=11, offset=1000)
+        dqkv = ops.attn_bwd(qkv, o, d_o.to(hip_device), lse, mask, B, T, H, 0.125, p)
+    if p > 0:
+        assert torch.equal(mask, mask32)
+    r16 = lambda t: t.to(torch.bfloat16).double()
+    x = qkv.cpu()
+    q, k, v = (r16(x[:, i * D:(i + 1) * D]).view(B, T, H, dh).transpose(1, 2) for i in range(3))
+    s = (q @ k.transpose(-1, -2)) * 0.125
+    P = torch.softmax(s, dim=-1)
+    if p > 0:
+        P = P * mask.cpu().view(B, H, T, T).double() / (1 - p)
+    ref_o = (r16(P.float()) @ v).transpose(1, 2).reshape(B * T, D)
+    assert (o.cpu().double() - ref_o).abs().max().item() <= 1e-3 * ref_o.abs().max().item()
+    assert (lse.cpu().double().view(B, H, T) - torch.logsumexp(s, dim=-1)).abs().max().item() <= 1e-5 * s.abs().max().item()
+    assert (o - o32).abs().max().item() <= 2e-2 * o32.abs().max().item()
+    # exact gradient of the exact forward
+    ref_in = x.double().requires_grad_(True)
+    q, k, v = (ref_in[:, i * D:(i + 1) * D].view(B, T, H, dh).transpose(1, 2) for i in range(3))
+    Pe = torch.softmax((q @ k.transpose(-1, -2)) * 0.125, dim=-1)
+    if p > 0:
+        Pe = Pe * mask.cpu().view(B, H, T, T).double() / (1 - p)
+    (Pe @ v).transpose(1, 2).reshape(B * T, D).backward(d_o.double())
+    for i in range(3):
+        ref = ref_in.grad[:, i * D:(i + 1) * D]
+        err = (dqkv[:, i * D:(i + 1) * D].cpu().double() - ref).abs().max().item()
+        assert err <= 2e-2 * ref.abs().max().item(), ("qkv"[i], err, ref.abs().max().item())
+
+
 def test_fused_and_unfused_attention_agree_in_the_model(hip_device, monkeypatch):
     """Whole Transformer-head JDCNet, train mode with live dropout: the fused attention path and the
     pe_bgemm + pe_softmax path give the same logits and gradients (same masks: same Philox offsets)."""

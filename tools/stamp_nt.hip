@@ -11,12 +11,14 @@ using namespace pe;
 
 enum { kFull = 0, kNoLoads = 1, kNoStage = 2, kNoFrag = 3, kNoMfma = 4, kNoSplit = 5, kSameTile = 6 };
 
-template <class TL, int AB, int OCC>
+template <class TL, int AB, int OCC, int PAD = 0>
 __global__ __launch_bounds__(256, OCC) void nt_kernel(RowLoader al, RowLoader bl, float* out, int ldc, int K, int tiles_m,
                                                       int tiles_n, float sa, float sb) {
   constexpr int NT = 2;
   __shared__ __attribute__((aligned(16))) float As_f[TL::BM * (2 * kBK / 2)];
   __shared__ __attribute__((aligned(16))) float Bs_f[TL::BN * (2 * kBK / 2)];
+  __shared__ float pad_lds[PAD + 1];
+  if (PAD > 0 && K < 0) pad_lds[threadIdx.x] = 1.f;
   const int tile_id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   const int m0 = (tile_id / tiles_n) * TL::BM, n0 = (tile_id % tiles_n) * TL::BN;
   al.init(m0);
@@ -214,7 +216,7 @@ void run_ov(const char* name, const float* A, const float* B, float* C, int M, i
 
 // Hand-ordered version of the same loop: one MFMA per slot, the slot's share of the next tile's staging behind it, a
 // scheduling fence after every slot.
-template <class TL, int OCC>
+template <class TL, int OCC, int PAD = 0>
 __global__ __launch_bounds__(256, OCC) void nt_slot_kernel(RowLoader al, RowLoader bl, float* out, int ldc, int K,
                                                            int tiles_m, int tiles_n, float sa, float sb) {
   constexpr int NT = 2;
@@ -224,6 +226,8 @@ __global__ __launch_bounds__(256, OCC) void nt_slot_kernel(RowLoader al, RowLoad
   constexpr int SLOTS = 2 * NB * 3;                        // MFMAs per k-tile
   __shared__ __attribute__((aligned(16))) __bf16 As[2][NT * A_IMG];
   __shared__ __attribute__((aligned(16))) __bf16 Bs[2][NT * B_IMG];
+  __shared__ float pad_lds[PAD + 1];
+  if (PAD > 0 && K < 0) pad_lds[threadIdx.x] = 1.f;         // keeps the padding allocated
   const int tile_id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   const int m0 = (tile_id / tiles_n) * TL::BM, n0 = (tile_id % tiles_n) * TL::BN;
   al.init(m0);
@@ -321,37 +325,37 @@ __global__ __launch_bounds__(256, OCC) void nt_slot_kernel(RowLoader al, RowLoad
     iter(std::integral_constant<int, 1>{}, kt + 1);
   }
   if (kt < nk) iter(std::integral_constant<int, 0>{}, kt);
-  for_each_acc<TL>(acc, [&](int rr, int cc, float v) { out[(long)(m0 + rr) * ldc + n0 + cc] = v; });
+  for_each_acc<TL>(acc, [&](int rr, int cc, float v) { out[(long)(m0 + rr) * ldc + n0 + cc] = v + (PAD > 0 && K < 0 ? pad_lds[0] : 0.f); });
 }
 
-template <class TL, int OCC>
+template <class TL, int OCC, int PAD = 0>
 void run_slot(const char* name, const float* A, const float* B, float* C, int M, int N, int K, int reps) {
   RowLoader al{A, (long)K, M, K, 0}, bl{B, (long)K, N, K, 0};
   const int tm = M / TL::BM, tn = N / TL::BN;
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int w = 0; w < 2; ++w) nt_slot_kernel<TL, OCC><<<tm * tn, 256>>>(al, bl, C, N, K, tm, tn, 1024.f, 1024.f);
+  for (int w = 0; w < 2; ++w) nt_slot_kernel<TL, OCC, PAD><<<tm * tn, 256>>>(al, bl, C, N, K, tm, tn, 1024.f, 1024.f);
   hipEventRecord(e0);
-  for (int w = 0; w < reps; ++w) nt_slot_kernel<TL, OCC><<<tm * tn, 256>>>(al, bl, C, N, K, tm, tn, 1024.f, 1024.f);
+  for (int w = 0; w < reps; ++w) nt_slot_kernel<TL, OCC, PAD><<<tm * tn, 256>>>(al, bl, C, N, K, tm, tn, 1024.f, 1024.f);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms = 0.f;
   hipEventElapsedTime(&ms, e0, e1);
   ms /= reps;
   int occ = 0;
-  hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, nt_slot_kernel<TL, OCC>, 256, 0);
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, nt_slot_kernel<TL, OCC, PAD>, 256, 0);
   printf("%-44s %.3f ms (%.0f TF)  %d WG/CU  %s\n", name, ms, 2.0 * M * N * K / ms * 1e-9, occ, hipGetErrorString(hipGetLastError()));
 }
 
-template <class TL, int AB, int OCC>
+template <class TL, int AB, int OCC, int PAD = 0>
 float run(const float* A, const float* B, float* C, int M, int N, int K, int reps) {
   RowLoader al{A, (long)K, M, K, 0}, bl{B, (long)K, N, K, 0};
   const int tm = M / TL::BM, tn = N / TL::BN;
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int w = 0; w < 2; ++w) nt_kernel<TL, AB, OCC><<<tm * tn, 256>>>(al, bl, C, N, K, tm, tn, 1024.f, 1024.f);
+  for (int w = 0; w < 2; ++w) nt_kernel<TL, AB, OCC, PAD><<<tm * tn, 256>>>(al, bl, C, N, K, tm, tn, 1024.f, 1024.f);
   hipEventRecord(e0);
-  for (int w = 0; w < reps; ++w) nt_kernel<TL, AB, OCC><<<tm * tn, 256>>>(al, bl, C, N, K, tm, tn, 1024.f, 1024.f);
+  for (int w = 0; w < reps; ++w) nt_kernel<TL, AB, OCC, PAD><<<tm * tn, 256>>>(al, bl, C, N, K, tm, tn, 1024.f, 1024.f);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms = 0.f;
@@ -373,6 +377,14 @@ void sweep(const char* name, const float* A, const float* B, float* C, int M, in
          name, t[0], fl / t[0] * 1e-9, t[1], t[2], t[3], t[4], t[5], tsame);
 }
 
+template <class TL>
+void one_wg(const float* A, const float* B, float* C, int M, int N, int K) {
+  const float t = run<TL, kFull, 1, 28000>(A, B, C, M, N, K, 20);
+  int occ = 0;
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, nt_kernel<TL, kFull, 1, 28000>, 256, 0);
+  printf("[%d WG/CU] two-barrier loop, padded LDS: %.3f ms\n", occ, t);
+}
+
 int main() {
   const int M = 49152, N = 768, K = 1536;
   float *A, *B, *C;
@@ -383,6 +395,8 @@ int main() {
   hipMemcpy(A, h.data(), (size_t)M * K * 4, hipMemcpyHostToDevice);
   hipMemcpy(B, h.data(), (size_t)N * K * 4, hipMemcpyHostToDevice);
   run_slot<Tile<128, 192, 2, 2>, 1>("slotted 128x192", A, B, C, M, N, K, 20);
+  run_slot<Tile<128, 192, 2, 2>, 1, 4096>("slotted 128x192, padded LDS", A, B, C, M, N, K, 20);
+  one_wg<Tile<128, 192, 2, 2>>(A, B, C, M, N, K);
   sweep<Tile<128, 192, 2, 2>, 2>("128x192, 2 WG/CU", A, B, C, M, N, K);
   hipMemset(A, 0, (size_t)M * K * 4); hipMemset(B, 0, (size_t)N * K * 4);
   sweep<Tile<128, 192, 2, 2>, 2>("128x192, zero data", A, B, C, M, N, K);
