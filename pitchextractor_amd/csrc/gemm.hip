@@ -219,6 +219,8 @@ static int gemm_nt_impl(const TA* A, long lda, const float* B, long ldb, TA* C, 
   if (M == 0 || N == 0) return PE_OK;
   if ((K & 3) || (lda & 3) || (ldb & 3) || (reinterpret_cast<uintptr_t>(A) & (4 * sizeof(TA) - 1)) || !aligned16(B))
     return PE_E_UNSUPPORTED;
+  // the operand loaders address a tile's rows through 32-bit buffer offsets (gemm_engine.h, RowLoaderT)
+  if (lda < 0 || ldb < 0 || lda >= (1L << 21) || ldb >= (1L << 21)) return PE_E_UNSUPPORTED;
   RowLoaderT<TA> al{A, lda, M, K, 0};
   RowLoader bl{B, ldb, N, K, 0};
   StoreEpiT<TA> ep{C, ldc, bias0, bias1, M, N, accumulate};
@@ -289,6 +291,7 @@ static int gemm_tn_impl(const TA* A, long lda, const TA* B, long ldb, float* C, 
   if ((M & 3) || (N & 3) || (lda & 3) || (ldb & 3) || (reinterpret_cast<uintptr_t>(A) & (4 * sizeof(TA) - 1)) ||
       (reinterpret_cast<uintptr_t>(B) & (4 * sizeof(TA) - 1)))
     return PE_E_UNSUPPORTED;
+  if (lda < 0 || ldb < 0 || lda >= (1L << 24) || ldb >= (1L << 24)) return PE_E_UNSUPPORTED;   // 32-bit offsets per k-tile
   hipStream_t st = pe_stream(stream);
   if (M <= 64 && N <= 64)
     return launch_tn<64, 64, MODE, TA>(A, lda, B, ldb, C, ldc, M, N, K, accumulate, workspace, workspace_bytes, st, amax_a,

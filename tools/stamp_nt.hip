@@ -9,7 +9,7 @@
 #include "../pitchextractor_amd/csrc/gemm_engine.h"
 using namespace pe;
 
-enum { kFull = 0, kNoLoads = 1, kNoStage = 2, kNoFrag = 3, kNoMfma = 4, kNoSplit = 5, kSameTile = 6 };
+enum { kFull = 0, kNoLoads = 1, kNoStage = 2, kNoFrag = 3, kNoMfma = 4, kNoSplit = 5, kSameTile = 6, kShape16 = 7 };
 
 template <class TL, int AB, int OCC, int PAD = 0>
 __global__ __launch_bounds__(256, OCC) void nt_kernel(RowLoader al, RowLoader bl, float* out, int ldc, int K, int tiles_m,
@@ -90,7 +90,25 @@ __global__ __launch_bounds__(256, OCC) void nt_kernel(RowLoader al, RowLoader bl
           for (int c = 0; c < NT; ++c)
             fb[j][c] = *reinterpret_cast<const bf16x8*>(Bs + c * B_IMG + swz_off(wn * TL::WN + j * 32 + r, kk * 2 + h));
       }
-      if (AB != kNoMfma) {
+      if (AB == kShape16) {
+        // the same FLOPs on v_mfma_f32_16x16x32_f16 (two per 32x32x16; fragment registers reused as they are, so the
+        // VALUES are meaningless: a timing / power probe of the instruction shape only)
+        typedef float f4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int i = 0; i < TL::TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TL::TN; ++j)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+              const f16x8 av = __builtin_bit_cast(f16x8, fa[i][t == 0 ? 1 : 0]), bv = __builtin_bit_cast(f16x8, fb[j][t == 1 ? 1 : 0]);
+              f4 c0 = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+              f4 c1 = {acc[i][j][4], acc[i][j][5], acc[i][j][6], acc[i][j][7]};
+              c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, c0, 0, 0, 0);
+              c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, c1, 0, 0, 0);
+              acc[i][j][0] = c0[0]; acc[i][j][1] = c0[1]; acc[i][j][2] = c0[2]; acc[i][j][3] = c0[3];
+              acc[i][j][4] = c1[0]; acc[i][j][5] = c1[1]; acc[i][j][6] = c1[2]; acc[i][j][7] = c1[3];
+            }
+      } else if (AB != kNoMfma) {
 #pragma unroll
         for (int i = 0; i < TL::TM; ++i)
 #pragma unroll
@@ -367,14 +385,15 @@ template <class TL, int OCC>
 void sweep(const char* name, const float* A, const float* B, float* C, int M, int N, int K) {
   const double fl = 2.0 * M * N * K;
   const float tsame = run<TL, kSameTile, OCC>(A, B, C, M, N, K, 20);
+  const float t16 = run<TL, kShape16, OCC>(A, B, C, M, N, K, 20);
   const float t[6] = {run<TL, kFull, OCC>(A, B, C, M, N, K, 20), run<TL, kNoLoads, OCC>(A, B, C, M, N, K, 20),
                       run<TL, kNoStage, OCC>(A, B, C, M, N, K, 20), run<TL, kNoFrag, OCC>(A, B, C, M, N, K, 20),
                       run<TL, kNoMfma, OCC>(A, B, C, M, N, K, 20), run<TL, kNoSplit, OCC>(A, B, C, M, N, K, 20)};
   int occ = 0;
   hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, nt_kernel<TL, kFull, OCC>, 256, 0);
   printf("[%d WG/CU] ", occ);
-  printf("%-28s full %.3f ms (%.0f TF) | no global loads %.3f | no split+LDS stores %.3f | no fragment reads %.3f | no MFMA %.3f | stores without split %.3f | loads that always hit %.3f\n",
-         name, t[0], fl / t[0] * 1e-9, t[1], t[2], t[3], t[4], t[5], tsame);
+  printf("%-28s full %.3f ms (%.0f TF) | no global loads %.3f | no split+LDS stores %.3f | no fragment reads %.3f | no MFMA %.3f | stores without split %.3f | loads that always hit %.3f | 16x16x32 MFMA shape (same FLOPs) %.3f\n",
+         name, t[0], fl / t[0] * 1e-9, t[1], t[2], t[3], t[4], t[5], tsame, t16);
 }
 
 template <class TL>
