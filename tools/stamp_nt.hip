@@ -365,6 +365,102 @@ void run_slot(const char* name, const float* A, const float* B, float* C, int M,
   printf("%-44s %.3f ms (%.0f TF)  %d WG/CU  %s\n", name, ms, 2.0 * M * N * K / ms * 1e-9, occ, hipGetErrorString(hipGetLastError()));
 }
 
+
+// What pre-split operands would buy: both operands already stored as two fp16 planes per 32-k tile ([row][k-tile][hi 64 B |
+// lo 64 B]), staged by LDS-DMA (no VGPR round trip, no split, no ds_write), two LDS stages, one barrier per k-tile.
+// Values are whatever the buffers hold: a timing probe.
+template <class TL, int OCC>
+__global__ __launch_bounds__(256, OCC) void nt_dma_kernel(const uint4* __restrict__ Asp, const uint4* __restrict__ Bsp,
+                                                          float* out, int ldc, int M, int N, int K, int tiles_m,
+                                                          int tiles_n) {
+  constexpr int NT = 2;
+  constexpr int A_IMG = TL::BM * kBK, B_IMG = TL::BN * kBK;           // bf16 elements per term image
+  __shared__ __attribute__((aligned(16))) __bf16 As[2][NT * A_IMG];
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[2][NT * B_IMG];
+  const int tile_id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (tile_id / tiles_n) * TL::BM, n0 = (tile_id % tiles_n) * TL::BN;
+  f32x16 acc[TL::TM][TL::TN];
+  zero_acc<TL>(acc);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm = wv / TL::WAVES_N, wn = wv % TL::WAVES_N;
+  const int r = lane & 31, h = lane >> 5;
+  const int nk = K / kBK;
+  // a piece = 16 rows x 64 B of ONE term image = 1 KB per wave instruction; lane l -> row l / 4, slot l % 4, and it
+  // fetches the chunk that the swizzle puts into that slot
+  const long row_bytes = (long)nk * 128;                             // bytes per operand row in the split layout
+  const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(Asp) + (long)m0 * row_bytes / 16, 0, (unsigned)(TL::BM * row_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(Bsp) + (long)n0 * row_bytes / 16, 0, (unsigned)(TL::BN * row_bytes), 0x00020000);
+  const int prow = lane >> 2, slot = lane & 3;
+  constexpr int A_PIECES = TL::BM / 16 * NT, B_PIECES = TL::BN / 16 * NT;   // per k-tile
+  auto dma = [&](int buf, int kt) {
+    // pieces are dealt round-robin to the four waves
+#pragma unroll
+    for (int p = 0; p < (A_PIECES + 3) / 4; ++p) {
+      const int pc = p * 4 + wv;
+      if (pc < A_PIECES) {
+        const int c = pc % NT, rb = pc / NT, row = rb * 16 + prow;
+        const unsigned vo = (unsigned)(row * row_bytes + c * 64 + ((slot ^ ((row >> 2) & 3)) * 16));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (__attribute__((address_space(3))) void*)(As[buf] + c * A_IMG + rb * 16 * 32), 16, vo, (unsigned)(kt * 128), 0, 0);
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < (B_PIECES + 3) / 4; ++p) {
+      const int pc = p * 4 + wv;
+      if (pc < B_PIECES) {
+        const int c = pc % NT, rb = pc / NT, row = rb * 16 + prow;
+        const unsigned vo = (unsigned)(row * row_bytes + c * 64 + ((slot ^ ((row >> 2) & 3)) * 16));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (__attribute__((address_space(3))) void*)(Bs[buf] + c * B_IMG + rb * 16 * 32), 16, vo, (unsigned)(kt * 128), 0, 0);
+      }
+    }
+  };
+  dma(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                  // tile kt has landed everywhere; everyone is done with tile kt - 1
+    if (kt + 1 < nk) dma(buf ^ 1, kt + 1);
+#pragma unroll
+    for (int kk = 0; kk < kBK / 16; ++kk) {
+      bf16x8 fa[TL::TM][NT], fb[TL::TN][NT];
+#pragma unroll
+      for (int i = 0; i < TL::TM; ++i)
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+          fa[i][c] = *reinterpret_cast<const bf16x8*>(As[buf] + c * A_IMG + swz_off(wm * TL::WM + i * 32 + r, kk * 2 + h));
+#pragma unroll
+      for (int j = 0; j < TL::TN; ++j)
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+          fb[j][c] = *reinterpret_cast<const bf16x8*>(Bs[buf] + c * B_IMG + swz_off(wn * TL::WN + j * 32 + r, kk * 2 + h));
+#pragma unroll
+      for (int i = 0; i < TL::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TL::TN; ++j) acc[i][j] = mfma_terms<NT, false>(fa[i], fb[j], acc[i][j]);
+    }
+  }
+  for_each_acc<TL>(acc, [&](int rr, int cc, float v) { out[(long)(m0 + rr) * ldc + n0 + cc] = v; });
+}
+
+template <class TL, int OCC>
+void run_dma(const char* name, const float* A, const float* B, float* C, int M, int N, int K, int reps) {
+  // the fp32 buffers are simply reinterpreted: same bytes per element as two fp16 planes
+  const int tm = M / TL::BM, tn = N / TL::BN;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  auto go = [&]() { nt_dma_kernel<TL, OCC><<<tm * tn, 256>>>((const uint4*)A, (const uint4*)B, C, N, M, N, K, tm, tn); };
+  for (int w = 0; w < 2; ++w) go();
+  hipEventRecord(e0);
+  for (int w = 0; w < reps; ++w) go();
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, e0, e1);
+  ms /= reps;
+  int occ = 0;
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, nt_dma_kernel<TL, OCC>, 256, 0);
+  printf("%-44s %.3f ms (%.0f TF)  %d WG/CU  %s\n", name, ms, 2.0 * M * N * K / ms * 1e-9, occ, hipGetErrorString(hipGetLastError()));
+}
+
 template <class TL, int AB, int OCC, int PAD = 0>
 float run(const float* A, const float* B, float* C, int M, int N, int K, int reps) {
   RowLoader al{A, (long)K, M, K, 0}, bl{B, (long)K, N, K, 0};
@@ -413,6 +509,8 @@ int main() {
   for (auto& v : h) { s = s * 1664525u + 1013904223u; v = ((s >> 8) * (1.0f / 16777216.0f) - 0.5f) * 1e-3f; }
   hipMemcpy(A, h.data(), (size_t)M * K * 4, hipMemcpyHostToDevice);
   hipMemcpy(B, h.data(), (size_t)N * K * 4, hipMemcpyHostToDevice);
+  run_dma<Tile<128, 192, 2, 2>, 1>("pre-split operands by LDS-DMA, 128x192", A, B, C, M, N, K, 20);
+  run_dma<Tile<128, 128, 2, 2>, 1>("pre-split operands by LDS-DMA, 128x128", A, B, C, M, N, K, 20);
   run_slot<Tile<128, 192, 2, 2>, 1>("slotted 128x192", A, B, C, M, N, K, 20);
   run_slot<Tile<128, 192, 2, 2>, 1, 4096>("slotted 128x192, padded LDS", A, B, C, M, N, K, 20);
   one_wg<Tile<128, 192, 2, 2>>(A, B, C, M, N, K);
