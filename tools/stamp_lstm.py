@@ -12,6 +12,8 @@ from pitchextractor_amd import _lib, ops  # noqa: E402
 
 ops.FP32_MATMUL = "x3"
 _lib.load().pe_lstm_configure_stamps(1)
+if os.environ.get("PE_STAMP_BF16") == "1":      # the mixed-precision build (one bf16 term, bf16 tile exchange)
+    ops.matmul_bf16(True, "bf16").__enter__()
 
 dev = torch.device("cuda:0")
 B, T, H, NC = 256, 192, 384, 2
