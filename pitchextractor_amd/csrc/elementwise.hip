@@ -9,7 +9,7 @@
 namespace {
 using namespace pe;
 
-constexpr int kMaxPartials = 1024;
+constexpr int kMaxPartials = 4096;
 
 // ---------------------------------------------------------------- per-channel two-value reduction
 // Each thread owns one channel quad and every G-th pixel; sums are kept in double so the biased
@@ -141,15 +141,15 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const TA* __restri
                                                               unsigned* __restrict__ amax) {
   const int quads = C >> 2;
   const int Fout = Fin / pool;
-  const long total = n_out_pix * quads;
   float am = 0.f;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int q = (int)(i % quads);
-    const long op = i / quads;
+  // thread = (channel quad q, pixel lane g): a thread's quad never changes, so its per-channel vectors are loaded once,
+  // not per pixel (with bf16 tensors they were most of the bytes a thread requested); 256 / quads pixels per block and
+  // trip (C = 192: 5 pixels, 16 idle threads)
+  const int G = 256 / quads, q = threadIdx.x % quads, g = threadIdx.x / quads;
+  const float4 sc = *reinterpret_cast<const float4*>(scale + q * 4), sh = *reinterpret_cast<const float4*>(shift + q * 4);
+  for (long op = (long)blockIdx.x * G + g; g < G && op < n_out_pix; op += (long)gridDim.x * G) {
     const long row = op / Fout;
     const int fo = (int)(op % Fout);
-    const float4 sc = *reinterpret_cast<const float4*>(scale + q * 4);
-    const float4 sh = *reinterpret_cast<const float4*>(shift + q * 4);
     const TA* xp = x + ((row * Fin + (long)fo * pool) * C + q * 4);
     float4 m;
     for (int j = 0; j < pool; ++j) {
@@ -293,7 +293,8 @@ struct BnWindow {
 };
 
 template <int POOL, class TA>
-__device__ __forceinline__ void bn_window(const BnBwdArgsT<TA>& a, long item, int nwin, int c, BnWindow<POOL>& w) {
+__device__ __forceinline__ void bn_window(const BnBwdArgsT<TA>& a, long item, int nwin, int c, BnWindow<POOL>& w,
+                                          const float4& sc, const float4& sh) {
   const int Fout = a.Fin / POOL;
   const long row = item / nwin;
   const int wi = (int)(item - row * nwin);
@@ -308,8 +309,6 @@ __device__ __forceinline__ void bn_window(const BnBwdArgsT<TA>& a, long item, in
   }
   if (!real) return;
   const float4 dyv = ld4(a.dy + (row * Fout + wi) * a.lddy + a.coff + c);
-  const float4 sc = *reinterpret_cast<const float4*>(a.scale + c);
-  const float4 sh = *reinterpret_cast<const float4*>(a.shift + c);
   const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
   const float dys[4] = {dyv.x, dyv.y, dyv.z, dyv.w};
 #pragma unroll
@@ -330,12 +329,13 @@ __device__ __forceinline__ void bn_window(const BnBwdArgsT<TA>& a, long item, in
 template <int POOL, class TA>
 __global__ __launch_bounds__(256) void bn_bwd_partial_win_kernel(const BnBwdArgsT<TA> a, long n_items, int nwin,
                                                                  double* __restrict__ partial) {
+  const int c0 = (threadIdx.x % (a.C >> 2)) * 4;               // column_reduce2 hands this thread no other quad
+  const float4 mu = *reinterpret_cast<const float4*>(a.mean + c0), is = *reinterpret_cast<const float4*>(a.invstd + c0);
+  const float4 sc = *reinterpret_cast<const float4*>(a.scale + c0), sh = *reinterpret_cast<const float4*>(a.shift + c0);
   column_reduce2(
       [&](long item, int c, float4& s, float4& t) {
         BnWindow<POOL> w;
-        bn_window<POOL, TA>(a, item, nwin, c, w);
-        const float4 mu = *reinterpret_cast<const float4*>(a.mean + c);
-        const float4 is = *reinterpret_cast<const float4*>(a.invstd + c);
+        bn_window<POOL, TA>(a, item, nwin, c, w, sc, sh);
         s = make_float4(0.f, 0.f, 0.f, 0.f);
         t = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -354,18 +354,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_win_kernel(const BnBwdArgsT<
                                                                const float* __restrict__ c2, TA* __restrict__ dx,
                                                                unsigned* __restrict__ amax) {
   const int quads = a.C >> 2;
-  const long total = n_items * quads;
   float am = 0.f;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long item = i / quads;
-    const int c = (int)(i - item * quads) * 4;
+  const int G = 256 / quads, c = (threadIdx.x % quads) * 4, g = threadIdx.x / quads;     // see bn_act_pool_fwd_kernel
+  const float4 mu = *reinterpret_cast<const float4*>(a.mean + c), is = *reinterpret_cast<const float4*>(a.invstd + c);
+  const float4 sc = *reinterpret_cast<const float4*>(a.scale + c), sh = *reinterpret_cast<const float4*>(a.shift + c);
+  const float4 k1 = *reinterpret_cast<const float4*>(c1 + c), k2 = *reinterpret_cast<const float4*>(c2 + c);
+  for (long item = (long)blockIdx.x * G + g; g < G && item < n_items; item += (long)gridDim.x * G) {
     BnWindow<POOL> w;
-    bn_window<POOL, TA>(a, item, nwin, c, w);
-    const float4 mu = *reinterpret_cast<const float4*>(a.mean + c);
-    const float4 is = *reinterpret_cast<const float4*>(a.invstd + c);
-    const float4 sc = *reinterpret_cast<const float4*>(a.scale + c);
-    const float4 k1 = *reinterpret_cast<const float4*>(c1 + c);
-    const float4 k2 = *reinterpret_cast<const float4*>(c2 + c);
+    bn_window<POOL, TA>(a, item, nwin, c, w, sc, sh);
 #pragma unroll
     for (int j = 0; j < POOL; ++j) {
       if (j >= w.n) break;
@@ -570,10 +566,10 @@ int ew_grid(long total_threads) {
   return (int)g;
 }
 
-int reduce_grid(long n_pix, int C) {
+int reduce_grid(long n_pix, int C, int cap = 1024) {
   const int G = 256 / (C / 4);
   long g = (n_pix + G - 1) / G;
-  if (g > kMaxPartials) g = kMaxPartials;
+  if (g > cap) g = cap;
   if (g < 1) g = 1;
   return (int)g;
 }
@@ -713,7 +709,7 @@ static int bn_act_pool_fwd_impl(const TA* x, const float* scale, const float* sh
   if (!x || !scale || !shift || !y || rows <= 0 || Fin <= 0 || pool <= 0) return PE_E_ARG;
   if (!bn_channels_ok(C) || (ldy & 3) || (coff & 3)) return PE_E_UNSUPPORTED;
   const long n_out = rows * (Fin / pool);
-  hipLaunchKernelGGL(bn_act_pool_fwd_kernel<TA>, dim3(ew_grid(n_out * (C / 4))), dim3(256), 0, pe_stream(stream), x,
+  hipLaunchKernelGGL(bn_act_pool_fwd_kernel<TA>, dim3(ew_grid(pe_cdiv(n_out, 256 / (C / 4)) * 256L)), dim3(256), 0, pe_stream(stream), x,
                      scale, shift, slope, y, n_out, Fin, C, pool, ldy, coff, amax_out);
   PE_LAUNCH_CHECK();
   return PE_OK;
@@ -749,7 +745,10 @@ static int bn_act_pool_bwd_impl(const TA* x, const TA* dy, const float* scale, c
   const long n_items = rows * nwin;
   const bool win = pool == 1 || pool == 2 || pool == 4;
   if (!win && !std::is_same<TA, float>::value) return PE_E_UNSUPPORTED;      // other pool widths: fp32 tensors only
-  const int grid = reduce_grid(win ? n_items : a.n_in_pix, C);
+  // bf16 tensors without pooling: 8-byte requests, so four times the workgroups keep the same bytes in flight
+  // (partial<1>: 348 -> 257 us; the pooled forms and fp32 tensors, at HBM speed with 1024, lose 5-10 % with more)
+  const int grid = reduce_grid(win ? n_items : a.n_in_pix, C,
+                               (!std::is_same<TA, float>::value && pool == 1) ? kMaxPartials : 1024);
   if (pool == 1)
     hipLaunchKernelGGL((bn_bwd_partial_win_kernel<1, TA>), dim3(grid), dim3(256), reduce_lds(C), st, a, n_items, nwin, partial);
   else if (pool == 2)
@@ -762,7 +761,7 @@ static int bn_act_pool_bwd_impl(const TA* x, const TA* dy, const float* scale, c
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pe_cdiv(C, 4)), dim3(256), 0, st, partial, grid, a.n_in_pix, C,
                      dgamma, dbeta, c1, c2);
   PE_LAUNCH_CHECK();
-  const int agrid = ew_grid((win ? n_items : a.n_in_pix) * (C / 4));
+  const int agrid = win ? ew_grid(pe_cdiv(n_items, 256 / (C / 4)) * 256L) : ew_grid(a.n_in_pix * (C / 4));
   if (pool == 1)
     hipLaunchKernelGGL((bn_bwd_apply_win_kernel<1, TA>), dim3(agrid), dim3(256), 0, st, a, n_items, nwin, c1, c2, dx,
                        amax_out);
