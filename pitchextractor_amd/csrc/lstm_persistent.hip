@@ -1269,6 +1269,7 @@ static int lstm_fwd_persistent_impl(int terms, int ncells, const float* const* w
   PE_CHECK_HIP(hipMemsetAsync(sync + kCtrStride, 0, (size_t)(sync_words(ncells, B) - kCtrStride) * 4, st));
   const int grid = ncells * ((B + 63) / 64) * (H / 32);
   if (terms == 3 && g_lstm_stamps && grid <= 128) return launch_fwd_v2<384, 3, 4, true>(cells, grid, B, T, ldy, sync, st);
+  if (terms == 1 && g_lstm_stamps && grid <= 128) return launch_fwd_v2<384, 1, 6, true>(cells, grid, B, T, ldy, sync, st);
   return terms == 3 ? launch_fwd_v2<384, 3, 4>(cells, grid, B, T, ldy, sync, st)
                     : launch_fwd_v2<384, 1, 6>(cells, grid, B, T, ldy, sync, st);
 }
@@ -1300,6 +1301,7 @@ static int lstm_bwd_persistent_impl(int terms, int ncells, const float* const* w
   PE_CHECK_HIP(hipMemsetAsync(sync + kXchgWord, 0, (size_t)ncells * ((B + 63) / 64) * 128 * sizeof(unsigned), st));
   const int grid = ncells * ((B + 63) / 64) * (H / 32);
   if (terms == 3 && g_lstm_stamps && grid <= 128) return launch_bwd_v2<384, 3, 8, true>(cells, grid, B, T, lddy, sync, st);
+  if (terms == 1 && g_lstm_stamps && grid <= 128) return launch_bwd_v2<384, 1, 24, true>(cells, grid, B, T, lddy, sync, st);
   return terms == 3 ? launch_bwd_v2<384, 3, 8>(cells, grid, B, T, lddy, sync, st)
                     : launch_bwd_v2<384, 1, 24>(cells, grid, B, T, lddy, sync, st);
 }
