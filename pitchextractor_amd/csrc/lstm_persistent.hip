@@ -980,7 +980,10 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_persistent_ks_kernel(const PB
   // inputs from the start, the wait for the peers in the middle, their tiles right behind it -- early enough that
   // they have landed when the last tile store is drained.  A column block's tile stores likewise go out one per
   // group of the next block.
-  constexpr int LPOLL = NBW >= 3 ? (2 * NBK) / 3 : (NBW / 2) * NKB + NKB / 2;   // MFMA group in front of which the wait sits
+  // MFMA group in front of which the wait sits.  One-term build: a group is ONE MFMA, the whole product is shorter than
+  // the hand-off it should cover (stamps: 2.6 k of an item's 7.6 k cycles in the poll), so the wait goes as late as the
+  // tile requests behind it allow (16 -> 22 of 24: backward 1.73 -> 1.64 ms per layer, interleaved on two boxes)
+  constexpr int LPOLL = TERMS == 1 ? NBK - 2 : NBW >= 3 ? (2 * NBK) / 3 : (NBW / 2) * NKB + NKB / 2;
   constexpr int LPEEK = LPOLL >= 4 ? LPOLL - 4 : 0;
   constexpr int LSPAN = (NBK - LPOLL) / 2 > 0 ? (NBK - LPOLL) / 2 : 1;  // groups that carry tile requests
   constexpr int LPER = (NJ + LSPAN - 1) / LSPAN;                        // tile requests per group

@@ -6,6 +6,8 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from pitchextractor_amd import ops
 dev = torch.device("cuda:0")
+if os.environ.get("PE_BENCH_BF16") == "1":      # the mixed-precision build of the recurrences
+    ops.matmul_bf16(True, "bf16").__enter__()
 B, T, H = 256, 192, 384
 whh = [torch.randn(4 * H, H, device=dev) * 0.05 for _ in range(4)]
 ys = [torch.empty(B, T, 2 * H, device=dev) for _ in range(2)]
