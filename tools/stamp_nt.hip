@@ -9,14 +9,17 @@
 #include "../pitchextractor_amd/csrc/gemm_engine.h"
 using namespace pe;
 
+#ifndef STAMP_NT
+#define STAMP_NT 2          // operand terms: 2 = h2 (two fp16 terms, 3 MFMAs per block), 1 = one rounded bf16 term
+#endif
 enum { kFull = 0, kNoLoads = 1, kNoStage = 2, kNoFrag = 3, kNoMfma = 4, kNoSplit = 5, kSameTile = 6, kShape16 = 7 };
 
 template <class TL, int AB, int OCC, int PAD = 0>
 __global__ __launch_bounds__(256, OCC) void nt_kernel(RowLoader al, RowLoader bl, float* out, int ldc, int K, int tiles_m,
                                                       int tiles_n, float sa, float sb) {
-  constexpr int NT = 2;
-  __shared__ __attribute__((aligned(16))) float As_f[TL::BM * (2 * kBK / 2)];
-  __shared__ __attribute__((aligned(16))) float Bs_f[TL::BN * (2 * kBK / 2)];
+  constexpr int NT = STAMP_NT;
+  __shared__ __attribute__((aligned(16))) float As_f[TL::BM * (STAMP_NT * kBK / 2)];
+  __shared__ __attribute__((aligned(16))) float Bs_f[TL::BN * (STAMP_NT * kBK / 2)];
   __shared__ float pad_lds[PAD + 1];
   if (PAD > 0 && K < 0) pad_lds[threadIdx.x] = 1.f;
   const int tile_id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(256, OCC) void nt_kernel(RowLoader al, RowLoader bl
     if (AB != kNoStage) {
 #pragma unroll
       for (int i = 0; i < TL::A_LOADS; ++i) {
-        if (AB == kNoSplit) {
+        if (AB == kNoSplit && NT == 2) {
           const int off = swz_off(srow + 32 * i, piece >> 1) + (piece & 1) * 4;
           *reinterpret_cast<uint2*>(As + off) = make_uint2(__float_as_uint(ra[i].x), __float_as_uint(ra[i].y));
           *reinterpret_cast<uint2*>(As + off + A_IMG) = make_uint2(__float_as_uint(ra[i].z), __float_as_uint(ra[i].w));
@@ -62,7 +65,7 @@ __global__ __launch_bounds__(256, OCC) void nt_kernel(RowLoader al, RowLoader bl
       }
 #pragma unroll
       for (int i = 0; i < TL::B_LOADS; ++i) {
-        if (AB == kNoSplit) {
+        if (AB == kNoSplit && NT == 2) {
           const int off = swz_off(srow + 32 * i, piece >> 1) + (piece & 1) * 4;
           *reinterpret_cast<uint2*>(Bs + off) = make_uint2(__float_as_uint(rb[i].x), __float_as_uint(rb[i].y));
           *reinterpret_cast<uint2*>(Bs + off + B_IMG) = make_uint2(__float_as_uint(rb[i].z), __float_as_uint(rb[i].w));
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(256, OCC) void nt_kernel(RowLoader al, RowLoader bl
           for (int c = 0; c < NT; ++c)
             fb[j][c] = *reinterpret_cast<const bf16x8*>(Bs + c * B_IMG + swz_off(wn * TL::WN + j * 32 + r, kk * 2 + h));
       }
-      if (AB == kShape16) {
+      if constexpr (AB == kShape16 && NT == 2) {
         // the same FLOPs on v_mfma_f32_16x16x32_f16 (two per 32x32x16; fragment registers reused as they are, so the
         // VALUES are meaningless: a timing / power probe of the instruction shape only)
         typedef float f4 __attribute__((ext_vector_type(4)));
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256, OCC) void nt_kernel(RowLoader al, RowLoader bl
 template <class TL, int OCC, int IL>
 __global__ __launch_bounds__(256, OCC) void nt_ov_kernel(RowLoader al, RowLoader bl, float* out, int ldc, int K,
                                                          int tiles_m, int tiles_n, float sa, float sb) {
-  constexpr int NT = 2;
+  constexpr int NT = STAMP_NT;
   constexpr int A_IMG = TL::BM * kBK, B_IMG = TL::BN * kBK;
   __shared__ __attribute__((aligned(16))) __bf16 As[2][NT * A_IMG];
   __shared__ __attribute__((aligned(16))) __bf16 Bs[2][NT * B_IMG];
@@ -232,12 +235,13 @@ void run_ov(const char* name, const float* A, const float* B, float* C, int M, i
 }
 
 
+#if STAMP_NT == 2
 // Hand-ordered version of the same loop: one MFMA per slot, the slot's share of the next tile's staging behind it, a
 // scheduling fence after every slot.
 template <class TL, int OCC, int PAD = 0>
 __global__ __launch_bounds__(256, OCC) void nt_slot_kernel(RowLoader al, RowLoader bl, float* out, int ldc, int K,
                                                            int tiles_m, int tiles_n, float sa, float sb) {
-  constexpr int NT = 2;
+  constexpr int NT = STAMP_NT;
   constexpr int A_IMG = TL::BM * kBK, B_IMG = TL::BN * kBK;
   constexpr int NQ = TL::A_LOADS + TL::B_LOADS;            // operand quads per thread and k-tile
   constexpr int NB = TL::TM * TL::TN;                      // accumulator blocks
@@ -373,7 +377,7 @@ template <class TL, int OCC>
 __global__ __launch_bounds__(256, OCC) void nt_dma_kernel(const uint4* __restrict__ Asp, const uint4* __restrict__ Bsp,
                                                           float* out, int ldc, int M, int N, int K, int tiles_m,
                                                           int tiles_n) {
-  constexpr int NT = 2;
+  constexpr int NT = STAMP_NT;
   constexpr int A_IMG = TL::BM * kBK, B_IMG = TL::BN * kBK;           // bf16 elements per term image
   __shared__ __attribute__((aligned(16))) __bf16 As[2][NT * A_IMG];
   __shared__ __attribute__((aligned(16))) __bf16 Bs[2][NT * B_IMG];
@@ -461,6 +465,8 @@ void run_dma(const char* name, const float* A, const float* B, float* C, int M, 
   printf("%-44s %.3f ms (%.0f TF)  %d WG/CU  %s\n", name, ms, 2.0 * M * N * K / ms * 1e-9, occ, hipGetErrorString(hipGetLastError()));
 }
 
+#endif
+
 template <class TL, int AB, int OCC, int PAD = 0>
 float run(const float* A, const float* B, float* C, int M, int N, int K, int reps) {
   RowLoader al{A, (long)K, M, K, 0}, bl{B, (long)K, N, K, 0};
@@ -509,6 +515,15 @@ int main() {
   for (auto& v : h) { s = s * 1664525u + 1013904223u; v = ((s >> 8) * (1.0f / 16777216.0f) - 0.5f) * 1e-3f; }
   hipMemcpy(A, h.data(), (size_t)M * K * 4, hipMemcpyHostToDevice);
   hipMemcpy(B, h.data(), (size_t)N * K * 4, hipMemcpyHostToDevice);
+#if STAMP_NT == 1
+  // one rounded bf16 term per operand (the mixed-precision GEMMs): a third of the matrix work, same staging
+  sweep<Tile<128, 192, 2, 2>, 2>("1 term, 128x192, 2 WG/CU", A, B, C, M, N, K);
+  run_ov<Tile<128, 192, 2, 2>, 1, 0>("1 term, one barrier / two stages 128x192", A, B, C, M, N, K, 20);
+  run_ov<Tile<128, 192, 2, 2>, 1, 3>("1 term, one barrier, pipelined 128x192", A, B, C, M, N, K, 20);
+  sweep<Tile<128, 128, 2, 2>, 3>("1 term, 128x128, 3 WG/CU", A, B, C, M, N, K);
+  run_ov<Tile<128, 128, 2, 2>, 1, 0>("1 term, one barrier / two stages 128x128", A, B, C, M, N, K, 20);
+  return 0;
+#else
   run_dma<Tile<128, 192, 2, 2>, 1>("pre-split operands by LDS-DMA, 128x192", A, B, C, M, N, K, 20);
   run_dma<Tile<128, 128, 2, 2>, 1>("pre-split operands by LDS-DMA, 128x128", A, B, C, M, N, K, 20);
   run_slot<Tile<128, 192, 2, 2>, 1>("slotted 128x192", A, B, C, M, N, K, 20);
@@ -522,5 +537,6 @@ int main() {
   sweep<Tile<128, 192, 2, 2>, 1>("128x192, launch bound 1", A, B, C, M, N, K);
   sweep<Tile<128, 128, 2, 2>, 3>("128x128, 3 WG/CU", A, B, C, M, N, K);
   sweep<Tile<256, 64, 4, 1>, 2>("256x64", A, B, C, M, N, K);
+#endif
   return 0;
 }
