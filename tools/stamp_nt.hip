@@ -520,6 +520,8 @@ int main() {
   sweep<Tile<128, 192, 2, 2>, 2>("1 term, 128x192, 2 WG/CU", A, B, C, M, N, K);
   run_ov<Tile<128, 192, 2, 2>, 1, 0>("1 term, one barrier / two stages 128x192", A, B, C, M, N, K, 20);
   run_ov<Tile<128, 192, 2, 2>, 1, 3>("1 term, one barrier, pipelined 128x192", A, B, C, M, N, K, 20);
+  sweep<Tile<128, 384, 2, 2>, 1>("1 term, 128x384", A, B, C, M, N, K);
+  sweep<Tile<256, 192, 4, 1>, 1>("1 term, 256x192 (4x1 waves)", A, B, C, M, N, K);
   sweep<Tile<128, 128, 2, 2>, 3>("1 term, 128x128, 3 WG/CU", A, B, C, M, N, K);
   run_ov<Tile<128, 128, 2, 2>, 1, 0>("1 term, one barrier / two stages 128x128", A, B, C, M, N, K, 20);
   return 0;
